@@ -1,0 +1,143 @@
+/*
+ * pfc.h — C ABI of libpfc_hip: the MI355X (gfx950) implementation of PressureFieldContact.jl's per-contact-pair
+ * hot path (OBB-BVH culling -> tet/triangle clipping -> pressure + friction wrench integration).
+ *
+ * The reference (pure Julia) has no FFI for this path; its only substitution hook is the `de::Function` field of
+ * MechanismScenario (src/mechanism_scenario.jl:175,181, invoked at src/radau/radau_functions.jl:9,67).  A
+ * replacement `calcXd_hip!` is calcXd! (src/contact_algorithms_non_friction.jl:18-38) with
+ * `forceAllElasticIntersections!` (:60-68) replaced by ONE call of pfc_eval() for all contact instructions; the
+ * Julia `ccall` stubs are in INTEGRATION.md.  Each entry point below names the reference code it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - All indices crossing the ABI are 0-based (the Julia shim subtracts 1).
+ *   - All matrices are column-major (Julia / StaticArrays order).
+ *   - Host-pointer entry points copy in/out; the caller owns its buffers.  The library owns all device memory.
+ *   - Every function returns a pfc_status (0 = ok, >0 = error) unless documented to return an id or a count
+ *     (>= 0) in which case errors are returned as -(pfc_status).
+ *   - A handle is not re-entrant (the reference scenario is not either: shared m.TT_Cache / tm.bodyBodyCache,
+ *     src/contact_algorithms_non_friction.jl:95,120); different handles may be used from different threads.
+ *   - The library never falls back to a CPU path: without a usable HIP device pfc_create() fails.
+ */
+#ifndef PFC_H
+#define PFC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFC_VERSION 100
+#define PFC_INTERNAL_NODE (-9999) /* leaf sentinel of internal nodes: src/obb/tree_types.jl:11,56 */
+
+typedef enum {
+    PFC_OK = 0,
+    PFC_ERR_NONFINITE = 1, /* error("Non-finite vertex likely"): src/clip/static_clip.jl:52 ; singular tet */
+    PFC_ERR_OVERFLOW = 2,  /* a device work list overflowed; capacities were grown, re-issue the evaluation */
+    PFC_ERR_BAD_ARG = 3,   /* bad id / size / NULL pointer; "something is wrong": src/clip/static_clip.jl:13 */
+    PFC_ERR_NOMEM = 4,
+    PFC_ERR_HIP = 5,       /* HIP runtime failure, see pfc_last_error() */
+    PFC_ERR_STATE = 6,     /* call order violated (e.g. add_mesh after finalize) */
+    PFC_ERR_INVERTED_TET = 7 /* error("inverted tetrahedron"): src/geometry/mesh.jl:28 */
+} pfc_status;
+
+typedef enum { PFC_REGULARIZED = 0, PFC_BRISTLE = 1 } pfc_friction_model;
+
+typedef struct pfc_context *pfc_handle;
+
+/* Library/ABI version (PFC_VERSION of the build). */
+int pfc_version(void);
+
+/* MechanismScenario() (src/mechanism_scenario.jl:181-198): creates an empty scenario bound to HIP device
+ * `device`.  Fails with PFC_ERR_HIP when no device is usable. */
+int pfc_create(int device, pfc_handle *out);
+void pfc_destroy(pfc_handle h);
+const char *pfc_last_error(pfc_handle h);
+
+/*
+ * add_contact! -> MeshCache(name, eMesh, tree, body, c_prop) -> addMesh! (src/mechanism_scenario.jl:298-314,258;
+ * src/structs.jl:33-45).  Uploads one eMesh (src/geometry/mesh.jl:10-46) and its flattened bin_BB_Tree{OBB}
+ * (src/obb/tree_types.jl:1-16, src/obb/box_types.jl:4-9).  Exactly one of tri / tet is non-NULL.
+ *   xyz      n_pt x 3        vertex coordinates in the mesh frame
+ *   tri      n_tri x 3       (or NULL)      tet  n_tet x 4 (or NULL)      eps  n_pt (tet meshes only)
+ *   Ebar     ContactProperties.Ē (tet meshes; ignored for tri meshes)
+ *   nodes    n_node entries, node 0 = root: c (x3), e (x3), R (x9 column-major), child (x2), leaf (element index,
+ *            or PFC_INTERNAL_NODE)
+ * Returns the mesh id (>= 0) or -(pfc_status).
+ */
+int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int *tri, int n_tet, const int *tet,
+                 const double *eps, double Ebar, int n_node, const double *node_c, const double *node_e,
+                 const double *node_R, const int *node_child, const int *node_leaf);
+
+/*
+ * add_friction_regularize! / add_friction_bristle! -> ContactInstructions (src/mechanism_scenario.jl:365-416,
+ * :36-49).  id_1 is the triangle mesh (or a tet mesh), id_2 is always a tet mesh (:402-416).
+ *   params (PFC_REGULARIZED): [mu_s, mu_d, v_tol]                       (Regularized, :22-34)
+ *   params (PFC_BRISTLE):     [mu_s, mu_d, tau, k_bar, magic]           (Bristle, :5-20)
+ * n_quad in {1, 2} (:45).  Returns the instruction id (>= 0) or -(pfc_status).
+ */
+int pfc_add_instruction(pfc_handle h, int id_1, int id_2, double chi, int n_quad, int model, const double *params);
+
+/* finalize! (src/mechanism_scenario.jl:206-231): meshes and instructions become immutable, device tables are
+ * built (per-tet zeta transforms of calc_ζ_transforms, src/contact_algorithms_non_friction.jl:158-162, are
+ * precomputed here because meshes never change afterwards). */
+int pfc_finalize(pfc_handle h);
+
+/*
+ * forceAllElasticIntersections! minus the RigidBodyDynamics parts (src/contact_algorithms_non_friction.jl:60-84):
+ * evaluates n_items (instruction, pose) items.  ins_ids == NULL means item i uses instruction i.
+ *   pose   n_items x 24  x_r2_r1 (R 9 col-major, t 3) then x_r1_r2 (R 9, t 3)   (refreshBodyBodyTransform!, :103-115)
+ *   twist  n_items x 6   twist_r2_r1_r2 = [angular; linear]                     (refreshBodyBodyCache!, :125-128)
+ *   s      n_items x 6   bristle deflection state (ignored for regularized items; may be NULL if none is bristle)
+ *   wrench n_items x 6   OUT wrench on body 2 in frame r2 about its origin, [angular; linear]; zeros if no contact
+ *   sdot   n_items x 6   OUT bristle state derivative (friction.jl:134; no contact: -s/tau, :77-81); zeros if regularized
+ *   counts n_items x 4   OUT {OBB node tests, candidate pairs, pairs with a non-empty polygon, traction points}
+ *                        (may be NULL)
+ * Synchronous.  Work-list overflows are handled internally (grow + re-run), mirroring VectorCache doubling
+ * (src/obb/vector_cache.jl:13-17).
+ */
+int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, const double *twist,
+             const double *s, double *wrench, double *sdot, int *counts);
+
+/*
+ * Same evaluation with every buffer resident in device memory (HBM) and no host synchronisation: kernels are
+ * enqueued on `stream` (a hipStream_t; NULL = the handle's own stream).  d_ins_ids may be NULL.  Call
+ * pfc_check() afterwards: it synchronises and returns PFC_ERR_OVERFLOW (after growing the work lists) if the
+ * evaluation must be re-issued.
+ */
+int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
+                    const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, void *stream);
+int pfc_check(pfc_handle h);
+
+/* Options: "debug" (1: keep per-pair clip counts and materialise traction points of every item so that the
+ * pfc_debug_* calls work), "profile" (1: bracket each stage with HIP events), "max_levels" (0 = automatic). */
+int pfc_set_option(pfc_handle h, const char *name, long long value);
+
+/* Totals of the last checked evaluation: out[0..7] = {node tests, candidate pairs, non-empty pairs, traction
+ * points, broadphase levels launched, frontier peak, status word, n_items}. */
+int pfc_get_stats(pfc_handle h, long long *out8);
+
+/* Per-stage device time of the last evaluation in ms (profile option): out[0..5] = {setup, broadphase,
+ * narrowphase, bristle passes (cop + K + eigen + friction), finalisation, total}.  Synchronises. */
+int pfc_get_stage_ms(pfc_handle h, float *out6);
+
+/*
+ * Debug views of the last evaluation (debug option), needed to restate test/test_normal.jl:31-41 and
+ * test/test_friction.jl:228-236,251-256 which read m.float.bodyBodyCache.{TractionCache,spatialStiffness}:
+ *   pfc_debug_pairs       candidate (i_1, i_2) pairs of an item (the TT_Cache contents, order unspecified) and the
+ *                         vertex count of each clipped polygon; returns the number of pairs of that item
+ *   pfc_debug_tractions   TractionCache entries of an item, 8 doubles each: n(3) r(3) dA p
+ *   pfc_debug_stiffness   spatialStiffness of a bristle item: K, K̄^{-1/2} (column-major 6x6), S^{-1}, and the cop
+ * Each returns a count (>= 0) or -(pfc_status); if the count exceeds cap only cap entries were written.
+ */
+int pfc_debug_pairs(pfc_handle h, int item, int *pairs, int *clip_n, int cap);
+int pfc_debug_tractions(pfc_handle h, int item, double *buf, int cap);
+int pfc_debug_stiffness(pfc_handle h, int item, double *K36, double *Kbar_inv_sqrt36, double *Sinv6, double *cop3);
+
+/* Device arithmetic self-test: out[0..n) = x/y, out[n..2n) = sqrt(|x|), out[2n..3n) = fma(x, y, x) computed on the
+ * GPU, so tests can check that device division / sqrt / fma are correctly rounded (bitwise = host). */
+int pfc_selftest_math(pfc_handle h, int n, const double *x, const double *y, double *out3n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

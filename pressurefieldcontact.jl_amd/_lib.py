@@ -1,0 +1,82 @@
+"""ctypes binding of csrc/libpfc_hip.so (the C ABI of include/pfc.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is usable, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libpfc_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"]
+
+OK, ERR_NONFINITE, ERR_OVERFLOW, ERR_BAD_ARG, ERR_NOMEM, ERR_HIP, ERR_STATE, ERR_INVERTED_TET = range(8)
+STATUS_NAMES = {0: "PFC_OK", 1: "PFC_ERR_NONFINITE", 2: "PFC_ERR_OVERFLOW", 3: "PFC_ERR_BAD_ARG", 4: "PFC_ERR_NOMEM",
+                5: "PFC_ERR_HIP", 6: "PFC_ERR_STATE", 7: "PFC_ERR_INVERTED_TET"}
+REGULARIZED, BRISTLE = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+# every symbol include/pfc.h declares: (restype, argtypes)
+SIGNATURES = {
+    "pfc_version": (C.c_int, []),
+    "pfc_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "pfc_destroy": (None, [C.c_void_p]),
+    "pfc_last_error": (C.c_char_p, [C.c_void_p]),
+    "pfc_add_mesh": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _ip, C.c_int, _ip, _dp, C.c_double, C.c_int,
+                               _dp, _dp, _dp, _ip, _ip]),
+    "pfc_add_instruction": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _dp]),
+    "pfc_finalize": (C.c_int, [C.c_void_p]),
+    "pfc_eval": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "pfc_eval_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pfc_check": (C.c_int, [C.c_void_p]),
+    "pfc_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong]),
+    "pfc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
+    "pfc_get_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "pfc_debug_pairs": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.c_int]),
+    "pfc_debug_tractions": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int]),
+    "pfc_debug_stiffness": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]),
+    "pfc_selftest_math": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
+}
+
+
+class PFCError(RuntimeError):
+    def __init__(self, status: int, message: str = ""):
+        self.status = status
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/pfc_hip.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("pfc_hip.hip", "pfc_kernels.h")]
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "pfc.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        cmd = [HIPCC] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0]]
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libpfc_hip.so; raises (never falls back) if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback for the contact hot path")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)       # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

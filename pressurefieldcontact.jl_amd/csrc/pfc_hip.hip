@@ -1,0 +1,1382 @@
+// pfc_hip.hip — kernels and C ABI of libpfc_hip (MI355X / gfx950).  See include/pfc.h and DESIGN.md.
+//
+// Evaluation pipeline (one stream, no host synchronisation between stages):
+//   k_setup_items   per item: ItemRec from (instruction, pose, twist, s); seeds the broadphase frontier with the
+//                   (root, root) node pair; clears the per-item accumulators
+//   k_bp_expand     level-synchronous dual-tree descent over ALL items at once: one lane per (item, node_a,
+//                   node_b) frontier entry, 15-axis SAT, children / leaf pairs appended with wave-aggregated
+//                   (ballot + mbcnt prefix) atomics                      [tree_tree_intersect, tree_types.jl:88]
+//   k_narrow        one lane per candidate (triangle, tet) pair: gather 96 B + 256 B records, transform to tet
+//                   coordinates, trivial reject in registers, Sutherland-Hodgman clip with the polygon staged in
+//                   LDS ([slot][coord][lane] layout: conflict-free per-lane dynamic indexing), fan quadrature,
+//                   pressure; regularized friction fused, bristle items materialise traction points (SoA)
+//   k_cop, k_stiff, k_eig, k_fric   the bristle model's dependent reductions and the 6x6 symmetric eigen solve
+//   k_final         per item: wrench, sdot, counts
+#include "pfc_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pfc.h"
+
+namespace pfc {
+
+// =================================================================================================================
+// mesh preparation kernels (pfc_finalize)
+// =================================================================================================================
+__global__ void k_prep_tri(int n, const double *__restrict__ pt, const int *__restrict__ tri, TriRec *__restrict__ out) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    V3 a = ld3(pt + 3 * tri[3 * k]), b = ld3(pt + 3 * tri[3 * k + 1]), c = ld3(pt + 3 * tri[3 * k + 2]);
+    V3 nh = normalize(vector_area(a, b, c));  // triangleNormal, geometry_kernel.jl:10
+    TriRec r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = b.x; r.v[4] = b.y; r.v[5] = b.z;
+    r.v[6] = c.x; r.v[7] = c.y; r.v[8] = c.z; r.n[0] = nh.x; r.n[1] = nh.y; r.n[2] = nh.z;
+    out[k] = r;
+}
+
+__global__ void k_prep_tet(int n, const double *__restrict__ pt, const double *__restrict__ eps,
+                           const int *__restrict__ tet, TetRec *__restrict__ out, unsigned *status) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double A[16], e[4];
+    TetRec r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int v = tet[4 * k + j];
+        A[4 * j] = pt[3 * v]; A[4 * j + 1] = pt[3 * v + 1]; A[4 * j + 2] = pt[3 * v + 2]; A[4 * j + 3] = 1.0;
+        r.xrz[3 * j] = A[4 * j]; r.xrz[3 * j + 1] = A[4 * j + 1]; r.xrz[3 * j + 2] = A[4 * j + 2];
+        e[j] = eps[v];
+    }
+    double id = inv4(A, r.xzr);
+    if (!(__builtin_fabs(id) <= 1.79769313486231570815e308)) atomicOr(status, kStNonFinite);
+    // ϵ_r2 = ϵ2 * x_ζ2_r2 (1x4 times 4x4)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        r.epsr[j] = ((e[0] * r.xzr[4 * j] + e[1] * r.xzr[4 * j + 1]) + e[2] * r.xzr[4 * j + 2]) + e[3] * r.xzr[4 * j + 3];
+    out[k] = r;
+}
+
+// =================================================================================================================
+// per-evaluation setup
+// =================================================================================================================
+struct EvalArgs {
+    int n_items;
+    const int *ins_ids;      // may be null
+    const double *pose, *twist, *s;
+    const InsDev *ins;
+    const MeshDev *meshes;
+    int n_ins;
+    ItemRec *items;
+    WorkRec *frontier0;
+    int *fcount;             // [max_levels + 2]
+    double *acc;             // n_items x kAccStride
+    int *icnt;               // n_items x 4
+    unsigned *status;
+};
+
+__global__ void k_setup_items(EvalArgs g) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n_items) return;
+    int id = g.ins_ids ? g.ins_ids[i] : i;
+    ItemRec r;
+    if (id < 0 || id >= g.n_ins) {
+        atomicOr(g.status, 16u);
+        id = 0;
+    }
+    const InsDev in = g.ins[id];
+    const MeshDev m1 = g.meshes[in.m1], m2 = g.meshes[in.m2];
+    const double *p = g.pose + 24 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { r.R21[k] = p[k]; r.R12[k] = p[12 + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.t21[k] = p[9 + k]; r.t12[k] = p[21 + k];
+        r.w[k] = g.twist[6 * (size_t)i + k]; r.v[k] = g.twist[6 * (size_t)i + 3 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r.s[k] = (g.s && in.model == PFC_BRISTLE) ? g.s[6 * (size_t)i + k] : 0.0;
+    r.chi = in.chi; r.Ebar = m2.Ebar;  // Ē of mesh_2 only: non_friction.jl:131
+    r.mu_s = in.mu_s; r.mu_d = in.mu_d; r.v_c = in.v_c; r.tau = in.tau; r.k_bar = in.k_bar; r.magic = in.magic;
+    r.nodes1 = m1.nodes; r.nodes2 = m2.nodes; r.tri = m1.tri; r.tet = m2.tet;
+    r.model = in.model; r.nq = (in.nq == 1) ? 1 : 3;  // quadrature POINTS of rule 1 / rule 2 (quadrature.jl:22,31)
+    r.ins = id; r.pad = 0;
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) finite &= (__builtin_fabs(p[k]) <= 1.79769313486231570815e308);
+    if (!finite) atomicOr(g.status, kStNonFinite);
+    g.items[i] = r;
+    WorkRec w;
+    w.item = i; w.a = 0; w.b = 0; w.pad = 0;
+    g.frontier0[i] = w;
+    for (int k = 0; k < kAccStride; ++k) g.acc[(size_t)i * kAccStride + k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.icnt[4 * (size_t)i + k] = 0;
+    if (i == 0) g.fcount[0] = g.n_items;
+}
+
+// =================================================================================================================
+// broadphase: one level of the simultaneous descent (src/obb/tree_types.jl:88-111)
+// =================================================================================================================
+struct BpArgs {
+    const ItemRec *items;
+    const WorkRec *fin;
+    WorkRec *fout;
+    WorkRec *cand;
+    int *fcount;     // fcount[level] = size of fin, fcount[level + 1] accumulates the size of fout
+    int *ccount;     // candidate counter
+    int *icnt;
+    unsigned *status;
+    int level, fcap, ccap;
+};
+
+__device__ __forceinline__ void count_per_item(int *icnt, int item, int slot, bool flag) {
+    // wave-aggregated per-item counter: one atomic per wave when the whole wave works on one item
+    unsigned long long m = __ballot(flag);
+    if (m == 0) return;
+    int first = __builtin_amdgcn_readfirstlane(item);
+    bool uni = __all(!flag || item == first);
+    if (uni) {
+        // `first` may belong to a lane without the flag; take the item of the lowest flagged lane instead
+        int src = __builtin_ctzll(m);
+        int it = __shfl(item, src, 64);
+        if (lane_id() == src) atomicAdd(&icnt[4 * (size_t)it + slot], __builtin_popcountll(m));
+    } else if (flag) {
+        atomicAdd(&icnt[4 * (size_t)item + slot], 1);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
+    const int n_in = g.fcount[g.level];
+    const int stride = gridDim.x * blockDim.x;
+    const int lane = lane_id();
+    // every lane of a wave runs the same number of iterations so the wave-level ballots are well defined
+    const int n_round = (n_in + stride - 1) / stride;
+    for (int rd = 0; rd < n_round; ++rd) {
+        int idx = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool active = idx < n_in;
+        WorkRec w;
+        w.item = 0; w.a = 0; w.b = 0; w.pad = 0;
+        bool hit = false, la = false, lb = false;
+        int ca0 = 0, ca1 = 0, cb0 = 0, cb1 = 0, leaf_a = 0, leaf_b = 0;
+        if (active) {
+            w = g.fin[idx];
+            const ItemRec *it = g.items + w.item;
+            const NodeRec a = it->nodes1[w.a];
+            const NodeRec b = it->nodes2[w.b];
+            hit = bb_bb_intersect(a, b, it->R12, it->t12);
+            la = a.leaf != kInternal; lb = b.leaf != kInternal;
+            ca0 = a.child0; ca1 = a.child1; cb0 = b.child0; cb1 = b.child1;
+            leaf_a = a.leaf; leaf_b = b.leaf;
+        }
+        count_per_item(g.icnt, w.item, 0, active);
+        bool is_cand = hit && la && lb;
+        bool two = hit && (la != lb);
+        bool four = hit && !la && !lb;
+        unsigned long long mc = __ballot(is_cand), m2 = __ballot(two), m4 = __ballot(four);
+        // candidates
+        if (mc) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(g.ccount, __builtin_popcountll(mc));
+            base = __shfl(base, 0, 64);
+            if (is_cand) {
+                int pos = base + prefix_count(mc);
+                if (pos < g.ccap) {
+                    WorkRec c;
+                    c.item = w.item; c.a = leaf_a; c.b = leaf_b; c.pad = 0;
+                    g.cand[pos] = c;
+                } else {
+                    atomicOr(g.status, kStCandOvf);
+                }
+            }
+            count_per_item(g.icnt, w.item, 1, is_cand);
+        }
+        // children
+        if (m2 | m4) {
+            int tot = 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&g.fcount[g.level + 1], tot);
+            base = __shfl(base, 0, 64);
+            int pos = base + 2 * prefix_count(m2) + 4 * prefix_count(m4);
+            int nout = two ? 2 : (four ? 4 : 0);
+            if (nout) {
+                if (pos + nout <= g.fcap) {
+                    WorkRec c;
+                    c.item = w.item; c.pad = 0;
+                    if (two) {
+                        if (la) {  // leaf_1: descend tree_2 (:97-98)
+                            c.a = w.a; c.b = cb0; g.fout[pos] = c;
+                            c.b = cb1; g.fout[pos + 1] = c;
+                        } else {   // leaf_2: descend tree_1 (:101-103)
+                            c.b = w.b; c.a = ca0; g.fout[pos] = c;
+                            c.a = ca1; g.fout[pos + 1] = c;
+                        }
+                    } else {       // (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107)
+                        c.a = ca0; c.b = cb0; g.fout[pos] = c;
+                        c.a = ca1; c.b = cb0; g.fout[pos + 1] = c;
+                        c.a = ca0; c.b = cb1; g.fout[pos + 2] = c;
+                        c.a = ca1; c.b = cb1; g.fout[pos + 3] = c;
+                    }
+                } else {
+                    atomicOr(g.status, kStFrontierOvf);
+                }
+            }
+        }
+    }
+}
+
+// =================================================================================================================
+// narrowphase
+// =================================================================================================================
+struct TracSoA {
+    int *item;
+    double *nx, *ny, *nz, *rx, *ry, *rz, *dA, *p;
+};
+
+struct NpArgs {
+    const ItemRec *items;
+    const WorkRec *cand;
+    const int *ccount;
+    int ccap;
+    double *acc;
+    int *icnt;
+    int *clip_n;     // per candidate, or null
+    TracSoA trac;
+    int *tcount;
+    int tcap;
+    unsigned *status;
+    int debug;       // materialise traction points for every item
+};
+
+constexpr int kNpBlock = 64;  // one wave per block: 32 KiB of LDS polygon staging per wave
+
+// weightPoly (src/math_kernel/utility.jl:21-26) on 4-vectors held in LDS slots
+#define PZ(buf, slot, c) poly[(((buf) * 8 + (slot)) * 4 + (c)) * kNpBlock + lane]
+
+__device__ __forceinline__ void accumulate_items(double *acc, int item, bool any, const double *v, int n0, int n) {
+    // wave-level reduction of per-lane partial sums into per-item accumulators
+    unsigned long long m = __ballot(any);
+    if (m == 0) return;
+    int src = __builtin_ctzll(m);
+    int it0 = __shfl(item, src, 64);
+    bool uni = __all(!any || item == it0);
+    if (uni) {
+        for (int k = 0; k < n; ++k) {
+            double s = wave_sum(any ? v[k] : 0.0);
+            if (lane_id() == 0 && s != 0.0) unsafeAtomicAdd(&acc[(size_t)it0 * kAccStride + n0 + k], s);
+        }
+    } else if (any) {
+        for (int k = 0; k < n; ++k)
+            if (v[k] != 0.0) unsafeAtomicAdd(&acc[(size_t)item * kAccStride + n0 + k], v[k]);
+    }
+}
+
+__global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
+    __shared__ double poly[2 * 8 * 4 * kNpBlock];
+    const int lane = threadIdx.x;
+    int n_c = *g.ccount;
+    if (n_c > g.ccap) n_c = g.ccap;
+    const int stride = gridDim.x * kNpBlock;
+    const int n_round = (n_c + stride - 1) / stride;
+    for (int rd = 0; rd < n_round; ++rd) {
+        const int idx = rd * stride + blockIdx.x * kNpBlock + lane;
+        const bool active = idx < n_c;
+        WorkRec cw;
+        cw.item = 0; cw.a = 0; cw.b = 0; cw.pad = 0;
+        if (active) cw = g.cand[idx];
+        const ItemRec *it = g.items + cw.item;
+        int n_poly = 0;
+        double sum[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) sum[k] = 0.0;
+        int n_trac_lane = 0;
+        const bool materialise = active && (g.debug || it->model == PFC_BRISTLE);
+        if (active) {
+            const TriRec tr = it->tri[cw.a];
+            const TetRec *tp = it->tet + cw.b;
+            // x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (non_friction.jl:204); last row of x_r2_r1.mat is (0 0 0 1)
+            double X[16];
+            {
+                double Z[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        X[i + 4 * j] = (Z[i] * it->R21[3 * j] + Z[i + 4] * it->R21[3 * j + 1]) + Z[i + 8] * it->R21[3 * j + 2];
+                    X[i + 12] = ((Z[i] * it->t21[0] + Z[i + 4] * it->t21[1]) + Z[i + 8] * it->t21[2]) + Z[i + 12];
+                }
+            }
+            // v_k = x_ζ2_r1 * onePad(vert_k) (:205-207)
+            double z[3][4];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    z[k][i] = ((X[i] * tr.v[3 * k] + X[i + 4] * tr.v[3 * k + 1]) + X[i + 8] * tr.v[3 * k + 2]) + X[i + 12];
+            bool finite = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) finite &= (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
+            if (!finite) atomicOr(g.status, kStNonFinite);
+            // Trivial reject: if all three vertices are non-positive on some plane the clip is empty.  Bit-exact
+            // shortcut: every clipped vertex is c1*p2 - c2*p1 with c1 >= 0 >= c2 (static_clip.jl:197-201), whose
+            // sign on that plane is exact, so Sutherland-Hodgman returns the empty polygon at that plane (:44).
+            bool reject = !finite;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0);
+            if (!reject) {
+                // ---- clip_in_tet_coordinates (static_clip.jl:17-23,34-201), polygon staged in LDS --------------
+                int n = 3, cur = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) PZ(0, k, i) = z[k][i];
+                bool err = false;
+                for (int i = 0; i < 4 && n > 0; ++i) {
+                    unsigned nonpos = 0, nonneg = 0;
+                    for (int k = 0; k < n; ++k) {
+                        double sv = PZ(cur, k, i);
+                        nonpos |= (unsigned)(sv <= 0.0) << k;
+                        nonneg |= (unsigned)(0.0 <= sv) << k;
+                    }
+                    const unsigned full = (1u << n) - 1u;
+                    if (nonpos == full) { n = 0; break; }       // :44
+                    if (nonneg == full) continue;               // :45-46
+                    // first k with is_non_pos[k] && !is_non_pos[k+1] (cyclic) (:48-50)
+                    unsigned nxt = ((nonpos >> 1) | ((nonpos & 1u) << (n - 1))) & full;
+                    unsigned cand_start = nonpos & ~nxt & full;
+                    if (cand_start == 0) { err = true; n = 0; break; }  // "Non-finite vertex likely" (:52)
+                    const int st = __builtin_ctz(cand_start);
+                    // cut_clip (:135-195): drop trailing vertices while z_{m-1} is non-positive
+                    int m = n;
+                    while (m > 3) {
+                        int k2 = st + m - 2; if (k2 >= n) k2 -= n;
+                        if (PZ(cur, k2, i) <= 0.0) --m; else break;
+                    }
+                    int k1 = st + 1; if (k1 >= n) k1 -= n;
+                    int kl = st + m - 1; if (kl >= n) kl -= n;   // z_m (last)
+                    int kp = st + m - 2; if (kp >= n) kp -= n;   // z_{m-1}
+                    const double last = PZ(cur, kl, i);
+                    const bool inside = (m <= 5) ? (0.0 < last) : (0.0 <= last);   // :140,150,162 vs :176,188
+                    const int nb = cur ^ 1;
+                    // z_start = clip_node(z1, z2)
+                    {
+                        double w1 = PZ(cur, st, i), w2 = PZ(cur, k1, i);
+                        double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) PZ(nb, 0, c) = c1 * PZ(cur, k1, c) - c2 * PZ(cur, st, c);
+                    }
+                    const int ncopy = inside ? (m - 1) : (m - 2);   // z2 .. z_m  or  z2 .. z_{m-1}
+                    for (int q = 0; q < ncopy; ++q) {
+                        int ks = st + 1 + q; if (ks >= n) ks -= n;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) PZ(nb, 1 + q, c) = PZ(cur, ks, c);
+                    }
+                    {
+                        // inside: z_end = clip_node(z1, z_m); else z_end = clip_node(z_m, z_{m-1})
+                        const int kn = inside ? st : kl, kq = inside ? kl : kp;
+                        double w1 = PZ(cur, kn, i), w2 = PZ(cur, kq, i);
+                        double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) PZ(nb, 1 + ncopy, c) = c1 * PZ(cur, kq, c) - c2 * PZ(cur, kn, c);
+                    }
+                    n = ncopy + 2;
+                    cur = nb;
+                    if (m == 7) break;  // the 7-vertex method returns the polygon directly (:185-195)
+                }
+                if (err) atomicOr(g.status, kStNonFinite);
+                n_poly = n;
+                if (n >= 3) {
+                    // ---- integrate_over_polygon_patch! (non_friction.jl:217-234) -------------------------------
+                    // n̂2 = R(x_r2_r1) * n̂_r1 (:211-212)
+                    V3 nh = mk3((it->R21[0] * tr.n[0] + it->R21[3] * tr.n[1]) + it->R21[6] * tr.n[2],
+                                (it->R21[1] * tr.n[0] + it->R21[4] * tr.n[1]) + it->R21[7] * tr.n[2],
+                                (it->R21[2] * tr.n[0] + it->R21[5] * tr.n[1]) + it->R21[8] * tr.n[2]);
+                    // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98) -> other LDS buffer (x,y,z)
+                    const int ob = cur ^ 1;
+                    {
+                        double V[12];
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
+                        for (int k = 0; k < n; ++k) {
+                            double z0 = PZ(cur, k, 0), z1 = PZ(cur, k, 1), z2 = PZ(cur, k, 2), z3 = PZ(cur, k, 3);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                PZ(ob, k, c) = ((V[c] * z0 + V[c + 3] * z1) + V[c + 6] * z2) + V[c + 9] * z3;
+                        }
+                    }
+                    // centroid(poly_r2, n̂2) (poly_eight.jl:35-52)
+                    V3 cen;
+                    {
+                        V3 a = mk3(PZ(ob, 0, 0), PZ(ob, 0, 1), PZ(ob, 0, 2));
+                        V3 cc = mk3(PZ(ob, 1, 0), PZ(ob, 1, 1), PZ(ob, 1, 2));
+                        double cum_sum = 0.0;
+                        V3 cum_prod = mk3(0.0, 0.0, 0.0);
+                        for (int k = 2; k < n; ++k) {
+                            V3 b = cc;
+                            cc = mk3(PZ(ob, k, 0), PZ(ob, k, 1), PZ(ob, k, 2));
+                            double ar = triangle_area(a, b, cc, nh);
+                            cum_prod = cum_prod + ((a + b) + cc) * (1.0 / 3.0) * ar;
+                            cum_sum += ar;
+                        }
+                        cen = (cum_sum == 0.0) ? a : cum_prod / cum_sum;
+                    }
+                    const double er0 = tp->epsr[0], er1 = tp->epsr[1], er2 = tp->epsr[2], er3 = tp->epsr[3];
+                    const V3 w = ld3(it->w), vl = ld3(it->v);
+                    const double chi = it->chi, Ebar = it->Ebar;
+                    const int nq = it->nq;
+                    const bool reg = it->model == PFC_REGULARIZED;
+                    V3 v2 = mk3(PZ(ob, n - 1, 0), PZ(ob, n - 1, 1), PZ(ob, n - 1, 2));
+                    for (int k = 0; k < n; ++k) {
+                        V3 v1 = v2;
+                        v2 = mk3(PZ(ob, k, 0), PZ(ob, k, 1), PZ(ob, k, 2));
+                        double area = triangle_area(v1, v2, cen, nh);
+                        if (!(0.0 < area)) continue;  // :232
+                        for (int q = 0; q < nq; ++q) {
+                            // TriTetQuadRule rules 1 and 2, literal decimals of src/clip/quadrature.jl:24-39
+                            double q0, q1, q2, qw;
+                            if (nq == 1) {
+                                q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
+                            } else {
+                                const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
+                                q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
+                                qw = 0.33333333333333331483;
+                            }
+                            // fillTractionCacheInnerLoop! (:251-265)
+                            V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
+                                       (v1.z * q0 + v2.z * q1) + cen.z * q2);
+                            double eq = __builtin_fma(er0, r.x, er3);
+                            eq = __builtin_fma(er1, r.y, eq);
+                            eq = __builtin_fma(er2, r.z, eq);
+                            V3 rdot = vl + cross(w, r);
+                            double ee = -dot(mk3(er0, er1, er2), rdot);
+                            double damp = fmax(0.0, 1.0 + chi * ee);
+                            double p = eq * Ebar * damp;
+                            double dA = qw * area;
+                            if (!(0.0 < p)) continue;  // :245
+                            ++n_trac_lane;
+                            double p_dA = p * dA;
+                            if (materialise) {
+                                int pos = atomicAdd(g.tcount, 1);
+                                if (pos < g.tcap) {
+                                    g.trac.item[pos] = cw.item;
+                                    g.trac.nx[pos] = nh.x; g.trac.ny[pos] = nh.y; g.trac.nz[pos] = nh.z;
+                                    g.trac.rx[pos] = r.x; g.trac.ry[pos] = r.y; g.trac.rz[pos] = r.z;
+                                    g.trac.dA[pos] = dA; g.trac.p[pos] = p;
+                                } else {
+                                    atomicOr(g.status, kStTracOvf);
+                                }
+                            }
+                            V3 tk;
+                            if (reg) {
+                                // yes_contact!(::Regularized) (friction.jl:50-72) fused
+                                V3 vel = vl + cross(w, r);
+                                V3 vt = vec_sub_vec_proj(vel, nh);
+                                double m2 = dot(vt, vt);
+                                V3 T;
+                                if (m2 < it->v_c * it->v_c) {
+                                    T = (vt * (-it->mu_s)) / it->v_c;
+                                } else {
+                                    double mg = __builtin_sqrt(m2);
+                                    double mu = clamped_piecewise(mg, 2 * it->v_c, 3 * it->v_c, it->mu_s, it->mu_d);
+                                    T = (vt * (-mu)) / mg;
+                                }
+                                tk = nh * p_dA + T * p_dA;
+                            } else {
+                                // normal_wrench_cop (normal.jl:17-34) fused: pass 1 of the bristle model
+                                tk = nh * p_dA;
+                                sum[6] += p_dA;
+                                sum[7] += p_dA * r.x; sum[8] += p_dA * r.y; sum[9] += p_dA * r.z;
+                            }
+                            V3 ta = cross(r, tk);
+                            sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+                            sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
+                        }
+                    }
+                }
+            }
+        }
+        if (g.clip_n && active) g.clip_n[idx] = n_poly;
+        // per-item reductions (wave-aggregated)
+        const bool contributed = active && n_trac_lane > 0;
+        accumulate_items(g.acc, cw.item, contributed, sum, 0, 10);
+        count_per_item(g.icnt, cw.item, 2, active && n_poly >= 3);
+        {
+            // traction counts: wave-uniform item -> one atomic
+            unsigned long long m = __ballot(contributed);
+            if (m) {
+                int src = __builtin_ctzll(m);
+                int it0 = __shfl(cw.item, src, 64);
+                bool uni = __all(!contributed || cw.item == it0);
+                if (uni) {
+                    int tot = n_trac_lane;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+                    if (lane == 0) atomicAdd(&g.icnt[4 * (size_t)it0 + 3], tot);
+                } else if (contributed) {
+                    atomicAdd(&g.icnt[4 * (size_t)cw.item + 3], n_trac_lane);
+                }
+            }
+        }
+    }
+}
+#undef PZ
+
+// =================================================================================================================
+// bristle model: cop, patch stiffness, 6x6 eigen, friction pass, finalisation
+// =================================================================================================================
+struct BrArgs {
+    const ItemRec *items;
+    int n_items;
+    double *acc;
+    double *res;
+    const int *icnt;
+    TracSoA trac;
+    const int *tcount;
+    int tcap;
+    double *wrench, *sdot;
+    int *counts;
+};
+
+__global__ void k_cop(BrArgs g) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n_items) return;
+    const double *a = g.acc + (size_t)i * kAccStride;
+    double ip = a[kAccIp];
+    double *r = g.res + (size_t)i * kResStride;
+    // cop = ∫p r dA / ∫p dA (normal.jl:33)
+    r[kResCop] = a[kAccIpc] / ip; r[kResCop + 1] = a[kAccIpc + 1] / ip; r[kResCop + 2] = a[kAccIpc + 2] / ip;
+}
+
+// calc_patch_spatial_stiffness! (friction.jl:147-169): one lane per traction point
+__global__ void __launch_bounds__(256) k_stiff(BrArgs g) {
+    int n_t = *g.tcount;
+    if (n_t > g.tcap) n_t = g.tcap;
+    const int stride = gridDim.x * blockDim.x;
+    const int n_round = (n_t + stride - 1) / stride;
+    for (int rd = 0; rd < n_round; ++rd) {
+        int idx = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool active = idx < n_t;
+        int item = 0;
+        double v[21];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) v[k] = 0.0;
+        if (active) {
+            item = g.trac.item[idx];
+            active = g.items[item].model == PFC_BRISTLE;
+        }
+        if (active) {
+            const double *cop = g.res + (size_t)item * kResStride + kResCop;
+            V3 n = mk3(g.trac.nx[idx], g.trac.ny[idx], g.trac.nz[idx]);
+            V3 r = mk3(g.trac.rx[idx], g.trac.ry[idx], g.trac.rz[idx]) - ld3(cop);
+            double p_dA = g.trac.p[idx] * g.trac.dA[idx];
+            V3 rn = cross(r, n);
+            double q1 = r.x * r.x, q2 = r.y * r.y, q3 = r.z * r.z;
+            // K11 -= p_dA * ([r]x^2 + (r x n)(r x n)')   (xx xy xz yy yz zz)
+            v[0] = -(p_dA * ((-q2 - q3) + rn.x * rn.x));
+            v[1] = -(p_dA * (r.x * r.y + rn.x * rn.y));
+            v[2] = -(p_dA * (r.x * r.z + rn.x * rn.z));
+            v[3] = -(p_dA * ((-q1 - q3) + rn.y * rn.y));
+            v[4] = -(p_dA * (r.y * r.z + rn.y * rn.z));
+            v[5] = -(p_dA * ((-q1 - q2) + rn.z * rn.z));
+            // K12 += p_dA * ([r]x - (r x n) n')   column-major 3x3
+            const double sk[9] = {0.0, r.z, -r.y, -r.z, 0.0, r.x, r.y, -r.x, 0.0};
+            const double nn[3] = {n.x, n.y, n.z}, rr[3] = {rn.x, rn.y, rn.z};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii) v[6 + ii + 3 * j] = p_dA * (sk[ii + 3 * j] - rr[ii] * nn[j]);
+            // K22 += p_dA * (I - n n')
+            v[15] = p_dA * (1.0 - n.x * n.x); v[16] = p_dA * (0.0 - n.x * n.y); v[17] = p_dA * (0.0 - n.x * n.z);
+            v[18] = p_dA * (1.0 - n.y * n.y); v[19] = p_dA * (0.0 - n.y * n.z); v[20] = p_dA * (1.0 - n.z * n.z);
+        }
+        accumulate_items(g.acc, item, active, v, kAccK11, 21);
+    }
+}
+
+// cyclic Jacobi, symmetric 6x6 (stands in for LAPACK eigen!(Hermitian), friction.jl:88)
+__device__ void jacobi6(double *A, double *V, double *w) {
+    for (int i = 0; i < 36; ++i) V[i] = 0.0;
+    for (int i = 0; i < 6; ++i) V[7 * i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j)
+                if (i != j) off += A[i + 6 * j] * A[i + 6 * j]; else dia += A[7 * i] * A[7 * i];
+        if (off <= 1e-300 || off <= 1e-34 * dia) break;
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                double apq = A[p + 6 * q];
+                if (apq == 0.0) continue;
+                double theta = (A[7 * q] - A[7 * p]) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
+                double cs = 1.0 / __builtin_sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 6; ++k) {
+                    double akp = A[k + 6 * p], akq = A[k + 6 * q];
+                    A[k + 6 * p] = cs * akp - sn * akq; A[k + 6 * q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    double apk = A[p + 6 * k], aqk = A[q + 6 * k];
+                    A[p + 6 * k] = cs * apk - sn * aqk; A[q + 6 * k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    double vkp = V[k + 6 * p], vkq = V[k + 6 * q];
+                    V[k + 6 * p] = cs * vkp - sn * vkq; V[k + 6 * q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 6; ++i) w[i] = A[7 * i];
+}
+
+// decompose_K! / calc_K̄_sqrt_inv / Δ² (friction.jl:85-132): one thread per bristle item in contact
+__global__ void k_eig(BrArgs g) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n_items) return;
+    const ItemRec *it = g.items + i;
+    if (it->model != PFC_BRISTLE || g.icnt[4 * (size_t)i + 3] == 0) return;
+    const double *a = g.acc + (size_t)i * kAccStride;
+    double *r = g.res + (size_t)i * kResStride;
+    double K[36];
+    const int s6[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};  // symmetric 3x3 from 6 unique
+    for (int j = 0; j < 3; ++j)
+        for (int ii = 0; ii < 3; ++ii) {
+            K[ii + 6 * j] = a[kAccK11 + s6[ii + 3 * j]];
+            K[(ii + 3) + 6 * j] = a[kAccK12 + j + 3 * ii];
+            K[ii + 6 * (j + 3)] = a[kAccK12 + ii + 3 * j];
+            K[(ii + 3) + 6 * (j + 3)] = a[kAccK22 + s6[ii + 3 * j]];
+        }
+    for (int k = 0; k < 36; ++k) { K[k] *= it->k_bar; r[kResK + k] = K[k]; }
+    double t1 = (K[0] + K[7]) + K[14], t2 = (K[21] + K[28]) + K[35];
+    double s1 = 1.0 / __builtin_sqrt(t1), s2 = 1.0 / __builtin_sqrt(t2);
+    double Sinv[6];
+    for (int k = 0; k < 3; ++k) { Sinv[k] = s1 * it->magic; Sinv[k + 3] = s2; }
+    double Kb[36], V[36], sig[6];
+    for (int j = 0; j < 6; ++j)
+        for (int ii = 0; ii < 6; ++ii) {
+            double kij = (ii <= j) ? K[ii + 6 * j] : K[j + 6 * ii];
+            Kb[ii + 6 * j] = (Sinv[ii] * kij) * Sinv[j];
+        }
+    jacobi6(Kb, V, sig);
+    double mx = sig[0];
+    for (int k = 1; k < 6; ++k) mx = fmax(mx, sig[k]);
+    for (int k = 0; k < 6; ++k) sig[k] = 1.0 / __builtin_sqrt(fmax(sig[k], mx * 1.0e-16));
+    for (int j = 0; j < 6; ++j)
+        for (int ii = 0; ii < 6; ++ii) {
+            double acc = 0.0;
+            for (int k = 0; k < 6; ++k) acc += (V[ii + 6 * k] * sig[k]) * V[j + 6 * k];
+            r[kResKis + ii + 6 * j] = acc;
+        }
+    for (int ii = 0; ii < 6; ++ii) {
+        double acc = 0.0;
+        for (int k = 0; k < 6; ++k) acc += r[kResKis + ii + 6 * k] * it->s[k];
+        r[kResDelta + ii] = Sinv[ii] * acc;
+        r[kResSinv + ii] = Sinv[ii];
+    }
+}
+
+// calc_spatial_bristle_force (friction.jl:171-201): one lane per traction point
+__global__ void __launch_bounds__(256) k_fric(BrArgs g) {
+    int n_t = *g.tcount;
+    if (n_t > g.tcap) n_t = g.tcap;
+    const int stride = gridDim.x * blockDim.x;
+    const int n_round = (n_t + stride - 1) / stride;
+    for (int rd = 0; rd < n_round; ++rd) {
+        int idx = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool active = idx < n_t;
+        int item = 0;
+        double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (active) {
+            item = g.trac.item[idx];
+            active = g.items[item].model == PFC_BRISTLE;
+        }
+        if (active) {
+            const ItemRec *it = g.items + item;
+            const double *res = g.res + (size_t)item * kResStride;
+            V3 cop = ld3(res + kResCop);
+            V3 Da = ld3(res + kResDelta), Dl = ld3(res + kResDelta + 3);
+            V3 n = mk3(g.trac.nx[idx], g.trac.ny[idx], g.trac.nz[idx]);
+            V3 r = mk3(g.trac.rx[idx], g.trac.ry[idx], g.trac.rz[idx]);
+            double p_dA = g.trac.p[idx] * g.trac.dA[idx];
+            V3 x = r - cop;
+            V3 del = Dl + cross(Da, x);
+            V3 rp = ld3(it->v) + cross(ld3(it->w), r);
+            V3 Ts = (del + rp * it->tau) * (-it->k_bar);
+            Ts = vec_sub_vec_proj(Ts, n);
+            // traction(::Bristle) (friction.jl:32-48)
+            double m2 = dot(Ts, Ts);
+            V3 T;
+            if (m2 < it->mu_s * it->mu_s) {
+                T = Ts;
+            } else {
+                double mg = __builtin_sqrt(m2);
+                double mu = clamped_piecewise(mg, 2 * it->mu_s, 3 * it->mu_s, it->mu_s, it->mu_d);
+                T = (Ts * mu) / mg;
+            }
+            V3 Tc = T * p_dA;
+            V3 ta = cross(x, Tc);
+            v[0] = ta.x; v[1] = ta.y; v[2] = ta.z; v[3] = Tc.x; v[4] = Tc.y; v[5] = Tc.z;
+        }
+        accumulate_items(g.acc, item, active, v, kAccFric, 6);
+    }
+}
+
+// yes_contact! / no_contact! epilogue (friction.jl:76-81,119-143; non_friction.jl:77-83)
+__global__ void k_final(BrArgs g) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n_items) return;
+    const ItemRec *it = g.items + i;
+    const double *a = g.acc + (size_t)i * kAccStride;
+    const double *r = g.res + (size_t)i * kResStride;
+    double *w = g.wrench + 6 * (size_t)i, *sd = g.sdot + 6 * (size_t)i;
+    const bool contact = g.icnt[4 * (size_t)i + 3] > 0;
+    if (g.counts)
+        for (int k = 0; k < 4; ++k) g.counts[4 * (size_t)i + k] = g.icnt[4 * (size_t)i + k];
+    for (int k = 0; k < 6; ++k) { w[k] = 0.0; sd[k] = 0.0; }
+    if (it->model == PFC_REGULARIZED) {
+        if (contact)
+            for (int k = 0; k < 6; ++k) w[k] = a[kAccWrench + k];
+        return;
+    }
+    const double tau_inv = 1.0 / it->tau;
+    if (!contact) {
+        for (int k = 0; k < 6; ++k) sd[k] = -tau_inv * it->s[k];
+        return;
+    }
+    V3 fang = ld3(a + kAccFric), flin = ld3(a + kAccFric + 3), cop = ld3(r + kResCop);
+    V3 fang2 = fang + cross(cop, flin);
+    w[0] = a[kAccWrench] + fang2.x; w[1] = a[kAccWrench + 1] + fang2.y; w[2] = a[kAccWrench + 2] + fang2.z;
+    w[3] = a[kAccWrench + 3] + flin.x; w[4] = a[kAccWrench + 4] + flin.y; w[5] = a[kAccWrench + 5] + flin.z;
+    double sw[6];
+    for (int k = 0; k < 6; ++k) sw[k] = r[kResSinv + k] * a[kAccFric + k];
+    for (int ii = 0; ii < 6; ++ii) {
+        double acc = 0.0;
+        for (int k = 0; k < 6; ++k) acc += r[kResKis + ii + 6 * k] * sw[k];
+        sd[ii] = -tau_inv * (acc + it->s[ii]);
+    }
+}
+
+__global__ void k_selftest(int n, const double *x, const double *y, double *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = x[i] / y[i];
+    out[n + i] = __builtin_sqrt(__builtin_fabs(x[i]));
+    out[2 * n + i] = __builtin_fma(x[i], y[i], x[i]);
+}
+
+}  // namespace pfc
+
+// =================================================================================================================
+// host side
+// =================================================================================================================
+using namespace pfc;
+
+namespace {
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct HostMesh {
+    int n_pt = 0, n_tri = 0, n_tet = 0, n_node = 0, depth = 0;
+    double Ebar = 0.0;
+    std::vector<double> xyz, eps;
+    std::vector<int> tri, tet;
+    std::vector<NodeRec> nodes;
+    NodeRec *d_nodes = nullptr;
+    TriRec *d_tri = nullptr;
+    TetRec *d_tet = nullptr;
+};
+
+enum { EV_START = 0, EV_SETUP, EV_BP, EV_NP, EV_BR, EV_FIN, EV_COUNT };
+
+}  // namespace
+
+struct pfc_context {
+    int device = 0;
+    bool finalized = false;
+    std::string err;
+    hipStream_t stream = nullptr;
+    std::vector<HostMesh> meshes;
+    std::vector<InsDev> ins;
+    MeshDev *d_meshes = nullptr;
+    InsDev *d_ins = nullptr;
+    int max_levels = 1;
+    bool any_bristle = false;
+    // options
+    int opt_debug = 0, opt_profile = 0, opt_max_levels = 0;
+    // work buffers
+    DevBuf<ItemRec> items;
+    DevBuf<WorkRec> frontier[2], cand;
+    DevBuf<int> clip_n, icnt, trac_item;
+    DevBuf<double> acc, res, trac_d;   // trac_d: 8 arrays of tcap
+    DevBuf<int> ctr;                   // [0]=ccount [1]=tcount [2..] fcount[levels+2]
+    DevBuf<unsigned> status;
+    size_t fcap = 0, ccap = 0, tcap = 0;
+    // host-pointer path staging
+    DevBuf<double> h_pose, h_twist, h_s, h_wrench, h_sdot;
+    DevBuf<int> h_ins, h_counts;
+    // last evaluation
+    int last_n_items = 0, last_levels = 0;
+    bool pending = false;
+    hipStream_t last_stream = nullptr;
+    long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t ev[EV_COUNT] = {};
+    bool ev_valid = false;
+};
+
+namespace {
+
+int fail(pfc_context *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(h, PFC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int tree_depth(const std::vector<NodeRec> &nodes) {
+    // iterative DFS; also validates child indices
+    int n = (int)nodes.size(), best = 0;
+    std::vector<std::pair<int, int>> st;
+    st.push_back({0, 0});
+    size_t visited = 0;
+    while (!st.empty()) {
+        auto [k, d] = st.back();
+        st.pop_back();
+        if (k < 0 || k >= n || ++visited > (size_t)n) return -1;
+        best = d > best ? d : best;
+        if (nodes[k].leaf == kInternal) {
+            st.push_back({nodes[k].child0, d + 1});
+            st.push_back({nodes[k].child1, d + 1});
+        }
+    }
+    return best;
+}
+
+int grid_for(size_t n, int block, int max_blocks) {
+    size_t b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > (size_t)max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+hipError_t ensure_work(pfc_context *h, int n_items) {
+    hipError_t e;
+    if ((e = h->items.ensure(n_items)) != hipSuccess) return e;
+    if ((e = h->acc.ensure((size_t)n_items * kAccStride)) != hipSuccess) return e;
+    if ((e = h->res.ensure((size_t)n_items * kResStride)) != hipSuccess) return e;
+    if ((e = h->icnt.ensure((size_t)n_items * 4)) != hipSuccess) return e;
+    if ((e = h->ctr.ensure((size_t)h->max_levels + 8)) != hipSuccess) return e;
+    if ((e = h->status.ensure(4)) != hipSuccess) return e;
+    size_t f = h->fcap ? h->fcap : 1u << 16;
+    while (f < (size_t)n_items * 8) f *= 2;
+    size_t c = h->ccap ? h->ccap : 1u << 16;
+    while (c < (size_t)n_items * 4) c *= 2;
+    size_t t = h->tcap ? h->tcap : 1u << 16;
+    h->fcap = f; h->ccap = c; h->tcap = t;
+    if ((e = h->frontier[0].ensure(f)) != hipSuccess) return e;
+    if ((e = h->frontier[1].ensure(f)) != hipSuccess) return e;
+    if ((e = h->cand.ensure(c)) != hipSuccess) return e;
+    if ((e = h->clip_n.ensure(c)) != hipSuccess) return e;
+    if ((e = h->trac_item.ensure(t)) != hipSuccess) return e;
+    if ((e = h->trac_d.ensure(t * 8)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+TracSoA trac_view(pfc_context *h) {
+    TracSoA t;
+    size_t n = h->tcap;
+    double *d = h->trac_d.p;
+    t.item = h->trac_item.p;
+    t.nx = d; t.ny = d + n; t.nz = d + 2 * n; t.rx = d + 3 * n; t.ry = d + 4 * n; t.rz = d + 5 * n;
+    t.dA = d + 6 * n; t.p = d + 7 * n;
+    return t;
+}
+
+// Enqueue one evaluation.  All pointers are device pointers.
+int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
+                 const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st) {
+    HIP_TRY(h, ensure_work(h, n_items));
+    const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
+    const bool prof = h->opt_profile != 0;
+    if (prof && !h->ev[0])
+        for (int k = 0; k < EV_COUNT; ++k) HIP_TRY(h, hipEventCreate(&h->ev[k]));
+    int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *fcount = h->ctr.p + 2;
+    HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(int) * ((size_t)levels + 8), st));
+    HIP_TRY(h, hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * 4, st));
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
+
+    EvalArgs ea;
+    ea.n_items = n_items; ea.ins_ids = d_ins_ids; ea.pose = d_pose; ea.twist = d_twist; ea.s = d_s;
+    ea.ins = h->d_ins; ea.meshes = h->d_meshes; ea.n_ins = (int)h->ins.size(); ea.items = h->items.p;
+    ea.frontier0 = h->frontier[0].p; ea.fcount = fcount; ea.acc = h->acc.p; ea.icnt = h->icnt.p;
+    ea.status = h->status.p;
+    hipLaunchKernelGGL(k_setup_items, dim3(grid_for(n_items, 128, 1 << 20)), dim3(128), 0, st, ea);
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_SETUP], st));
+
+    // broadphase levels
+    for (int lv = 0; lv < levels; ++lv) {
+        BpArgs b;
+        b.items = h->items.p; b.fin = h->frontier[lv & 1].p; b.fout = h->frontier[(lv + 1) & 1].p;
+        b.cand = h->cand.p; b.fcount = fcount; b.ccount = ccount; b.icnt = h->icnt.p; b.status = h->status.p;
+        b.level = lv; b.fcap = (int)h->fcap; b.ccap = (int)h->ccap;
+        // upper bound of this level's frontier: n_items * 4^lv, capped by the buffer
+        double ub = (double)n_items * std::pow(4.0, (double)(lv < 15 ? lv : 15));
+        size_t bound = ub > (double)h->fcap ? h->fcap : (size_t)ub;
+        hipLaunchKernelGGL(k_bp_expand, dim3(grid_for(bound, 256, 2048)), dim3(256), 0, st, b);
+    }
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));
+
+    NpArgs np;
+    np.items = h->items.p; np.cand = h->cand.p; np.ccount = ccount; np.ccap = (int)h->ccap; np.acc = h->acc.p;
+    np.icnt = h->icnt.p; np.clip_n = h->opt_debug ? h->clip_n.p : nullptr; np.trac = trac_view(h);
+    np.tcount = tcount; np.tcap = (int)h->tcap; np.status = h->status.p; np.debug = h->opt_debug;
+    hipLaunchKernelGGL(k_narrow, dim3(grid_for(h->ccap, kNpBlock, 256 * 20)), dim3(kNpBlock), 0, st, np);
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_NP], st));
+
+    BrArgs br;
+    br.items = h->items.p; br.n_items = n_items; br.acc = h->acc.p; br.res = h->res.p; br.icnt = h->icnt.p;
+    br.trac = trac_view(h); br.tcount = tcount; br.tcap = (int)h->tcap; br.wrench = d_wrench; br.sdot = d_sdot;
+    br.counts = d_counts;
+    if (h->any_bristle) {
+        int gi = grid_for(n_items, 128, 1 << 20);
+        hipLaunchKernelGGL(k_cop, dim3(gi), dim3(128), 0, st, br);
+        hipLaunchKernelGGL(k_stiff, dim3(grid_for(h->tcap, 256, 2048)), dim3(256), 0, st, br);
+        hipLaunchKernelGGL(k_eig, dim3(grid_for(n_items, 64, 1 << 20)), dim3(64), 0, st, br);
+        hipLaunchKernelGGL(k_fric, dim3(grid_for(h->tcap, 256, 2048)), dim3(256), 0, st, br);
+    }
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BR], st));
+    hipLaunchKernelGGL(k_final, dim3(grid_for(n_items, 128, 1 << 20)), dim3(128), 0, st, br);
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_FIN], st));
+    HIP_TRY(h, hipGetLastError());
+    h->last_n_items = n_items; h->last_levels = levels; h->pending = true; h->last_stream = st;
+    h->ev_valid = prof;
+    return PFC_OK;
+}
+
+// Synchronise, read counters, grow on overflow.
+int check_eval(pfc_context *h) {
+    if (!h->pending) return PFC_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    h->pending = false;
+    const int levels = h->last_levels;
+    std::vector<int> ctr((size_t)levels + 8);
+    unsigned status = 0;
+    HIP_TRY(h, hipMemcpy(ctr.data(), h->ctr.p, sizeof(int) * ctr.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(&status, h->status.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+    long long fpeak = 0;
+    int used_levels = 0;
+    for (int lv = 0; lv <= levels; ++lv) {
+        if (ctr[2 + lv] > fpeak) fpeak = ctr[2 + lv];
+        if (ctr[2 + lv] > 0) used_levels = lv + 1;
+    }
+    h->stats[1] = ctr[0]; h->stats[3] = ctr[1]; h->stats[4] = used_levels; h->stats[5] = fpeak;
+    h->stats[6] = status; h->stats[7] = h->last_n_items;
+    if (status & 16u) return fail(h, PFC_ERR_BAD_ARG, "instruction id out of range in ins_ids");
+    if (status & (kStFrontierOvf | kStCandOvf | kStTracOvf)) {
+        // VectorCache-style growth (src/obb/vector_cache.jl:13-17): at least double, at least the observed need
+        if (status & kStFrontierOvf) { size_t f = h->fcap * 2; while (f < (size_t)fpeak) f *= 2; h->fcap = f; }
+        if (status & kStCandOvf) { size_t c = h->ccap * 2; while (c < (size_t)ctr[0]) c *= 2; h->ccap = c; }
+        if (status & kStTracOvf) { size_t t = h->tcap * 2; while (t < (size_t)ctr[1]) t *= 2; h->tcap = t; }
+        return fail(h, PFC_ERR_OVERFLOW, "work list overflow (status %u): capacities grown to frontier %zu, candidates %zu, tractions %zu",
+                    status, h->fcap, h->ccap, h->tcap);
+    }
+    if (ctr[2 + levels] > 0)
+        return fail(h, PFC_ERR_STATE, "broadphase did not terminate within %d levels", levels);
+    if (status & kStNonFinite) return fail(h, PFC_ERR_NONFINITE, "Non-finite vertex likely");
+    // totals
+    std::vector<int> ic((size_t)h->last_n_items * 4);
+    if (!ic.empty()) HIP_TRY(h, hipMemcpy(ic.data(), h->icnt.p, sizeof(int) * ic.size(), hipMemcpyDeviceToHost));
+    long long nt = 0, ne = 0;
+    for (int i = 0; i < h->last_n_items; ++i) { nt += ic[4 * (size_t)i]; ne += ic[4 * (size_t)i + 2]; }
+    h->stats[0] = nt; h->stats[2] = ne;
+    return PFC_OK;
+}
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+int pfc_version(void) { return PFC_VERSION; }
+
+int pfc_create(int device, pfc_handle *out) {
+    if (!out) return PFC_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PFC_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return PFC_ERR_HIP;
+    pfc_context *h = new (std::nothrow) pfc_context();
+    if (!h) return PFC_ERR_NOMEM;
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return PFC_ERR_HIP; }
+    *out = h;
+    return PFC_OK;
+}
+
+void pfc_destroy(pfc_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &m : h->meshes) {
+        if (m.d_nodes) (void)hipFree(m.d_nodes);
+        if (m.d_tri) (void)hipFree(m.d_tri);
+        if (m.d_tet) (void)hipFree(m.d_tet);
+    }
+    if (h->d_meshes) (void)hipFree(h->d_meshes);
+    if (h->d_ins) (void)hipFree(h->d_ins);
+    h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
+    h->clip_n.release(); h->icnt.release(); h->trac_item.release(); h->acc.release(); h->res.release();
+    h->trac_d.release(); h->ctr.release(); h->status.release();
+    h->h_pose.release(); h->h_twist.release(); h->h_s.release(); h->h_wrench.release(); h->h_sdot.release();
+    h->h_ins.release(); h->h_counts.release();
+    for (int k = 0; k < EV_COUNT; ++k)
+        if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char *pfc_last_error(pfc_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int *tri, int n_tet, const int *tet,
+                 const double *eps, double Ebar, int n_node, const double *node_c, const double *node_e,
+                 const double *node_R, const int *node_child, const int *node_leaf) {
+    if (!h) return -PFC_ERR_BAD_ARG;
+    if (h->finalized) return -fail(h, PFC_ERR_STATE, "pfc_add_mesh after pfc_finalize");
+    if (n_pt <= 0 || !xyz || n_node <= 0 || !node_c || !node_e || !node_R || !node_child || !node_leaf)
+        return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: null or empty argument");
+    const bool has_tri = tri && n_tri > 0, has_tet = tet && n_tet > 0;
+    if (has_tri == has_tet)  // verify_eMesh_ContactProperties: src/mechanism_scenario.jl:301-306
+        return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: exactly one of tri / tet must be given");
+    if (has_tet && !eps) return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: tet mesh without eps");
+    HostMesh m;
+    m.n_pt = n_pt; m.n_tri = has_tri ? n_tri : 0; m.n_tet = has_tet ? n_tet : 0; m.n_node = n_node; m.Ebar = Ebar;
+    const int n_elem = has_tri ? n_tri : n_tet;
+    for (int k = 0; k < 3 * n_pt; ++k)
+        if (!std::isfinite(xyz[k])) return -fail(h, PFC_ERR_NONFINITE, "pfc_add_mesh: non-finite vertex");
+    m.xyz.assign(xyz, xyz + 3 * (size_t)n_pt);
+    if (has_tri) {
+        for (int k = 0; k < 3 * n_tri; ++k)
+            if (tri[k] < 0 || tri[k] >= n_pt) return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: triangle index out of range");
+        m.tri.assign(tri, tri + 3 * (size_t)n_tri);
+    } else {
+        for (int k = 0; k < 4 * n_tet; ++k)
+            if (tet[k] < 0 || tet[k] >= n_pt) return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: tet index out of range");
+        m.tet.assign(tet, tet + 4 * (size_t)n_tet);
+        m.eps.assign(eps, eps + n_pt);
+        // (0.0 < volume(point[tet[k]])) || error("inverted tetrahedron"): src/geometry/mesh.jl:27-29,
+        // volume: src/math_kernel/geometry_kernel.jl:22-38
+        for (int k = 0; k < n_tet; ++k) {
+            const double *a = xyz + 3 * (size_t)tet[4 * k], *b = xyz + 3 * (size_t)tet[4 * k + 1];
+            const double *c = xyz + 3 * (size_t)tet[4 * k + 2], *d = xyz + 3 * (size_t)tet[4 * k + 3];
+            double V = (b[0] - a[0]) * (c[1] * d[2] - c[2] * d[1]);
+            V = std::fma(b[1] - a[1], c[2] * d[0] - c[0] * d[2], V);
+            V = std::fma(b[2] - a[2], c[0] * d[1] - c[1] * d[0], V);
+            V = std::fma(c[0] - d[0], a[2] * b[1] - a[1] * b[2], V);
+            V = std::fma(c[1] - d[1], a[0] * b[2] - a[2] * b[0], V);
+            V = std::fma(c[2] - d[2], a[1] * b[0] - a[0] * b[1], V);
+            if (!(0.0 < V * (1.0 / 6.0))) return -fail(h, PFC_ERR_INVERTED_TET, "inverted tetrahedron %d", k);
+        }
+    }
+    m.nodes.resize(n_node);
+    int n_leaf = 0;
+    for (int k = 0; k < n_node; ++k) {
+        NodeRec &r = m.nodes[k];
+        for (int j = 0; j < 3; ++j) { r.c[j] = node_c[3 * k + j]; r.e[j] = node_e[3 * k + j]; }
+        for (int j = 0; j < 9; ++j) r.R[j] = node_R[9 * k + j];
+        r.child0 = node_child[2 * k]; r.child1 = node_child[2 * k + 1]; r.leaf = node_leaf[k];
+        static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        r.aabb = std::memcmp(r.R, I9, sizeof I9) == 0 ? 1 : 0;
+        if (r.leaf == kInternal) {
+            if (r.child0 <= 0 || r.child0 >= n_node || r.child1 <= 0 || r.child1 >= n_node)
+                return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: node %d has a bad child index", k);
+        } else {
+            if (r.leaf < 0 || r.leaf >= n_elem) return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: node %d has a bad leaf id", k);
+            ++n_leaf;
+        }
+    }
+    m.depth = tree_depth(m.nodes);
+    if (m.depth < 0) return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: the node array is not a tree");
+    h->meshes.push_back(std::move(m));
+    return (int)h->meshes.size() - 1;
+}
+
+int pfc_add_instruction(pfc_handle h, int id_1, int id_2, double chi, int n_quad, int model, const double *params) {
+    if (!h) return -PFC_ERR_BAD_ARG;
+    if (h->finalized) return -fail(h, PFC_ERR_STATE, "pfc_add_instruction after pfc_finalize");
+    const int nm = (int)h->meshes.size();
+    if (id_1 < 0 || id_1 >= nm || id_2 < 0 || id_2 >= nm || !params)
+        return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_instruction: bad mesh id");
+    if (h->meshes[id_2].n_tet == 0)  // id_2 is always a tet mesh: src/mechanism_scenario.jl:402-416
+        return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_instruction: id_2 must be a tet mesh");
+    if (h->meshes[id_1].n_tri == 0)
+        return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_instruction: tet-tet instructions are not implemented in this build (id_1 must be a triangle mesh)");
+    if (n_quad < 1 || n_quad > 2)  // src/mechanism_scenario.jl:45
+        return -fail(h, PFC_ERR_BAD_ARG, "only quadrature rules 1 and 2 are currently implemented");
+    if (model != PFC_REGULARIZED && model != PFC_BRISTLE) return -fail(h, PFC_ERR_BAD_ARG, "unknown friction model");
+    InsDev in;
+    std::memset(&in, 0, sizeof in);
+    in.m1 = id_1; in.m2 = id_2; in.model = model; in.nq = n_quad; in.chi = chi;
+    in.mu_s = params[0]; in.mu_d = params[1];
+    if (!(in.mu_d <= in.mu_s))  // determine_μs_μd: src/mechanism_scenario.jl:353-356
+        return -fail(h, PFC_ERR_BAD_ARG, "something is wrong: mu_d must be <= mu_s");
+    if (model == PFC_REGULARIZED) {
+        in.v_c = params[2];
+    } else {
+        in.tau = params[2]; in.k_bar = params[3]; in.magic = params[4];
+        if (!(0.0 < in.mu_d)) return -fail(h, PFC_ERR_BAD_ARG, "mu_d cannot be 0 for bristle friction");
+    }
+    h->ins.push_back(in);
+    return (int)h->ins.size() - 1;
+}
+
+int pfc_finalize(pfc_handle h) {
+    if (!h) return PFC_ERR_BAD_ARG;
+    if (h->finalized) return fail(h, PFC_ERR_STATE, "pfc_finalize called twice");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, h->status.ensure(4));
+    HIP_TRY(h, hipMemset(h->status.p, 0, sizeof(unsigned) * 4));
+    std::vector<MeshDev> md(h->meshes.size());
+    for (size_t k = 0; k < h->meshes.size(); ++k) {
+        HostMesh &m = h->meshes[k];
+        double *d_xyz = nullptr, *d_eps = nullptr;
+        int *d_idx = nullptr;
+        HIP_TRY(h, hipMalloc((void **)&m.d_nodes, sizeof(NodeRec) * m.nodes.size()));
+        HIP_TRY(h, hipMemcpy(m.d_nodes, m.nodes.data(), sizeof(NodeRec) * m.nodes.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMalloc((void **)&d_xyz, sizeof(double) * m.xyz.size()));
+        HIP_TRY(h, hipMemcpy(d_xyz, m.xyz.data(), sizeof(double) * m.xyz.size(), hipMemcpyHostToDevice));
+        if (m.n_tri) {
+            HIP_TRY(h, hipMalloc((void **)&d_idx, sizeof(int) * m.tri.size()));
+            HIP_TRY(h, hipMemcpy(d_idx, m.tri.data(), sizeof(int) * m.tri.size(), hipMemcpyHostToDevice));
+            HIP_TRY(h, hipMalloc((void **)&m.d_tri, sizeof(TriRec) * m.n_tri));
+            hipLaunchKernelGGL(k_prep_tri, dim3((m.n_tri + 127) / 128), dim3(128), 0, h->stream, m.n_tri, d_xyz, d_idx, m.d_tri);
+        } else {
+            HIP_TRY(h, hipMalloc((void **)&d_idx, sizeof(int) * m.tet.size()));
+            HIP_TRY(h, hipMemcpy(d_idx, m.tet.data(), sizeof(int) * m.tet.size(), hipMemcpyHostToDevice));
+            HIP_TRY(h, hipMalloc((void **)&d_eps, sizeof(double) * m.eps.size()));
+            HIP_TRY(h, hipMemcpy(d_eps, m.eps.data(), sizeof(double) * m.eps.size(), hipMemcpyHostToDevice));
+            HIP_TRY(h, hipMalloc((void **)&m.d_tet, sizeof(TetRec) * m.n_tet));
+            hipLaunchKernelGGL(k_prep_tet, dim3((m.n_tet + 127) / 128), dim3(128), 0, h->stream, m.n_tet, d_xyz, d_eps, d_idx,
+                               m.d_tet, h->status.p);
+        }
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(d_xyz); (void)hipFree(d_idx);
+        if (d_eps) (void)hipFree(d_eps);
+        md[k].nodes = m.d_nodes; md[k].tri = m.d_tri; md[k].tet = m.d_tet; md[k].Ebar = m.Ebar;
+        md[k].n_tri = m.n_tri; md[k].n_tet = m.n_tet; md[k].n_node = m.n_node; md[k].depth = m.depth;
+    }
+    unsigned status = 0;
+    HIP_TRY(h, hipMemcpy(&status, h->status.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (status & kStNonFinite) return fail(h, PFC_ERR_NONFINITE, "singular tetrahedron (non-finite zeta transform)");
+    if (!md.empty()) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_meshes, sizeof(MeshDev) * md.size()));
+        HIP_TRY(h, hipMemcpy(h->d_meshes, md.data(), sizeof(MeshDev) * md.size(), hipMemcpyHostToDevice));
+    }
+    h->max_levels = 1;
+    h->any_bristle = false;
+    for (const InsDev &in : h->ins) {
+        int lv = h->meshes[in.m1].depth + h->meshes[in.m2].depth + 1;
+        if (lv > h->max_levels) h->max_levels = lv;
+        if (in.model == PFC_BRISTLE) h->any_bristle = true;
+    }
+    if (!h->ins.empty()) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_ins, sizeof(InsDev) * h->ins.size()));
+        HIP_TRY(h, hipMemcpy(h->d_ins, h->ins.data(), sizeof(InsDev) * h->ins.size(), hipMemcpyHostToDevice));
+    }
+    h->finalized = true;
+    return PFC_OK;
+}
+
+int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
+                    const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, void *stream) {
+    if (!h) return PFC_ERR_BAD_ARG;
+    if (!h->finalized) return fail(h, PFC_ERR_STATE, "pfc_eval before pfc_finalize");
+    if (n_items < 0) return fail(h, PFC_ERR_BAD_ARG, "negative n_items");
+    if (n_items == 0) { h->pending = false; h->last_n_items = 0; return PFC_OK; }
+    if (h->ins.empty()) return fail(h, PFC_ERR_STATE, "no contact instructions");
+    if (!d_pose || !d_twist || !d_wrench || !d_sdot) return fail(h, PFC_ERR_BAD_ARG, "null buffer");
+    if (!d_ins_ids && n_items > (int)h->ins.size())
+        return fail(h, PFC_ERR_BAD_ARG, "n_items exceeds the number of instructions and no ins_ids given");
+    if (h->any_bristle && !d_s) return fail(h, PFC_ERR_BAD_ARG, "bristle instructions need the state buffer s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return enqueue_eval(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts,
+                        stream ? (hipStream_t)stream : h->stream);
+}
+
+int pfc_check(pfc_handle h) {
+    if (!h) return PFC_ERR_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return check_eval(h);
+}
+
+int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, const double *twist,
+             const double *s, double *wrench, double *sdot, int *counts) {
+    if (!h) return PFC_ERR_BAD_ARG;
+    if (!h->finalized) return fail(h, PFC_ERR_STATE, "pfc_eval before pfc_finalize");
+    if (n_items < 0) return fail(h, PFC_ERR_BAD_ARG, "negative n_items");
+    if (n_items == 0) return PFC_OK;
+    if (!pose || !twist || !wrench || !sdot) return fail(h, PFC_ERR_BAD_ARG, "null buffer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = (size_t)n_items;
+    HIP_TRY(h, h->h_pose.ensure(n * 24)); HIP_TRY(h, h->h_twist.ensure(n * 6)); HIP_TRY(h, h->h_s.ensure(n * 6));
+    HIP_TRY(h, h->h_wrench.ensure(n * 6)); HIP_TRY(h, h->h_sdot.ensure(n * 6)); HIP_TRY(h, h->h_counts.ensure(n * 4));
+    HIP_TRY(h, h->h_ins.ensure(n));
+    hipStream_t st = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->h_pose.p, pose, sizeof(double) * n * 24, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->h_twist.p, twist, sizeof(double) * n * 6, hipMemcpyHostToDevice, st));
+    if (s) HIP_TRY(h, hipMemcpyAsync(h->h_s.p, s, sizeof(double) * n * 6, hipMemcpyHostToDevice, st));
+    if (ins_ids) HIP_TRY(h, hipMemcpyAsync(h->h_ins.p, ins_ids, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    int rc = PFC_OK;
+    for (int attempt = 0; attempt < 40; ++attempt) {
+        rc = pfc_eval_device(h, n_items, ins_ids ? h->h_ins.p : nullptr, h->h_pose.p, h->h_twist.p,
+                             s ? h->h_s.p : nullptr, h->h_wrench.p, h->h_sdot.p, h->h_counts.p, st);
+        if (rc != PFC_OK) return rc;
+        rc = check_eval(h);
+        if (rc != PFC_ERR_OVERFLOW) break;
+    }
+    if (rc != PFC_OK) return rc;
+    HIP_TRY(h, hipMemcpy(wrench, h->h_wrench.p, sizeof(double) * n * 6, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(sdot, h->h_sdot.p, sizeof(double) * n * 6, hipMemcpyDeviceToHost));
+    if (counts) HIP_TRY(h, hipMemcpy(counts, h->h_counts.p, sizeof(int) * n * 4, hipMemcpyDeviceToHost));
+    return PFC_OK;
+}
+
+int pfc_set_option(pfc_handle h, const char *name, long long value) {
+    if (!h || !name) return PFC_ERR_BAD_ARG;
+    if (!std::strcmp(name, "debug")) h->opt_debug = value != 0;
+    else if (!std::strcmp(name, "profile")) h->opt_profile = value != 0;
+    else if (!std::strcmp(name, "max_levels")) h->opt_max_levels = (int)value;
+    else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
+    return PFC_OK;
+}
+
+int pfc_get_stats(pfc_handle h, long long *out8) {
+    if (!h || !out8) return PFC_ERR_BAD_ARG;
+    for (int k = 0; k < 8; ++k) out8[k] = h->stats[k];
+    return PFC_OK;
+}
+
+int pfc_get_stage_ms(pfc_handle h, float *out6) {
+    if (!h || !out6) return PFC_ERR_BAD_ARG;
+    if (!h->ev_valid) return fail(h, PFC_ERR_STATE, "profile option was off for the last evaluation");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(h->ev[EV_FIN]));
+    for (int k = 0; k < 5; ++k) HIP_TRY(h, hipEventElapsedTime(&out6[k], h->ev[k], h->ev[k + 1]));
+    HIP_TRY(h, hipEventElapsedTime(&out6[5], h->ev[EV_START], h->ev[EV_FIN]));
+    return PFC_OK;
+}
+
+int pfc_debug_pairs(pfc_handle h, int item, int *pairs, int *clip_n, int cap) {
+    if (!h) return -PFC_ERR_BAD_ARG;
+    if (!h->opt_debug) return -fail(h, PFC_ERR_STATE, "debug option is off");
+    if (h->pending) { int rc = check_eval(h); if (rc) return -rc; }
+    if (item < 0 || item >= h->last_n_items) return -fail(h, PFC_ERR_BAD_ARG, "bad item");
+    size_t nc = (size_t)h->stats[1];
+    std::vector<WorkRec> c(nc);
+    std::vector<int> cn(nc);
+    if (nc) {
+        if (hipMemcpy(c.data(), h->cand.p, sizeof(WorkRec) * nc, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(cn.data(), h->clip_n.p, sizeof(int) * nc, hipMemcpyDeviceToHost) != hipSuccess)
+            return -fail(h, PFC_ERR_HIP, "copy failed");
+    }
+    int n = 0;
+    for (size_t k = 0; k < nc; ++k)
+        if (c[k].item == item) {
+            if (n < cap) {
+                if (pairs) { pairs[2 * n] = c[k].a; pairs[2 * n + 1] = c[k].b; }
+                if (clip_n) clip_n[n] = cn[k];
+            }
+            ++n;
+        }
+    return n;
+}
+
+int pfc_debug_tractions(pfc_handle h, int item, double *buf, int cap) {
+    if (!h) return -PFC_ERR_BAD_ARG;
+    if (!h->opt_debug) return -fail(h, PFC_ERR_STATE, "debug option is off");
+    if (h->pending) { int rc = check_eval(h); if (rc) return -rc; }
+    if (item < 0 || item >= h->last_n_items) return -fail(h, PFC_ERR_BAD_ARG, "bad item");
+    size_t nt = (size_t)h->stats[3];
+    std::vector<int> ti(nt);
+    std::vector<double> td(nt * 8);
+    if (nt) {
+        if (hipMemcpy(ti.data(), h->trac_item.p, sizeof(int) * nt, hipMemcpyDeviceToHost) != hipSuccess)
+            return -fail(h, PFC_ERR_HIP, "copy failed");
+        for (int a = 0; a < 8; ++a)
+            if (hipMemcpy(td.data() + a * nt, h->trac_d.p + a * h->tcap, sizeof(double) * nt, hipMemcpyDeviceToHost) != hipSuccess)
+                return -fail(h, PFC_ERR_HIP, "copy failed");
+    }
+    int n = 0;
+    for (size_t k = 0; k < nt; ++k)
+        if (ti[k] == item) {
+            if (n < cap && buf)
+                for (int a = 0; a < 8; ++a) buf[8 * (size_t)n + a] = td[a * nt + k];
+            ++n;
+        }
+    return n;
+}
+
+int pfc_debug_stiffness(pfc_handle h, int item, double *K36, double *Kis36, double *Sinv6, double *cop3) {
+    if (!h) return -PFC_ERR_BAD_ARG;
+    if (h->pending) { int rc = check_eval(h); if (rc) return -rc; }
+    if (item < 0 || item >= h->last_n_items) return -fail(h, PFC_ERR_BAD_ARG, "bad item");
+    std::vector<double> r(kResStride);
+    int ic[4];
+    if (hipMemcpy(r.data(), h->res.p + (size_t)item * kResStride, sizeof(double) * kResStride, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(ic, h->icnt.p + 4 * (size_t)item, sizeof ic, hipMemcpyDeviceToHost) != hipSuccess)
+        return -fail(h, PFC_ERR_HIP, "copy failed");
+    if (ic[3] == 0) return 0;
+    if (K36) std::memcpy(K36, r.data() + kResK, sizeof(double) * 36);
+    if (Kis36) std::memcpy(Kis36, r.data() + kResKis, sizeof(double) * 36);
+    if (Sinv6) std::memcpy(Sinv6, r.data() + kResSinv, sizeof(double) * 6);
+    if (cop3) std::memcpy(cop3, r.data() + kResCop, sizeof(double) * 3);
+    return 1;
+}
+
+int pfc_selftest_math(pfc_handle h, int n, const double *x, const double *y, double *out3n) {
+    if (!h || n <= 0 || !x || !y || !out3n) return PFC_ERR_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&dx, sizeof(double) * n));
+    HIP_TRY(h, hipMalloc((void **)&dy, sizeof(double) * n));
+    HIP_TRY(h, hipMalloc((void **)&dout, sizeof(double) * 3 * (size_t)n));
+    HIP_TRY(h, hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(dy, y, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, dx, dy, dout);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out3n, dout, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return PFC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// pfc_kernels.h — device records and device-side math of libpfc_hip (gfx950 / CDNA4, wave64).
+//
+// Everything here is Float64 vector ALU work: branchy small-polygon geometry, no MFMA.  The arithmetic of every
+// predicate-relevant expression follows the reference's operation order (cited per function, paths relative to
+// the reference repository) so that candidate pairs and clipped-polygon vertex counts are bit-identical to the
+// CPU oracle; the file is compiled with -ffp-contract=off and the reference's `muladd` sites are explicit fma.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pfc {
+
+constexpr int kInternal = -9999;  // src/obb/tree_types.jl:11,56
+constexpr int kWave = 64;
+
+// status word bits (device -> host)
+enum : unsigned {
+    kStNonFinite = 1u,
+    kStFrontierOvf = 2u,
+    kStCandOvf = 4u,
+    kStTracOvf = 8u,
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// HBM records.  Element-expanded AoS: a lane that owns one (triangle, tet) pair gathers two contiguous records
+// (96 B + 256 B) instead of 7 index-chased vertices; the per-tet zeta transforms are precomputed once at
+// pfc_finalize because meshes are immutable afterwards (src/mechanism_scenario.jl:206).
+// ---------------------------------------------------------------------------------------------------------------
+struct alignas(16) NodeRec {  // OBB{c,e,R} + bin_BB_Tree links: src/obb/box_types.jl:4-9, tree_types.jl:1-16
+    double c[3];
+    double e[3];
+    double R[9];  // column-major
+    int child0, child1;
+    int leaf;   // element index or kInternal
+    int aabb;   // 1 if R is exactly the identity (all merged/internal boxes: src/obb/util.jl:47-51)
+};
+static_assert(sizeof(NodeRec) == 144, "NodeRec layout");
+
+struct alignas(16) TriRec {  // triangle_vertices (non_friction.jl:145) + triangleNormal (geometry_kernel.jl:10)
+    double v[9];  // v1, v2, v3 in frame r1
+    double n[3];  // unit normal in frame r1
+};
+static_assert(sizeof(TriRec) == 96, "TriRec layout");
+
+struct alignas(16) TetRec {  // tetrahedron_vertices_ϵ + calc_ζ_transforms (non_friction.jl:150-162)
+    double xrz[12];  // x_r2_ζ2 rows 1..3, column-major 3x4 (= the 4 vertices); row 4 is all ones
+    double xzr[16];  // x_ζ2_r2 = inv([v1 v2 v3 v4; 1 1 1 1]), column-major 4x4
+    double epsr[4];  // ϵ_r2 = ϵ2 * x_ζ2_r2   (1x4 affine pressure functional), non_friction.jl:202
+};
+static_assert(sizeof(TetRec) == 256, "TetRec layout");
+
+struct MeshDev {
+    const NodeRec *nodes;
+    const TriRec *tri;
+    const TetRec *tet;
+    double Ebar;
+    int n_tri, n_tet, n_node, depth;
+};
+
+struct InsDev {  // ContactInstructions + friction model: src/mechanism_scenario.jl:5-49
+    int m1, m2, model, nq;
+    double chi, mu_s, mu_d, v_c, tau, k_bar, magic, pad;
+};
+
+struct alignas(16) ItemRec {  // per (instruction, pose) item: outputs of refreshBodyBodyTransform!/Cache!
+    double R21[9], t21[3];    // x_r2_r1
+    double R12[9], t12[3];    // x_r1_r2  (= TT_Cache.R_a_b, t_a_b: src/obb/tree_types.jl:43-50)
+    double w[3], v[3];        // twist_r2_r1_r2
+    double s[6];              // bristle state
+    double chi, Ebar, mu_s, mu_d, v_c, tau, k_bar, magic;
+    const NodeRec *nodes1, *nodes2;
+    const TriRec *tri;
+    const TetRec *tet;
+    int model, nq, ins, pad;  // nq = number of quadrature points (1 or 3)
+};
+
+struct alignas(16) WorkRec {  // frontier entry (item, node_a, node_b) or candidate (item, i_1, i_2)
+    int item, a, b, pad;
+};
+
+// per-item accumulator slots (doubles)
+constexpr int kAccWrench = 0;   // 6: regularized total wrench, or bristle normal wrench [ang; lin]
+constexpr int kAccIp = 6;       // 1: ∫p dA
+constexpr int kAccIpc = 7;      // 3: ∫p r dA
+constexpr int kAccK11 = 10;     // 6: xx xy xz yy yz zz
+constexpr int kAccK12 = 16;     // 9: column-major
+constexpr int kAccK22 = 25;     // 6
+constexpr int kAccFric = 31;    // 6: friction wrench about the cop [ang; lin]
+constexpr int kAccStride = 40;
+// per-item derived results (doubles)
+constexpr int kResCop = 0;      // 3
+constexpr int kResSinv = 3;     // 6
+constexpr int kResDelta = 9;    // 6
+constexpr int kResKis = 15;     // 36  K̄^{-1/2}
+constexpr int kResK = 51;       // 36
+constexpr int kResStride = 88;
+
+// ---------------------------------------------------------------------------------------------------------------
+// small vector helpers (StaticArrays evaluation order: left-to-right sums, no contraction)
+// ---------------------------------------------------------------------------------------------------------------
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 mk3(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 ld3(const double *p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 operator/(V3 a, double s) { return V3{a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// StaticArrays normalize(a) = inv(norm(a)) * a
+__device__ __forceinline__ V3 normalize(V3 a) {
+    double s = 1.0 / __builtin_sqrt(dot(a, a));
+    return V3{s * a.x, s * a.y, s * a.z};
+}
+// src/math_kernel/geometry_kernel.jl:5-9
+__device__ __forceinline__ V3 vector_area(V3 a, V3 b, V3 c) { return cross(b - a, c - b) * 0.5; }
+__device__ __forceinline__ double triangle_area(V3 a, V3 b, V3 c, V3 n) { return dot(n, vector_area(a, b, c)); }
+// src/math_kernel/vector_projections.jl:2-7
+__device__ __forceinline__ V3 vec_sub_vec_proj(V3 v, V3 n) {
+    double t = -dot(v, n);
+    return V3{__builtin_fma(t, n.x, v.x), __builtin_fma(t, n.y, v.y), __builtin_fma(t, n.z, v.z)};
+}
+// src/contact_algorithms_friction.jl:2-10
+__device__ __forceinline__ double clamped_piecewise(double x, double x1, double x2, double y1, double y2) {
+    double k = (y2 - y1) / (x2 - x1);
+    double y = y1 + (x - x1) * k;
+    return (y > y1) ? y1 : ((y < y2) ? y2 : y);
+}
+
+// 4x4 inverse by 2x2 minors, adjugate x (1/det); stands in for StaticArrays inv(::SMatrix{4,4})
+// (src/contact_algorithms_non_friction.jl:160).  a, b column-major.  Returns 1/det.
+__device__ __forceinline__ double inv4(const double *a, double *b) {
+#define A_(i, j) a[(i) + 4 * (j)]
+#define B_(i, j) b[(i) + 4 * (j)]
+    double s0 = A_(0, 0) * A_(1, 1) - A_(1, 0) * A_(0, 1);
+    double s1 = A_(0, 0) * A_(1, 2) - A_(1, 0) * A_(0, 2);
+    double s2 = A_(0, 0) * A_(1, 3) - A_(1, 0) * A_(0, 3);
+    double s3 = A_(0, 1) * A_(1, 2) - A_(1, 1) * A_(0, 2);
+    double s4 = A_(0, 1) * A_(1, 3) - A_(1, 1) * A_(0, 3);
+    double s5 = A_(0, 2) * A_(1, 3) - A_(1, 2) * A_(0, 3);
+    double c5 = A_(2, 2) * A_(3, 3) - A_(3, 2) * A_(2, 3);
+    double c4 = A_(2, 1) * A_(3, 3) - A_(3, 1) * A_(2, 3);
+    double c3 = A_(2, 1) * A_(3, 2) - A_(3, 1) * A_(2, 2);
+    double c2 = A_(2, 0) * A_(3, 3) - A_(3, 0) * A_(2, 3);
+    double c1 = A_(2, 0) * A_(3, 2) - A_(3, 0) * A_(2, 2);
+    double c0 = A_(2, 0) * A_(3, 1) - A_(3, 0) * A_(2, 1);
+    double det = ((((s0 * c5 - s1 * c4) + s2 * c3) + s3 * c2) - s4 * c1) + s5 * c0;
+    double id = 1.0 / det;
+    B_(0, 0) = ((A_(1, 1) * c5 - A_(1, 2) * c4) + A_(1, 3) * c3) * id;
+    B_(0, 1) = ((-A_(0, 1) * c5 + A_(0, 2) * c4) - A_(0, 3) * c3) * id;
+    B_(0, 2) = ((A_(3, 1) * s5 - A_(3, 2) * s4) + A_(3, 3) * s3) * id;
+    B_(0, 3) = ((-A_(2, 1) * s5 + A_(2, 2) * s4) - A_(2, 3) * s3) * id;
+    B_(1, 0) = ((-A_(1, 0) * c5 + A_(1, 2) * c2) - A_(1, 3) * c1) * id;
+    B_(1, 1) = ((A_(0, 0) * c5 - A_(0, 2) * c2) + A_(0, 3) * c1) * id;
+    B_(1, 2) = ((-A_(3, 0) * s5 + A_(3, 2) * s2) - A_(3, 3) * s1) * id;
+    B_(1, 3) = ((A_(2, 0) * s5 - A_(2, 2) * s2) + A_(2, 3) * s1) * id;
+    B_(2, 0) = ((A_(1, 0) * c4 - A_(1, 1) * c2) + A_(1, 3) * c0) * id;
+    B_(2, 1) = ((-A_(0, 0) * c4 + A_(0, 1) * c2) - A_(0, 3) * c0) * id;
+    B_(2, 2) = ((A_(3, 0) * s4 - A_(3, 1) * s2) + A_(3, 3) * s0) * id;
+    B_(2, 3) = ((-A_(2, 0) * s4 + A_(2, 1) * s2) - A_(2, 3) * s0) * id;
+    B_(3, 0) = ((-A_(1, 0) * c3 + A_(1, 1) * c1) - A_(1, 2) * c0) * id;
+    B_(3, 1) = ((A_(0, 0) * c3 - A_(0, 1) * c1) + A_(0, 2) * c0) * id;
+    B_(3, 2) = ((-A_(3, 0) * s3 + A_(3, 1) * s1) - A_(3, 2) * s0) * id;
+    B_(3, 3) = ((A_(2, 0) * s3 - A_(2, 1) * s1) + A_(2, 2) * s0) * id;
+#undef A_
+#undef B_
+    return id;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// OBB-OBB separating-axis test, src/obb/bb_intersection.jl:2-74.
+// The reference composes three 4x4 homogeneous transforms per node pair (:3-7); products with the structural
+// zeros/ones of those matrices are exact, so they are skipped here without changing any bit of R_tot / t.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sat15(const double *ea, const double *eb, const double *t, const double *R,
+                                      const double *aR) {
+#define R_(i, j) R[(i) + 3 * (j)]
+#define AR_(i, j) aR[(i) + 3 * (j)]
+    bool sep = false;
+    // face test 1/2 (:29-32)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double rb = (AR_(i, 0) * eb[0] + AR_(i, 1) * eb[1]) + AR_(i, 2) * eb[2];
+        sep |= (ea[i] + rb) < __builtin_fabs(t[i]);
+    }
+    if (sep) return false;
+    // face test 2/2 (:35-38)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double tl = __builtin_fabs((R_(0, j) * t[0] + R_(1, j) * t[1]) + R_(2, j) * t[2]);
+        double ra = (AR_(0, j) * ea[0] + AR_(1, j) * ea[1]) + AR_(2, j) * ea[2];
+        sep |= (ra + eb[j]) < tl;
+    }
+    if (sep) return false;
+    // s100(r) = (r2, r1, r1), s221(r) = (r3, r3, r2) (1-based; :14-15)
+    constexpr int i100[3] = {1, 0, 0}, i221[3] = {2, 2, 1};
+    // cross tests 1/3..3/3 (:56-72)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double tl = __builtin_fabs(t[2] * R_(1, j) - t[1] * R_(2, j));
+        double ra = ea[1] * AR_(2, j) + ea[2] * AR_(1, j);
+        double rb = eb[i100[j]] * AR_(0, i221[j]) + eb[i221[j]] * AR_(0, i100[j]);
+        sep |= (ra + rb) < tl;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double tl = __builtin_fabs(t[0] * R_(2, j) - t[2] * R_(0, j));
+        double ra = ea[0] * AR_(2, j) + ea[2] * AR_(0, j);
+        double rb = eb[i100[j]] * AR_(1, i221[j]) + eb[i221[j]] * AR_(1, i100[j]);
+        sep |= (ra + rb) < tl;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double tl = __builtin_fabs(t[1] * R_(0, j) - t[0] * R_(1, j));
+        double ra = ea[0] * AR_(1, j) + ea[1] * AR_(0, j);
+        double rb = eb[i100[j]] * AR_(2, i221[j]) + eb[i221[j]] * AR_(2, i100[j]);
+        sep |= (ra + rb) < tl;
+    }
+#undef R_
+#undef AR_
+    return !sep;
+}
+
+// BB_BB_intersect(tt, a, b) (:2-12): dh_final = inv(dh_a) * dh_a_b * dh_b, then the 15-axis test.
+__device__ __forceinline__ bool bb_bb_intersect(const NodeRec &a, const NodeRec &b, const double *Rab,
+                                                const double *tab) {
+    double R[9], aR[9], t[3];
+    // tmp = i_dh_a * dh_a_b, with i_dh_a = [Ra' | (-Ra') ca]
+    double T[9], tt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        // row i of Ra' = column i of Ra
+        double r0 = a.R[3 * i], r1 = a.R[3 * i + 1], r2 = a.R[3 * i + 2];
+        double nt = ((-r0) * a.c[0] + (-r1) * a.c[1]) + (-r2) * a.c[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T[i + 3 * j] = (r0 * Rab[3 * j] + r1 * Rab[3 * j + 1]) + r2 * Rab[3 * j + 2];
+        tt[i] = ((r0 * tab[0] + r1 * tab[1]) + r2 * tab[2]) + nt;
+    }
+    // fin = tmp * dh_b, with dh_b = [Rb | cb]
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double r = (T[i] * b.R[3 * j] + T[i + 3] * b.R[3 * j + 1]) + T[i + 6] * b.R[3 * j + 2];
+            R[i + 3 * j] = r;
+            aR[i + 3 * j] = __builtin_fabs(r) + 1.0e-14;
+        }
+        t[i] = ((T[i] * b.c[0] + T[i + 3] * b.c[1]) + T[i + 6] * b.c[2]) + tt[i];
+    }
+    return sat15(a.e, b.e, t, R, aR);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ int prefix_count(unsigned long long mask) {  // set bits of mask below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace pfc
