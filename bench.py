@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the contact hot path on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 the driver launches it under
+``python -m torch.distributed.run --nproc-per-node N`` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json metric / configs[2], "C3"): a 9 680-tet compliant blob against a 5 120-triangle rigid
+tool, bristle friction, evaluated for a batch of independent Monte-Carlo poses.  One *step* = one pass of the whole
+hot path (OBB-tree broadphase -> tri/tet clip + quadrature -> bristle friction reductions) over the batch, with
+meshes, trees, poses, twists and bristle states already resident in HBM, plus (N > 1) the RCCL all-gather of the
+per-item [wrench, sdot] rows.  Work per GPU is fixed as N grows (weak scaling): rank r evaluates its own
+``--poses`` poses (PRNG streams r*poses ...).
+
+metric  = tet-tri clip+integrate ops/s, one op = one broadphase candidate (triangle, tet) pair pushed through
+          the narrowphase; contact-pairs/s (items/s) is reported beside it.
+roofline: HBM-bound (no MFMA: branchy Float64 geometry); ``achieved`` = algorithmic bytes (236 B per op for
+          the narrowphase kernel, 240 B per OBB node test for the broadphase kernel) / kernel time measured with
+          HIP events on the launch stream inside libpfc_hip (pfc_get_stage_ms).
+cpu_baseline: the plain-C oracle (a scalar port of the reference algorithm; the Julia reference cannot run here)
+          timed single-threaded on a bounded sample of the same poses, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_OP = 236          # pair 8 + tri idx 12 + 3 verts 72 + tet idx 16 + 4 verts 96 + 4 eps 32
+BYTES_PER_NODE_TEST = 240   # 2 x (c 24 + e 24 + R 72)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(pfc, w, budget_s: float):
+    """Oracle ("port") timed on the host: items evaluated one after the other, single thread."""
+    from oracle import oracle as O
+    O.build()
+    om = [O.OracleMesh(ms.mesh, ms.tree, ms.Ebar or 0.0) for ms in w.meshes]
+    c = w.instructions[0]
+    mu_s, mu_d = pfc.scenario.determine_mu_s_mu_d(c.mu_s, c.mu_d)
+    ins = O.make_ins(c.chi, c.n_quad_rule, O.BRISTLE, mu_s, mu_d, tau=c.tau, k_bar=c.k_bar, magic=c.magic)
+    ops = items = 0
+    O.evaluate(om[c.id_1], om[c.id_2], ins, w.pose[0], w.twist[0], w.s[0], debug=False)   # warm
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        r = O.evaluate(om[c.id_1], om[c.id_2], ins, w.pose[k % w.n_items], w.twist[k % w.n_items],
+                       w.s[k % w.n_items], debug=False)
+        ops += int(r.counts[1]); items += 1; k += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    return {"value": ops / dt, "unit": "ops/s", "cores": 1, "kind": "port",
+            "sample": f"{items} poses of the same C3 batch, {ops} ops, {dt:.1f} s, oracle/pfc_oracle.c single thread",
+            "contact_pairs_per_s": items / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--poses", type=int, default=2048, help="Monte-Carlo poses (items) per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import pfc_pkg
+    pfc = pfc_pkg.load()
+
+    # ---- synthetic C3 batch; meshes are identical on every rank, poses are rank-specific ---------------------------
+    w = pfc.configs.c3_blob_tool(args.poses, seed=20260103 + 7919 * rank)
+    m = pfc.configs.build_scenario(w, device=local_rank)
+    n = w.n_items
+    d_ins = torch.from_numpy(w.ins_ids.astype(np.int32)).to(dev)
+    d_pose = torch.from_numpy(np.ascontiguousarray(w.pose)).to(dev)
+    d_twist = torch.from_numpy(np.ascontiguousarray(w.twist)).to(dev)
+    d_s = torch.from_numpy(np.ascontiguousarray(w.s)).to(dev)
+    d_out = torch.zeros((n, 12), dtype=torch.float64, device=dev)      # [wrench 6 | sdot 6] per item
+    d_wrench = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    d_sdot = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    d_counts = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    gathered = torch.zeros((world * n, 12), dtype=torch.float64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        # re-issue while a work list overflowed (only happens while buffers are still growing, i.e. in warmup)
+        for _ in range(40):
+            m.eval_device(n, d_ins.data_ptr(), d_pose.data_ptr(), d_twist.data_ptr(), d_s.data_ptr(),
+                          d_wrench.data_ptr(), d_sdot.data_ptr(), d_counts.data_ptr(), stream)
+            if m.check() == 0:
+                break
+        else:
+            raise RuntimeError("work lists kept overflowing")
+        if world > 1:
+            d_out[:, :6] = d_wrench
+            d_out[:, 6:] = d_sdot
+            dist.all_gather_into_tensor(gathered, d_out)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    m.set_option("profile", 1)
+    stage = {}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k, v in m.stage_ms().items():
+            stage[k] = stage.get(k, 0.0) + v
+    fence()
+    dt = time.perf_counter() - t0
+    st = m.stats()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(st["candidates"]), float(n), float(st["node_tests"]), float(st["tractions"])],
+                       dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    ops_step, items_step, nodes_step, trac_step = [float(v) for v in tot.tolist()]
+
+    if rank == 0:
+        K = args.steps
+        np_ms = stage["narrowphase"] / K
+        bp_ms = stage["broadphase"] / K
+        roof_np = {"kernel": "k_narrow", "bound": "hbm", "achieved": BYTES_PER_OP * st["candidates"] / (np_ms * 1e-3) / 1e9,
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms_per_launch": np_ms}
+        roof_bp = {"kernel": "k_bp_expand (all levels of one step)", "bound": "hbm",
+                   "achieved": BYTES_PER_NODE_TEST * st["node_tests"] / (bp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "traffic": None, "ms_per_launch": bp_ms}
+        for r in (roof_np, roof_bp):
+            r["frac"] = r["achieved"] / r["peak"]
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # measured offline with rocprofv3 --pmc
+        if os.path.exists(pmc):
+            try:
+                tj = json.load(open(pmc))
+                roof_np["traffic"] = tj.get("k_narrow")
+                roof_bp["traffic"] = tj.get("k_bp_expand")
+            except Exception:
+                pass
+        dominant, other = (roof_bp, roof_np) if bp_ms >= np_ms else (roof_np, roof_bp)
+        out = {
+            "metric": "tet-tri clip+integrate ops/s",
+            "value": ops_step * K / dt,
+            "unit": "ops/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C3: 9680-tet blob x 5120-tri tool, bristle friction, quad rule 2, "
+                                   f"{args.poses} Monte-Carlo poses per GPU per step",
+                       "poses_per_gpu": args.poses, "ops_per_step": ops_step, "node_tests_per_step": nodes_step,
+                       "traction_points_per_step": trac_step,
+                       "exchange": "RCCL all-gather of [wrench, sdot] per item" if world > 1 else "none"},
+            "contact_pairs_per_s": items_step * K / dt,
+            "node_tests_per_s": nodes_step * K / dt,
+            "stage_ms_per_step": {k: v / K for k, v in stage.items()},
+            "roofline": dominant,
+            "roofline_other": other,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(pfc, w, args.cpu_seconds)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(out))
+    m.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -151,7 +151,8 @@ __device__ __forceinline__ void count_per_item(int *icnt, int item, int slot, bo
 }
 
 __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
-    const int n_in = g.fcount[g.level];
+    int n_in = g.fcount[g.level];
+    if (n_in > g.fcap) n_in = g.fcap;  // the previous level overflowed (flagged there); never read past the buffer
     const int stride = gridDim.x * blockDim.x;
     const int lane = lane_id();
     // every lane of a wave runs the same number of iterations so the wave-level ballots are well defined
@@ -230,6 +231,117 @@ __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
 }
 
 // =================================================================================================================
+// broadphase, deep part: one wave per seed node pair, cooperative depth-first descent with the work stack in LDS.
+// Same node-pair tests as the recursion of tree_tree_intersect (src/obb/tree_types.jl:88-111), 64 at a time: each
+// iteration pops up to 64 node pairs from the top of the stack (one per lane), runs the SAT, and pushes the 2 or 4
+// child pairs / stages the leaf-leaf candidates with ballot + mbcnt prefix sums.  No global frontier, no global
+// atomics per test: a seed's candidates leave in runs of up to kDfsOut records (one atomic per flush), which also
+// keeps the candidate list grouped by item for the reductions downstream.
+// =================================================================================================================
+constexpr int kDfsStack = 1024;  // node pairs per wave (8 KiB)
+constexpr int kDfsOut = 320;     // staged candidates per wave (2.5 KiB)
+
+struct DfsArgs {
+    const ItemRec *items;
+    const WorkRec *seeds;
+    const int *n_seed;   // device counter
+    int seed_cap;
+    WorkRec *cand;
+    int *ccount;
+    int ccap;
+    int *icnt;
+    unsigned *status;
+    int reserve;         // 3 * (max remaining depth) + 3 slots kept free for the pure depth-first mode
+};
+
+__global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
+    __shared__ int2 stk[kDfsStack];
+    __shared__ int2 ob[kDfsOut];
+    const int lane = threadIdx.x;
+    int n_seed = *g.n_seed;
+    if (n_seed > g.seed_cap) n_seed = g.seed_cap;
+    for (int sd = blockIdx.x; sd < n_seed; sd += gridDim.x) {
+        const WorkRec s = g.seeds[sd];
+        const int item = __builtin_amdgcn_readfirstlane(s.item);
+        const ItemRec *it = g.items + item;
+        double R12[9], t12[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R12[k] = it->R12[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t12[k] = it->t12[k];
+        const NodeRec *n1 = it->nodes1, *n2 = it->nodes2;
+        int sp = 1, n_out = 0, n_test = 0, n_cand = 0;
+        if (lane == 0) stk[0] = make_int2(s.a, s.b);
+        __syncthreads();
+        while (sp > 0) {
+            // wide mode while there is room for 4 children per popped pair above the depth-first reserve
+            int pw = (kDfsStack - g.reserve - sp) / 3;
+            int p = sp < 64 ? sp : 64;
+            if (pw < 1) pw = 1;
+            if (p > pw) p = pw;
+            const bool act = lane < p;
+            int2 e = make_int2(0, 0);
+            if (act) e = stk[sp - 1 - lane];
+            __syncthreads();
+            sp -= p;
+            n_test += p;
+            bool hit = false, la = false, lb = false;
+            int ca0 = 0, ca1 = 0, cb0 = 0, cb1 = 0, leaf_a = 0, leaf_b = 0;
+            if (act) {
+                const NodeRec a = n1[e.x];
+                const NodeRec b = n2[e.y];
+                hit = bb_bb_intersect(a, b, R12, t12);
+                la = a.leaf != kInternal; lb = b.leaf != kInternal;
+                ca0 = a.child0; ca1 = a.child1; cb0 = b.child0; cb1 = b.child1;
+                leaf_a = a.leaf; leaf_b = b.leaf;
+            }
+            const bool is_cand = hit && la && lb;
+            const bool two = hit && (la != lb);
+            const bool four = hit && !la && !lb;
+            const unsigned long long mc = __ballot(is_cand), m2 = __ballot(two), m4 = __ballot(four);
+            if (is_cand) ob[n_out + prefix_count(mc)] = make_int2(leaf_a, leaf_b);
+            n_out += __builtin_popcountll(mc);
+            if (two | four) {
+                int pos = sp + 2 * prefix_count(m2) + 4 * prefix_count(m4);
+                if (two) {
+                    if (la) {  // leaf_1: descend tree_2 (:97-98)
+                        stk[pos] = make_int2(e.x, cb0); stk[pos + 1] = make_int2(e.x, cb1);
+                    } else {   // leaf_2: descend tree_1 (:101-103)
+                        stk[pos] = make_int2(ca0, e.y); stk[pos + 1] = make_int2(ca1, e.y);
+                    }
+                } else {       // (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107)
+                    stk[pos] = make_int2(ca0, cb0); stk[pos + 1] = make_int2(ca1, cb0);
+                    stk[pos + 2] = make_int2(ca0, cb1); stk[pos + 3] = make_int2(ca1, cb1);
+                }
+            }
+            sp += 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
+            __syncthreads();
+            if (n_out > kDfsOut - 64 || (sp == 0 && n_out > 0)) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(g.ccount, n_out);
+                base = __shfl(base, 0, 64);
+                if (base + n_out <= g.ccap) {
+                    for (int j = lane; j < n_out; j += 64) {
+                        WorkRec c;
+                        c.item = item; c.a = ob[j].x; c.b = ob[j].y; c.pad = 0;
+                        g.cand[base + j] = c;
+                    }
+                } else if (lane == 0) {
+                    atomicOr(g.status, kStCandOvf);
+                }
+                n_cand += n_out;
+                n_out = 0;
+                __syncthreads();
+            }
+        }
+        if (lane == 0) {
+            atomicAdd(&g.icnt[4 * (size_t)item], n_test);
+            if (n_cand) atomicAdd(&g.icnt[4 * (size_t)item + 1], n_cand);
+        }
+    }
+}
+
+// =================================================================================================================
 // narrowphase
 // =================================================================================================================
 struct TracSoA {
@@ -289,15 +401,20 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         cw.item = 0; cw.a = 0; cw.b = 0; cw.pad = 0;
         if (active) cw = g.cand[idx];
         const ItemRec *it = g.items + cw.item;
-        int n_poly = 0;
-        double sum[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) sum[k] = 0.0;
-        int n_trac_lane = 0;
-        const bool materialise = active && (g.debug || it->model == PFC_BRISTLE);
+        const TetRec *tp = it->tet + cw.b;
+        const int nq = it->nq;
+        const bool reg = it->model == PFC_REGULARIZED;
+        const bool materialise = active && (g.debug || !reg);
+        int n_poly = 0, cur = 0;
+        V3 nh = mk3(0.0, 0.0, 0.0);
+        // ==== phase 1 (divergent): gather, transform to tet coordinates, clip ========================================
         if (active) {
             const TriRec tr = it->tri[cw.a];
-            const TetRec *tp = it->tet + cw.b;
+            double R21[9], t21[3];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R21[k] = it->R21[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t21[k] = it->t21[k];
             // x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (non_friction.jl:204); last row of x_r2_r1.mat is (0 0 0 1)
             double X[16];
             {
@@ -308,8 +425,8 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
-                        X[i + 4 * j] = (Z[i] * it->R21[3 * j] + Z[i + 4] * it->R21[3 * j + 1]) + Z[i + 8] * it->R21[3 * j + 2];
-                    X[i + 12] = ((Z[i] * it->t21[0] + Z[i + 4] * it->t21[1]) + Z[i + 8] * it->t21[2]) + Z[i + 12];
+                        X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
+                    X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + Z[i + 12];
                 }
             }
             // v_k = x_ζ2_r1 * onePad(vert_k) (:205-207)
@@ -333,7 +450,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             for (int i = 0; i < 4; ++i) reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0);
             if (!reject) {
                 // ---- clip_in_tet_coordinates (static_clip.jl:17-23,34-201), polygon staged in LDS --------------
-                int n = 3, cur = 0;
+                int n = 3;
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -393,123 +510,148 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 }
                 if (err) atomicOr(g.status, kStNonFinite);
                 n_poly = n;
-                if (n >= 3) {
-                    // ---- integrate_over_polygon_patch! (non_friction.jl:217-234) -------------------------------
-                    // n̂2 = R(x_r2_r1) * n̂_r1 (:211-212)
-                    V3 nh = mk3((it->R21[0] * tr.n[0] + it->R21[3] * tr.n[1]) + it->R21[6] * tr.n[2],
-                                (it->R21[1] * tr.n[0] + it->R21[4] * tr.n[1]) + it->R21[7] * tr.n[2],
-                                (it->R21[2] * tr.n[0] + it->R21[5] * tr.n[1]) + it->R21[8] * tr.n[2]);
-                    // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98) -> other LDS buffer (x,y,z)
-                    const int ob = cur ^ 1;
-                    {
-                        double V[12];
-#pragma unroll
-                        for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
-                        for (int k = 0; k < n; ++k) {
-                            double z0 = PZ(cur, k, 0), z1 = PZ(cur, k, 1), z2 = PZ(cur, k, 2), z3 = PZ(cur, k, 3);
-#pragma unroll
-                            for (int c = 0; c < 3; ++c)
-                                PZ(ob, k, c) = ((V[c] * z0 + V[c + 3] * z1) + V[c + 6] * z2) + V[c + 9] * z3;
-                        }
-                    }
-                    // centroid(poly_r2, n̂2) (poly_eight.jl:35-52)
-                    V3 cen;
-                    {
-                        V3 a = mk3(PZ(ob, 0, 0), PZ(ob, 0, 1), PZ(ob, 0, 2));
-                        V3 cc = mk3(PZ(ob, 1, 0), PZ(ob, 1, 1), PZ(ob, 1, 2));
-                        double cum_sum = 0.0;
-                        V3 cum_prod = mk3(0.0, 0.0, 0.0);
-                        for (int k = 2; k < n; ++k) {
-                            V3 b = cc;
-                            cc = mk3(PZ(ob, k, 0), PZ(ob, k, 1), PZ(ob, k, 2));
-                            double ar = triangle_area(a, b, cc, nh);
-                            cum_prod = cum_prod + ((a + b) + cc) * (1.0 / 3.0) * ar;
-                            cum_sum += ar;
-                        }
-                        cen = (cum_sum == 0.0) ? a : cum_prod / cum_sum;
-                    }
-                    const double er0 = tp->epsr[0], er1 = tp->epsr[1], er2 = tp->epsr[2], er3 = tp->epsr[3];
-                    const V3 w = ld3(it->w), vl = ld3(it->v);
-                    const double chi = it->chi, Ebar = it->Ebar;
-                    const int nq = it->nq;
-                    const bool reg = it->model == PFC_REGULARIZED;
-                    V3 v2 = mk3(PZ(ob, n - 1, 0), PZ(ob, n - 1, 1), PZ(ob, n - 1, 2));
-                    for (int k = 0; k < n; ++k) {
-                        V3 v1 = v2;
-                        v2 = mk3(PZ(ob, k, 0), PZ(ob, k, 1), PZ(ob, k, 2));
-                        double area = triangle_area(v1, v2, cen, nh);
-                        if (!(0.0 < area)) continue;  // :232
-                        for (int q = 0; q < nq; ++q) {
-                            // TriTetQuadRule rules 1 and 2, literal decimals of src/clip/quadrature.jl:24-39
-                            double q0, q1, q2, qw;
-                            if (nq == 1) {
-                                q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
-                            } else {
-                                const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
-                                q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
-                                qw = 0.33333333333333331483;
-                            }
-                            // fillTractionCacheInnerLoop! (:251-265)
-                            V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
-                                       (v1.z * q0 + v2.z * q1) + cen.z * q2);
-                            double eq = __builtin_fma(er0, r.x, er3);
-                            eq = __builtin_fma(er1, r.y, eq);
-                            eq = __builtin_fma(er2, r.z, eq);
-                            V3 rdot = vl + cross(w, r);
-                            double ee = -dot(mk3(er0, er1, er2), rdot);
-                            double damp = fmax(0.0, 1.0 + chi * ee);
-                            double p = eq * Ebar * damp;
-                            double dA = qw * area;
-                            if (!(0.0 < p)) continue;  // :245
-                            ++n_trac_lane;
-                            double p_dA = p * dA;
-                            if (materialise) {
-                                int pos = atomicAdd(g.tcount, 1);
-                                if (pos < g.tcap) {
-                                    g.trac.item[pos] = cw.item;
-                                    g.trac.nx[pos] = nh.x; g.trac.ny[pos] = nh.y; g.trac.nz[pos] = nh.z;
-                                    g.trac.rx[pos] = r.x; g.trac.ry[pos] = r.y; g.trac.rz[pos] = r.z;
-                                    g.trac.dA[pos] = dA; g.trac.p[pos] = p;
-                                } else {
-                                    atomicOr(g.status, kStTracOvf);
-                                }
-                            }
-                            V3 tk;
-                            if (reg) {
-                                // yes_contact!(::Regularized) (friction.jl:50-72) fused
-                                V3 vel = vl + cross(w, r);
-                                V3 vt = vec_sub_vec_proj(vel, nh);
-                                double m2 = dot(vt, vt);
-                                V3 T;
-                                if (m2 < it->v_c * it->v_c) {
-                                    T = (vt * (-it->mu_s)) / it->v_c;
-                                } else {
-                                    double mg = __builtin_sqrt(m2);
-                                    double mu = clamped_piecewise(mg, 2 * it->v_c, 3 * it->v_c, it->mu_s, it->mu_d);
-                                    T = (vt * (-mu)) / mg;
-                                }
-                                tk = nh * p_dA + T * p_dA;
-                            } else {
-                                // normal_wrench_cop (normal.jl:17-34) fused: pass 1 of the bristle model
-                                tk = nh * p_dA;
-                                sum[6] += p_dA;
-                                sum[7] += p_dA * r.x; sum[8] += p_dA * r.y; sum[9] += p_dA * r.z;
-                            }
-                            V3 ta = cross(r, tk);
-                            sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
-                            sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
-                        }
-                    }
-                }
+                if (n >= 3)  // n̂2 = R(x_r2_r1) * n̂_r1 (:211-212)
+                    nh = mk3((R21[0] * tr.n[0] + R21[3] * tr.n[1]) + R21[6] * tr.n[2],
+                             (R21[1] * tr.n[0] + R21[4] * tr.n[1]) + R21[7] * tr.n[2],
+                             (R21[2] * tr.n[0] + R21[5] * tr.n[1]) + R21[8] * tr.n[2]);
             }
         }
         if (g.clip_n && active) g.clip_n[idx] = n_poly;
-        // per-item reductions (wave-aggregated)
+        // ==== phase 2 (wave-uniform): reserve a contiguous run of traction slots for the whole wave ================
+        // A lane with an n-gon owns n * nq consecutive slots, so the traction points of a wave (and, because the
+        // candidate list is grouped by item, of an item) are contiguous: the later per-point passes then reduce
+        // wave-uniformly with one atomic per wave instead of one per lane.
+        const int slots = (materialise && n_poly >= 3) ? n_poly * nq : 0;
+        int tbase = 0;
+        {
+            int incl = slots;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            const int tot = __shfl(incl, 63, 64);
+            int base = 0;
+            if (tot > 0) {
+                if (lane == 0) base = atomicAdd(g.tcount, tot);
+                base = __shfl(base, 0, 64);
+            }
+            tbase = base + incl - slots;
+        }
+        // ==== phase 3 (divergent): integrate_over_polygon_patch! (non_friction.jl:217-234) ============================
+        double sum[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) sum[k] = 0.0;
+        int n_trac_lane = 0;
+        if (n_poly >= 3) {
+            const int n = n_poly;
+            // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98) -> other LDS buffer (x,y,z)
+            const int ob = cur ^ 1;
+            {
+                double V[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
+                for (int k = 0; k < n; ++k) {
+                    double z0 = PZ(cur, k, 0), z1 = PZ(cur, k, 1), z2 = PZ(cur, k, 2), z3 = PZ(cur, k, 3);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        PZ(ob, k, c) = ((V[c] * z0 + V[c + 3] * z1) + V[c + 6] * z2) + V[c + 9] * z3;
+                }
+            }
+            // centroid(poly_r2, n̂2) (poly_eight.jl:35-52)
+            V3 cen;
+            {
+                V3 a = mk3(PZ(ob, 0, 0), PZ(ob, 0, 1), PZ(ob, 0, 2));
+                V3 cc = mk3(PZ(ob, 1, 0), PZ(ob, 1, 1), PZ(ob, 1, 2));
+                double cum_sum = 0.0;
+                V3 cum_prod = mk3(0.0, 0.0, 0.0);
+                for (int k = 2; k < n; ++k) {
+                    V3 b = cc;
+                    cc = mk3(PZ(ob, k, 0), PZ(ob, k, 1), PZ(ob, k, 2));
+                    double ar = triangle_area(a, b, cc, nh);
+                    cum_prod = cum_prod + ((a + b) + cc) * (1.0 / 3.0) * ar;
+                    cum_sum += ar;
+                }
+                cen = (cum_sum == 0.0) ? a : cum_prod / cum_sum;
+            }
+            const double er0 = tp->epsr[0], er1 = tp->epsr[1], er2 = tp->epsr[2], er3 = tp->epsr[3];
+            const V3 w = ld3(it->w), vl = ld3(it->v);
+            const double chi = it->chi, Ebar = it->Ebar;
+            const double v_c = it->v_c, mu_s = it->mu_s, mu_d = it->mu_d;
+            const bool store = materialise && (tbase + slots <= g.tcap);
+            if (materialise && !store) atomicOr(g.status, kStTracOvf);
+            int tpos = tbase;
+            V3 v2 = mk3(PZ(ob, n - 1, 0), PZ(ob, n - 1, 1), PZ(ob, n - 1, 2));
+            for (int k = 0; k < n; ++k) {
+                V3 v1 = v2;
+                v2 = mk3(PZ(ob, k, 0), PZ(ob, k, 1), PZ(ob, k, 2));
+                double area = triangle_area(v1, v2, cen, nh);
+                if (!(0.0 < area)) continue;  // :232
+                for (int q = 0; q < nq; ++q) {
+                    // TriTetQuadRule rules 1 and 2, literal decimals of src/clip/quadrature.jl:24-39
+                    double q0, q1, q2, qw;
+                    if (nq == 1) {
+                        q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
+                    } else {
+                        const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
+                        q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
+                        qw = 0.33333333333333331483;
+                    }
+                    // fillTractionCacheInnerLoop! (:251-265)
+                    V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
+                               (v1.z * q0 + v2.z * q1) + cen.z * q2);
+                    double eq = __builtin_fma(er0, r.x, er3);
+                    eq = __builtin_fma(er1, r.y, eq);
+                    eq = __builtin_fma(er2, r.z, eq);
+                    V3 rdot = vl + cross(w, r);
+                    double ee = -dot(mk3(er0, er1, er2), rdot);
+                    double damp = fmax(0.0, 1.0 + chi * ee);
+                    double p = eq * Ebar * damp;
+                    double dA = qw * area;
+                    if (!(0.0 < p)) continue;  // :245
+                    ++n_trac_lane;
+                    double p_dA = p * dA;
+                    if (store) {
+                        g.trac.item[tpos] = cw.item;
+                        g.trac.nx[tpos] = nh.x; g.trac.ny[tpos] = nh.y; g.trac.nz[tpos] = nh.z;
+                        g.trac.rx[tpos] = r.x; g.trac.ry[tpos] = r.y; g.trac.rz[tpos] = r.z;
+                        g.trac.dA[tpos] = dA; g.trac.p[tpos] = p;
+                        ++tpos;
+                    }
+                    V3 tk;
+                    if (reg) {
+                        // yes_contact!(::Regularized) (friction.jl:50-72) fused
+                        V3 vel = vl + cross(w, r);
+                        V3 vt = vec_sub_vec_proj(vel, nh);
+                        double m2 = dot(vt, vt);
+                        V3 T;
+                        if (m2 < v_c * v_c) {
+                            T = (vt * (-mu_s)) / v_c;
+                        } else {
+                            double mg = __builtin_sqrt(m2);
+                            double mu = clamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
+                            T = (vt * (-mu)) / mg;
+                        }
+                        tk = nh * p_dA + T * p_dA;
+                    } else {
+                        // normal_wrench_cop (normal.jl:17-34) fused: pass 1 of the bristle model
+                        tk = nh * p_dA;
+                        sum[6] += p_dA;
+                        sum[7] += p_dA * r.x; sum[8] += p_dA * r.y; sum[9] += p_dA * r.z;
+                    }
+                    V3 ta = cross(r, tk);
+                    sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+                    sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
+                }
+            }
+            if (store)  // unused slots of this lane's run (area <= 0 or p <= 0 points)
+                for (; tpos < tbase + slots; ++tpos) g.trac.item[tpos] = -1;
+        }
+        // ==== phase 4 (wave-uniform): per-item reductions =============================================================
         const bool contributed = active && n_trac_lane > 0;
         accumulate_items(g.acc, cw.item, contributed, sum, 0, 10);
         count_per_item(g.icnt, cw.item, 2, active && n_poly >= 3);
         {
-            // traction counts: wave-uniform item -> one atomic
             unsigned long long m = __ballot(contributed);
             if (m) {
                 int src = __builtin_ctzll(m);
@@ -570,7 +712,8 @@ __global__ void __launch_bounds__(256) k_stiff(BrArgs g) {
         for (int k = 0; k < 21; ++k) v[k] = 0.0;
         if (active) {
             item = g.trac.item[idx];
-            active = g.items[item].model == PFC_BRISTLE;
+            active = item >= 0 && g.items[item].model == PFC_BRISTLE;
+            if (item < 0) item = 0;
         }
         if (active) {
             const double *cop = g.res + (size_t)item * kResStride + kResCop;
@@ -694,7 +837,8 @@ __global__ void __launch_bounds__(256) k_fric(BrArgs g) {
         double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (active) {
             item = g.trac.item[idx];
-            active = g.items[item].model == PFC_BRISTLE;
+            active = item >= 0 && g.items[item].model == PFC_BRISTLE;
+            if (item < 0) item = 0;
         }
         if (active) {
             const ItemRec *it = g.items + item;
@@ -821,7 +965,7 @@ struct pfc_context {
     int max_levels = 1;
     bool any_bristle = false;
     // options
-    int opt_debug = 0, opt_profile = 0, opt_max_levels = 0;
+    int opt_debug = 0, opt_profile = 0, opt_max_levels = 0, opt_bfs_levels = -1;
     // work buffers
     DevBuf<ItemRec> items;
     DevBuf<WorkRec> frontier[2], cand;
@@ -834,10 +978,11 @@ struct pfc_context {
     DevBuf<double> h_pose, h_twist, h_s, h_wrench, h_sdot;
     DevBuf<int> h_ins, h_counts;
     // last evaluation
-    int last_n_items = 0, last_levels = 0;
+    int last_n_items = 0, last_levels = 0, last_bfs_levels = 0;
     bool pending = false;
     hipStream_t last_stream = nullptr;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long last_tslots = 0;         // traction slots used by the last evaluation (>= traction points)
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
 };
@@ -941,8 +1086,17 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     hipLaunchKernelGGL(k_setup_items, dim3(grid_for(n_items, 128, 1 << 20)), dim3(128), 0, st, ea);
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_SETUP], st));
 
-    // broadphase levels
-    for (int lv = 0; lv < levels; ++lv) {
+    // broadphase: a few level-synchronous expansions to get enough independent seed pairs, then the per-wave
+    // depth-first kernel for everything below
+    int L = 0;
+    if (h->opt_bfs_levels >= 0) {
+        L = h->opt_bfs_levels;
+    } else {
+        double seeds = (double)n_items;
+        while (seeds < 65536.0 && L < 8) { seeds *= 4.0; ++L; }
+    }
+    if (L > levels) L = levels;
+    for (int lv = 0; lv < L; ++lv) {
         BpArgs b;
         b.items = h->items.p; b.fin = h->frontier[lv & 1].p; b.fout = h->frontier[(lv + 1) & 1].p;
         b.cand = h->cand.p; b.fcount = fcount; b.ccount = ccount; b.icnt = h->icnt.p; b.status = h->status.p;
@@ -952,6 +1106,16 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
         size_t bound = ub > (double)h->fcap ? h->fcap : (size_t)ub;
         hipLaunchKernelGGL(k_bp_expand, dim3(grid_for(bound, 256, 2048)), dim3(256), 0, st, b);
     }
+    {
+        DfsArgs d;
+        d.items = h->items.p; d.seeds = h->frontier[L & 1].p; d.n_seed = fcount + L; d.seed_cap = (int)h->fcap;
+        d.cand = h->cand.p; d.ccount = ccount; d.ccap = (int)h->ccap; d.icnt = h->icnt.p; d.status = h->status.p;
+        d.reserve = 3 * levels + 3;
+        double ub = (double)n_items * std::pow(4.0, (double)(L < 15 ? L : 15));
+        size_t bound = ub > (double)h->fcap ? h->fcap : (size_t)ub;
+        hipLaunchKernelGGL(k_bp_dfs, dim3(grid_for(bound, 1, 256 * 15)), dim3(64), 0, st, d);
+    }
+    h->last_bfs_levels = L;
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));
 
     NpArgs np;
@@ -993,11 +1157,11 @@ int check_eval(pfc_context *h) {
     HIP_TRY(h, hipMemcpy(&status, h->status.p, sizeof(unsigned), hipMemcpyDeviceToHost));
     long long fpeak = 0;
     int used_levels = 0;
-    for (int lv = 0; lv <= levels; ++lv) {
+    for (int lv = 0; lv <= h->last_bfs_levels && lv <= levels; ++lv) {
         if (ctr[2 + lv] > fpeak) fpeak = ctr[2 + lv];
         if (ctr[2 + lv] > 0) used_levels = lv + 1;
     }
-    h->stats[1] = ctr[0]; h->stats[3] = ctr[1]; h->stats[4] = used_levels; h->stats[5] = fpeak;
+    h->stats[1] = ctr[0]; h->last_tslots = ctr[1]; h->stats[4] = used_levels; h->stats[5] = fpeak;
     h->stats[6] = status; h->stats[7] = h->last_n_items;
     if (status & 16u) return fail(h, PFC_ERR_BAD_ARG, "instruction id out of range in ins_ids");
     if (status & (kStFrontierOvf | kStCandOvf | kStTracOvf)) {
@@ -1008,15 +1172,15 @@ int check_eval(pfc_context *h) {
         return fail(h, PFC_ERR_OVERFLOW, "work list overflow (status %u): capacities grown to frontier %zu, candidates %zu, tractions %zu",
                     status, h->fcap, h->ccap, h->tcap);
     }
-    if (ctr[2 + levels] > 0)
-        return fail(h, PFC_ERR_STATE, "broadphase did not terminate within %d levels", levels);
     if (status & kStNonFinite) return fail(h, PFC_ERR_NONFINITE, "Non-finite vertex likely");
     // totals
     std::vector<int> ic((size_t)h->last_n_items * 4);
     if (!ic.empty()) HIP_TRY(h, hipMemcpy(ic.data(), h->icnt.p, sizeof(int) * ic.size(), hipMemcpyDeviceToHost));
-    long long nt = 0, ne = 0;
-    for (int i = 0; i < h->last_n_items; ++i) { nt += ic[4 * (size_t)i]; ne += ic[4 * (size_t)i + 2]; }
-    h->stats[0] = nt; h->stats[2] = ne;
+    long long nt = 0, ne = 0, np = 0;
+    for (int i = 0; i < h->last_n_items; ++i) {
+        nt += ic[4 * (size_t)i]; ne += ic[4 * (size_t)i + 2]; np += ic[4 * (size_t)i + 3];
+    }
+    h->stats[0] = nt; h->stats[2] = ne; h->stats[3] = np;
     return PFC_OK;
 }
 
@@ -1209,6 +1373,9 @@ int pfc_finalize(pfc_handle h) {
         if (lv > h->max_levels) h->max_levels = lv;
         if (in.model == PFC_BRISTLE) h->any_bristle = true;
     }
+    // the depth-first broadphase keeps 3 * levels + 3 stack slots in reserve (k_bp_dfs)
+    if (3 * h->max_levels + 3 > kDfsStack - 128)
+        return fail(h, PFC_ERR_BAD_ARG, "OBB trees too deep (depth sum %d): rebuild them balanced", h->max_levels - 1);
     if (!h->ins.empty()) {
         HIP_TRY(h, hipMalloc((void **)&h->d_ins, sizeof(InsDev) * h->ins.size()));
         HIP_TRY(h, hipMemcpy(h->d_ins, h->ins.data(), sizeof(InsDev) * h->ins.size(), hipMemcpyHostToDevice));
@@ -1276,6 +1443,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     if (!std::strcmp(name, "debug")) h->opt_debug = value != 0;
     else if (!std::strcmp(name, "profile")) h->opt_profile = value != 0;
     else if (!std::strcmp(name, "max_levels")) h->opt_max_levels = (int)value;
+    else if (!std::strcmp(name, "bfs_levels")) h->opt_bfs_levels = (int)value;
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;
 }
@@ -1326,7 +1494,7 @@ int pfc_debug_tractions(pfc_handle h, int item, double *buf, int cap) {
     if (!h->opt_debug) return -fail(h, PFC_ERR_STATE, "debug option is off");
     if (h->pending) { int rc = check_eval(h); if (rc) return -rc; }
     if (item < 0 || item >= h->last_n_items) return -fail(h, PFC_ERR_BAD_ARG, "bad item");
-    size_t nt = (size_t)h->stats[3];
+    size_t nt = (size_t)h->last_tslots;
     std::vector<int> ti(nt);
     std::vector<double> td(nt * 8);
     if (nt) {
