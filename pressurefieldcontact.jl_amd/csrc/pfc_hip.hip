@@ -10,7 +10,8 @@
 //                   coordinates, trivial reject in registers, Sutherland-Hodgman clip with the polygon staged in
 //                   LDS ([slot][coord][lane] layout: conflict-free per-lane dynamic indexing), fan quadrature,
 //                   pressure; regularized friction fused, bristle items materialise traction points (SoA)
-//   k_cop, k_stiff, k_eig, k_fric   the bristle model's dependent reductions and the 6x6 symmetric eigen solve
+//   k_eig, k_fric   the bristle model: cop + patch stiffness from the origin moments, 6x6 symmetric eigen solve,
+//                   friction pass over the traction points
 //   k_final         per item: wrench, sdot, counts
 #include "pfc_kernels.h"
 
@@ -539,9 +540,11 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             tbase = base + incl - slots;
         }
         // ==== phase 3 (divergent): integrate_over_polygon_patch! (non_friction.jl:217-234) ============================
-        double sum[10];
+        double sum[10], wrr[6];
 #pragma unroll
         for (int k = 0; k < 10; ++k) sum[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wrr[k] = 0.0;
         int n_trac_lane = 0;
         if (n_poly >= 3) {
             const int n = n_poly;
@@ -636,8 +639,11 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                     } else {
                         // normal_wrench_cop (normal.jl:17-34) fused: pass 1 of the bristle model
                         tk = nh * p_dA;
+                        const double wx = p_dA * r.x, wy = p_dA * r.y, wz = p_dA * r.z;
                         sum[6] += p_dA;
-                        sum[7] += p_dA * r.x; sum[8] += p_dA * r.y; sum[9] += p_dA * r.z;
+                        sum[7] += wx; sum[8] += wy; sum[9] += wz;
+                        wrr[0] += wx * r.x; wrr[1] += wx * r.y; wrr[2] += wx * r.z;
+                        wrr[3] += wy * r.y; wrr[4] += wy * r.z; wrr[5] += wz * r.z;
                     }
                     V3 ta = cross(r, tk);
                     sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
@@ -650,6 +656,34 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         // ==== phase 4 (wave-uniform): per-item reductions =============================================================
         const bool contributed = active && n_trac_lane > 0;
         accumulate_items(g.acc, cw.item, contributed, sum, 0, 10);
+        if (__any(contributed && !reg)) {
+            // second moments of the bristle patch about the frame origin; n̂ is constant over a lane's polygon, so
+            // sum w n n' = W n n', sum w (r x n) n' = (Wr x n) n', sum w (r x n)(r x n)' = [n]x Wrr [n]x'
+            const bool cb = contributed && !reg;
+            const double W = sum[6];
+            double v[27];
+            v[0] = W * nh.x * nh.x; v[1] = W * nh.x * nh.y; v[2] = W * nh.x * nh.z;
+            v[3] = W * nh.y * nh.y; v[4] = W * nh.y * nh.z; v[5] = W * nh.z * nh.z;
+            const V3 an = cross(mk3(sum[7], sum[8], sum[9]), nh);
+            v[6] = an.x * nh.x; v[7] = an.y * nh.x; v[8] = an.z * nh.x;
+            v[9] = an.x * nh.y; v[10] = an.y * nh.y; v[11] = an.z * nh.y;
+            v[12] = an.x * nh.z; v[13] = an.y * nh.z; v[14] = an.z * nh.z;
+            {
+                // M = [n]x Wrr (rows), then Saa = M [n]x'  i.e. Saa_ij = (n x (Wrr n-cross column j))...
+                const double xx = wrr[0], xy = wrr[1], xz = wrr[2], yy = wrr[3], yz = wrr[4], zz = wrr[5];
+                // columns of Wrr
+                const V3 c0 = mk3(xx, xy, xz), c1 = mk3(xy, yy, yz), c2 = mk3(xz, yz, zz);
+                // M = [n]x Wrr: column j of M = n x c_j
+                const V3 m0 = cross(nh, c0), m1 = cross(nh, c1), m2 = cross(nh, c2);
+                // Saa = M [n]x' ; row i of Saa = (row i of M) [n]x' = -(row_i x n)... use Saa_i. = n x row_i(M)
+                const V3 r0 = cross(nh, mk3(m0.x, m1.x, m2.x)), r1 = cross(nh, mk3(m0.y, m1.y, m2.y));
+                const V3 r2 = cross(nh, mk3(m0.z, m1.z, m2.z));
+                v[15] = r0.x; v[16] = r0.y; v[17] = r0.z; v[18] = r1.y; v[19] = r1.z; v[20] = r2.z;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[21 + k] = wrr[k];
+            accumulate_items(g.acc, cw.item, cb, v, kAccSnn, 27);
+        }
         count_per_item(g.icnt, cw.item, 2, active && n_poly >= 3);
         {
             unsigned long long m = __ballot(contributed);
@@ -686,63 +720,6 @@ struct BrArgs {
     double *wrench, *sdot;
     int *counts;
 };
-
-__global__ void k_cop(BrArgs g) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.n_items) return;
-    const double *a = g.acc + (size_t)i * kAccStride;
-    double ip = a[kAccIp];
-    double *r = g.res + (size_t)i * kResStride;
-    // cop = ∫p r dA / ∫p dA (normal.jl:33)
-    r[kResCop] = a[kAccIpc] / ip; r[kResCop + 1] = a[kAccIpc + 1] / ip; r[kResCop + 2] = a[kAccIpc + 2] / ip;
-}
-
-// calc_patch_spatial_stiffness! (friction.jl:147-169): one lane per traction point
-__global__ void __launch_bounds__(256) k_stiff(BrArgs g) {
-    int n_t = *g.tcount;
-    if (n_t > g.tcap) n_t = g.tcap;
-    const int stride = gridDim.x * blockDim.x;
-    const int n_round = (n_t + stride - 1) / stride;
-    for (int rd = 0; rd < n_round; ++rd) {
-        int idx = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        bool active = idx < n_t;
-        int item = 0;
-        double v[21];
-#pragma unroll
-        for (int k = 0; k < 21; ++k) v[k] = 0.0;
-        if (active) {
-            item = g.trac.item[idx];
-            active = item >= 0 && g.items[item].model == PFC_BRISTLE;
-            if (item < 0) item = 0;
-        }
-        if (active) {
-            const double *cop = g.res + (size_t)item * kResStride + kResCop;
-            V3 n = mk3(g.trac.nx[idx], g.trac.ny[idx], g.trac.nz[idx]);
-            V3 r = mk3(g.trac.rx[idx], g.trac.ry[idx], g.trac.rz[idx]) - ld3(cop);
-            double p_dA = g.trac.p[idx] * g.trac.dA[idx];
-            V3 rn = cross(r, n);
-            double q1 = r.x * r.x, q2 = r.y * r.y, q3 = r.z * r.z;
-            // K11 -= p_dA * ([r]x^2 + (r x n)(r x n)')   (xx xy xz yy yz zz)
-            v[0] = -(p_dA * ((-q2 - q3) + rn.x * rn.x));
-            v[1] = -(p_dA * (r.x * r.y + rn.x * rn.y));
-            v[2] = -(p_dA * (r.x * r.z + rn.x * rn.z));
-            v[3] = -(p_dA * ((-q1 - q3) + rn.y * rn.y));
-            v[4] = -(p_dA * (r.y * r.z + rn.y * rn.z));
-            v[5] = -(p_dA * ((-q1 - q2) + rn.z * rn.z));
-            // K12 += p_dA * ([r]x - (r x n) n')   column-major 3x3
-            const double sk[9] = {0.0, r.z, -r.y, -r.z, 0.0, r.x, r.y, -r.x, 0.0};
-            const double nn[3] = {n.x, n.y, n.z}, rr[3] = {rn.x, rn.y, rn.z};
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int ii = 0; ii < 3; ++ii) v[6 + ii + 3 * j] = p_dA * (sk[ii + 3 * j] - rr[ii] * nn[j]);
-            // K22 += p_dA * (I - n n')
-            v[15] = p_dA * (1.0 - n.x * n.x); v[16] = p_dA * (0.0 - n.x * n.y); v[17] = p_dA * (0.0 - n.x * n.z);
-            v[18] = p_dA * (1.0 - n.y * n.y); v[19] = p_dA * (0.0 - n.y * n.z); v[20] = p_dA * (1.0 - n.z * n.z);
-        }
-        accumulate_items(g.acc, item, active, v, kAccK11, 21);
-    }
-}
 
 // cyclic Jacobi, symmetric 6x6 (stands in for LAPACK eigen!(Hermitian), friction.jl:88)
 __device__ void jacobi6(double *A, double *V, double *w) {
@@ -786,14 +763,45 @@ __global__ void k_eig(BrArgs g) {
     if (it->model != PFC_BRISTLE || g.icnt[4 * (size_t)i + 3] == 0) return;
     const double *a = g.acc + (size_t)i * kAccStride;
     double *r = g.res + (size_t)i * kResStride;
-    double K[36];
+    // cop = sum w r / sum w (normal.jl:33)
+    const double S = a[kAccIp];
+    const double c[3] = {a[kAccIpc] / S, a[kAccIpc + 1] / S, a[kAccIpc + 2] / S};
+    r[kResCop] = c[0]; r[kResCop + 1] = c[1]; r[kResCop + 2] = c[2];
+    // calc_patch_spatial_stiffness! (friction.jl:147-169) from the origin moments, shifted to the cop:
+    //   K22 = S I - Snn
+    //   K12 = -(San - [c]x Snn)                               (sum w r = 0 about the cop)
+    //   K11 = -(Crr - tr(Crr) I + Saa - San [c]x' - [c]x San' + [c]x Snn [c]x'),  Crr = Srr - S c c'
     const int s6[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};  // symmetric 3x3 from 6 unique
+    double Snn[9], San[9], Saa[9], Crr[9], cx[9] = {0.0, c[2], -c[1], -c[2], 0.0, c[0], c[1], -c[0], 0.0};
+    for (int k = 0; k < 9; ++k) {
+        Snn[k] = a[kAccSnn + s6[k]]; Saa[k] = a[kAccSaa + s6[k]]; San[k] = a[kAccSan + k];
+        Crr[k] = a[kAccSrr + s6[k]] - S * c[k % 3] * c[k / 3];
+    }
+    double cS[9], Sc[9], cSc[9];   // [c]x Snn,  San [c]x',  [c]x Snn [c]x'
     for (int j = 0; j < 3; ++j)
         for (int ii = 0; ii < 3; ++ii) {
-            K[ii + 6 * j] = a[kAccK11 + s6[ii + 3 * j]];
-            K[(ii + 3) + 6 * j] = a[kAccK12 + j + 3 * ii];
-            K[ii + 6 * (j + 3)] = a[kAccK12 + ii + 3 * j];
-            K[(ii + 3) + 6 * (j + 3)] = a[kAccK22 + s6[ii + 3 * j]];
+            double x = 0.0, y = 0.0;
+            for (int k = 0; k < 3; ++k) { x += cx[ii + 3 * k] * Snn[k + 3 * j]; y += San[ii + 3 * k] * cx[j + 3 * k]; }
+            cS[ii + 3 * j] = x; Sc[ii + 3 * j] = y;
+        }
+    for (int j = 0; j < 3; ++j)
+        for (int ii = 0; ii < 3; ++ii) {
+            double x = 0.0;
+            for (int k = 0; k < 3; ++k) x += cS[ii + 3 * k] * cx[j + 3 * k];
+            cSc[ii + 3 * j] = x;
+        }
+    const double trC = Crr[0] + Crr[4] + Crr[8];
+    double K[36];
+    for (int j = 0; j < 3; ++j)
+        for (int ii = 0; ii < 3; ++ii) {
+            const double I = (ii == j) ? 1.0 : 0.0;
+            const double k11 = -(Crr[ii + 3 * j] - trC * I + Saa[ii + 3 * j] - Sc[ii + 3 * j] - Sc[j + 3 * ii] + cSc[ii + 3 * j]);
+            const double k12 = -(San[ii + 3 * j] - cS[ii + 3 * j]);
+            const double k22 = S * I - Snn[ii + 3 * j];
+            K[ii + 6 * j] = k11;
+            K[ii + 6 * (j + 3)] = k12;
+            K[(j + 3) + 6 * ii] = k12;
+            K[(ii + 3) + 6 * (j + 3)] = k22;
         }
     for (int k = 0; k < 36; ++k) { K[k] *= it->k_bar; r[kResK + k] = K[k]; }
     double t1 = (K[0] + K[7]) + K[14], t2 = (K[21] + K[28]) + K[35];
@@ -1130,9 +1138,6 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     br.trac = trac_view(h); br.tcount = tcount; br.tcap = (int)h->tcap; br.wrench = d_wrench; br.sdot = d_sdot;
     br.counts = d_counts;
     if (h->any_bristle) {
-        int gi = grid_for(n_items, 128, 1 << 20);
-        hipLaunchKernelGGL(k_cop, dim3(gi), dim3(128), 0, st, br);
-        hipLaunchKernelGGL(k_stiff, dim3(grid_for(h->tcap, 256, 2048)), dim3(256), 0, st, br);
         hipLaunchKernelGGL(k_eig, dim3(grid_for(n_items, 64, 1 << 20)), dim3(64), 0, st, br);
         hipLaunchKernelGGL(k_fric, dim3(grid_for(h->tcap, 256, 2048)), dim3(256), 0, st, br);
     }

@@ -77,15 +77,19 @@ struct alignas(16) WorkRec {  // frontier entry (item, node_a, node_b) or candid
     int item, a, b, pad;
 };
 
-// per-item accumulator slots (doubles)
+// per-item accumulator slots (doubles).  The bristle model's patch stiffness (calc_patch_spatial_stiffness!,
+// src/contact_algorithms_friction.jl:147-169) is a sum over traction points of polynomials in r - cop; it is
+// accumulated about the frame origin in the same pass that finds the cop and shifted to the cop algebraically
+// afterwards (k_eig), which removes one full pass over the traction points.
 constexpr int kAccWrench = 0;   // 6: regularized total wrench, or bristle normal wrench [ang; lin]
-constexpr int kAccIp = 6;       // 1: ∫p dA
-constexpr int kAccIpc = 7;      // 3: ∫p r dA
-constexpr int kAccK11 = 10;     // 6: xx xy xz yy yz zz
-constexpr int kAccK12 = 16;     // 9: column-major
-constexpr int kAccK22 = 25;     // 6
-constexpr int kAccFric = 31;    // 6: friction wrench about the cop [ang; lin]
-constexpr int kAccStride = 40;
+constexpr int kAccIp = 6;       // 1: S   = sum w            (w = p dA)
+constexpr int kAccIpc = 7;      // 3: Sr  = sum w r
+constexpr int kAccSnn = 10;     // 6: sum w n n'             (xx xy xz yy yz zz)
+constexpr int kAccSan = 16;     // 9: sum w (r x n) n'       (column-major 3x3)
+constexpr int kAccSaa = 25;     // 6: sum w (r x n)(r x n)'
+constexpr int kAccSrr = 31;     // 6: sum w r r'
+constexpr int kAccFric = 37;    // 6: friction wrench about the cop [ang; lin]
+constexpr int kAccStride = 44;
 // per-item derived results (doubles)
 constexpr int kResCop = 0;      // 3
 constexpr int kResSinv = 3;     // 6
