@@ -6,6 +6,6 @@ configs    the synthetic workloads of BASELINE.md (C1..C5)
 parallel   one-process-per-GPU sharding of independent items + all-gather of per-item results
 _lib       ctypes binding / build of csrc/libpfc_hip.so
 """
-from . import geometry, _lib, scenario, configs  # noqa: F401
+from . import geometry, _lib, scenario, configs, parallel  # noqa: F401
 from .scenario import (MechanismScenario, ContactProperties, Regularized, Bristle, ContactInstructions,  # noqa: F401
                        MeshCache, relative_pose, relative_twist)
