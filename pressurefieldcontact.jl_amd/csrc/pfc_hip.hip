@@ -135,20 +135,12 @@ struct BpArgs {
     int level, fcap, ccap;
 };
 
-__device__ __forceinline__ void count_per_item(int *icnt, int item, int slot, bool flag) {
-    // wave-aggregated per-item counter: one atomic per wave when the whole wave works on one item
-    unsigned long long m = __ballot(flag);
-    if (m == 0) return;
-    int first = __builtin_amdgcn_readfirstlane(item);
-    bool uni = __all(!flag || item == first);
-    if (uni) {
-        // `first` may belong to a lane without the flag; take the item of the lowest flagged lane instead
-        int src = __builtin_ctzll(m);
-        int it = __shfl(item, src, 64);
-        if (lane_id() == src) atomicAdd(&icnt[4 * (size_t)it + slot], __builtin_popcountll(m));
-    } else if (flag) {
-        atomicAdd(&icnt[4 * (size_t)item + slot], 1);
-    }
+__device__ __forceinline__ void count_per_item(int *icnt, int item, int slot, bool flag, int n = 1) {
+    // per-item integer counter: one atomic per run of equal items in the wave
+    if (__ballot(flag) == 0) return;
+    const Seg sg = seg_setup(flag ? item : -1);
+    const int t = seg_sum(flag ? n : 0, sg);
+    if (sg.tail && sg.valid && t != 0) atomicAdd(&icnt[4 * (size_t)item + slot], t);
 }
 
 __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
@@ -371,20 +363,12 @@ constexpr int kNpBlock = 64;  // one wave per block: 32 KiB of LDS polygon stagi
 #define PZ(buf, slot, c) poly[(((buf) * 8 + (slot)) * 4 + (c)) * kNpBlock + lane]
 
 __device__ __forceinline__ void accumulate_items(double *acc, int item, bool any, const double *v, int n0, int n) {
-    // wave-level reduction of per-lane partial sums into per-item accumulators
-    unsigned long long m = __ballot(any);
-    if (m == 0) return;
-    int src = __builtin_ctzll(m);
-    int it0 = __shfl(item, src, 64);
-    bool uni = __all(!any || item == it0);
-    if (uni) {
-        for (int k = 0; k < n; ++k) {
-            double s = wave_sum(any ? v[k] : 0.0);
-            if (lane_id() == 0 && s != 0.0) unsafeAtomicAdd(&acc[(size_t)it0 * kAccStride + n0 + k], s);
-        }
-    } else if (any) {
-        for (int k = 0; k < n; ++k)
-            if (v[k] != 0.0) unsafeAtomicAdd(&acc[(size_t)item * kAccStride + n0 + k], v[k]);
+    // per-item accumulation of per-lane partial sums: one atomic per run of equal items in the wave
+    if (__ballot(any) == 0) return;
+    const Seg sg = seg_setup(any ? item : -1);
+    for (int k = 0; k < n; ++k) {
+        const double t = seg_sum(any ? v[k] : 0.0, sg);
+        if (sg.tail && sg.valid && t != 0.0) unsafeAtomicAdd(&acc[(size_t)item * kAccStride + n0 + k], t);
     }
 }
 
@@ -685,22 +669,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             accumulate_items(g.acc, cw.item, cb, v, kAccSnn, 27);
         }
         count_per_item(g.icnt, cw.item, 2, active && n_poly >= 3);
-        {
-            unsigned long long m = __ballot(contributed);
-            if (m) {
-                int src = __builtin_ctzll(m);
-                int it0 = __shfl(cw.item, src, 64);
-                bool uni = __all(!contributed || cw.item == it0);
-                if (uni) {
-                    int tot = n_trac_lane;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-                    if (lane == 0) atomicAdd(&g.icnt[4 * (size_t)it0 + 3], tot);
-                } else if (contributed) {
-                    atomicAdd(&g.icnt[4 * (size_t)cw.item + 3], n_trac_lane);
-                }
-            }
-        }
+        count_per_item(g.icnt, cw.item, 3, contributed, n_trac_lane);
     }
 }
 #undef PZ
@@ -721,42 +690,54 @@ struct BrArgs {
     int *counts;
 };
 
-// cyclic Jacobi, symmetric 6x6 (stands in for LAPACK eigen!(Hermitian), friction.jl:88)
-__device__ void jacobi6(double *A, double *V, double *w) {
+// cyclic Jacobi, symmetric 6x6 (stands in for LAPACK eigen!(Hermitian), friction.jl:88).  Every index is a
+// compile-time constant after unrolling so A and V live in registers (runtime-indexed arrays would go to scratch).
+__device__ __forceinline__ void jacobi6(double *A, double *V, double *w) {
+#pragma unroll
     for (int i = 0; i < 36; ++i) V[i] = 0.0;
+#pragma unroll
     for (int i = 0; i < 6; ++i) V[7 * i] = 1.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0.0, dia = 0.0;
+#pragma unroll
         for (int i = 0; i < 6; ++i)
+#pragma unroll
             for (int j = 0; j < 6; ++j)
                 if (i != j) off += A[i + 6 * j] * A[i + 6 * j]; else dia += A[7 * i] * A[7 * i];
         if (off <= 1e-300 || off <= 1e-34 * dia) break;
+#pragma unroll
         for (int p = 0; p < 5; ++p)
+#pragma unroll
             for (int q = p + 1; q < 6; ++q) {
-                double apq = A[p + 6 * q];
-                if (apq == 0.0) continue;
-                double theta = (A[7 * q] - A[7 * p]) / (2.0 * apq);
+                const double apq = A[p + 6 * q];
+                // apq == 0: identity rotation (t = 0), same result as skipping the pair
+                const double theta = (A[7 * q] - A[7 * p]) / (2.0 * apq);
                 double t = (theta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
-                double cs = 1.0 / __builtin_sqrt(t * t + 1.0), sn = t * cs;
+                if (apq == 0.0) t = 0.0;
+                const double cs = 1.0 / __builtin_sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    double akp = A[k + 6 * p], akq = A[k + 6 * q];
+                    const double akp = A[k + 6 * p], akq = A[k + 6 * q];
                     A[k + 6 * p] = cs * akp - sn * akq; A[k + 6 * q] = sn * akp + cs * akq;
                 }
+#pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    double apk = A[p + 6 * k], aqk = A[q + 6 * k];
+                    const double apk = A[p + 6 * k], aqk = A[q + 6 * k];
                     A[p + 6 * k] = cs * apk - sn * aqk; A[q + 6 * k] = sn * apk + cs * aqk;
                 }
+#pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    double vkp = V[k + 6 * p], vkq = V[k + 6 * q];
+                    const double vkp = V[k + 6 * p], vkq = V[k + 6 * q];
                     V[k + 6 * p] = cs * vkp - sn * vkq; V[k + 6 * q] = sn * vkp + cs * vkq;
                 }
             }
     }
+#pragma unroll
     for (int i = 0; i < 6; ++i) w[i] = A[7 * i];
 }
 
 // decompose_K! / calc_K̄_sqrt_inv / Δ² (friction.jl:85-132): one thread per bristle item in contact
-__global__ void k_eig(BrArgs g) {
+__global__ void __launch_bounds__(64) k_eig(BrArgs g) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.n_items) return;
     const ItemRec *it = g.items + i;
@@ -773,26 +754,35 @@ __global__ void k_eig(BrArgs g) {
     //   K11 = -(Crr - tr(Crr) I + Saa - San [c]x' - [c]x San' + [c]x Snn [c]x'),  Crr = Srr - S c c'
     const int s6[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};  // symmetric 3x3 from 6 unique
     double Snn[9], San[9], Saa[9], Crr[9], cx[9] = {0.0, c[2], -c[1], -c[2], 0.0, c[0], c[1], -c[0], 0.0};
+#pragma unroll
     for (int k = 0; k < 9; ++k) {
         Snn[k] = a[kAccSnn + s6[k]]; Saa[k] = a[kAccSaa + s6[k]]; San[k] = a[kAccSan + k];
         Crr[k] = a[kAccSrr + s6[k]] - S * c[k % 3] * c[k / 3];
     }
     double cS[9], Sc[9], cSc[9];   // [c]x Snn,  San [c]x',  [c]x Snn [c]x'
+#pragma unroll
     for (int j = 0; j < 3; ++j)
+#pragma unroll
         for (int ii = 0; ii < 3; ++ii) {
             double x = 0.0, y = 0.0;
+#pragma unroll
             for (int k = 0; k < 3; ++k) { x += cx[ii + 3 * k] * Snn[k + 3 * j]; y += San[ii + 3 * k] * cx[j + 3 * k]; }
             cS[ii + 3 * j] = x; Sc[ii + 3 * j] = y;
         }
+#pragma unroll
     for (int j = 0; j < 3; ++j)
+#pragma unroll
         for (int ii = 0; ii < 3; ++ii) {
             double x = 0.0;
+#pragma unroll
             for (int k = 0; k < 3; ++k) x += cS[ii + 3 * k] * cx[j + 3 * k];
             cSc[ii + 3 * j] = x;
         }
     const double trC = Crr[0] + Crr[4] + Crr[8];
     double K[36];
+#pragma unroll
     for (int j = 0; j < 3; ++j)
+#pragma unroll
         for (int ii = 0; ii < 3; ++ii) {
             const double I = (ii == j) ? 1.0 : 0.0;
             const double k11 = -(Crr[ii + 3 * j] - trC * I + Saa[ii + 3 * j] - Sc[ii + 3 * j] - Sc[j + 3 * ii] + cSc[ii + 3 * j]);
@@ -803,29 +793,40 @@ __global__ void k_eig(BrArgs g) {
             K[(j + 3) + 6 * ii] = k12;
             K[(ii + 3) + 6 * (j + 3)] = k22;
         }
+#pragma unroll
     for (int k = 0; k < 36; ++k) { K[k] *= it->k_bar; r[kResK + k] = K[k]; }
     double t1 = (K[0] + K[7]) + K[14], t2 = (K[21] + K[28]) + K[35];
     double s1 = 1.0 / __builtin_sqrt(t1), s2 = 1.0 / __builtin_sqrt(t2);
     double Sinv[6];
+#pragma unroll
     for (int k = 0; k < 3; ++k) { Sinv[k] = s1 * it->magic; Sinv[k + 3] = s2; }
     double Kb[36], V[36], sig[6];
+#pragma unroll
     for (int j = 0; j < 6; ++j)
+#pragma unroll
         for (int ii = 0; ii < 6; ++ii) {
             double kij = (ii <= j) ? K[ii + 6 * j] : K[j + 6 * ii];
             Kb[ii + 6 * j] = (Sinv[ii] * kij) * Sinv[j];
         }
     jacobi6(Kb, V, sig);
     double mx = sig[0];
+#pragma unroll
     for (int k = 1; k < 6; ++k) mx = fmax(mx, sig[k]);
+#pragma unroll
     for (int k = 0; k < 6; ++k) sig[k] = 1.0 / __builtin_sqrt(fmax(sig[k], mx * 1.0e-16));
+#pragma unroll
     for (int j = 0; j < 6; ++j)
+#pragma unroll
         for (int ii = 0; ii < 6; ++ii) {
             double acc = 0.0;
+#pragma unroll
             for (int k = 0; k < 6; ++k) acc += (V[ii + 6 * k] * sig[k]) * V[j + 6 * k];
             r[kResKis + ii + 6 * j] = acc;
         }
+#pragma unroll
     for (int ii = 0; ii < 6; ++ii) {
         double acc = 0.0;
+#pragma unroll
         for (int k = 0; k < 6; ++k) acc += r[kResKis + ii + 6 * k] * it->s[k];
         r[kResDelta + ii] = Sinv[ii] * acc;
         r[kResSinv + ii] = Sinv[ii];

@@ -268,4 +268,44 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Segmented wave reduction.  Work lists are grouped by item in runs (a seed's candidates, a polygon's traction
+// points), so the 64 lanes of a wave hold a few runs of equal keys.  seg_setup() finds the runs with one ballot;
+// seg_sum() is a segmented inclusive scan (6 shuffle steps, all runs at once) whose value on the last lane of each
+// run is the run's total; that lane issues the run's single atomic.  key < 0 marks a lane without contribution.
+struct Seg {
+    int start;   // first lane of this lane's run
+    bool tail;   // last lane of its run
+    bool valid;  // key >= 0
+};
+__device__ __forceinline__ Seg seg_setup(int key) {
+    const int lane = lane_id();
+    const int prev = __shfl_up(key, 1, 64);
+    const bool head = (lane == 0) || (key != prev);
+    const unsigned long long H = __ballot(head);
+    const unsigned long long below = H & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    Seg s;
+    s.start = 63 - __builtin_clzll(below);
+    s.tail = (lane == 63) || (((H >> (lane + 1)) & 1ull) != 0);
+    s.valid = key >= 0;
+    return s;
+}
+__device__ __forceinline__ double seg_sum(double v, const Seg &s) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o, 64);
+        if (lane - o >= s.start) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ int seg_sum(int v, const Seg &s) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane - o >= s.start) v += t;
+    }
+    return v;
+}
+
 }  // namespace pfc
