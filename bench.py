@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--poses", type=int, default=2048, help="Monte-Carlo poses (items) per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--bfs-levels", type=int, default=-1, help="broadphase BFS levels before the DFS kernel (-1 = auto)")
     args = ap.parse_args()
 
     import numpy as np
@@ -92,6 +93,8 @@ def main():
     # ---- synthetic C3 batch; meshes are identical on every rank, poses are rank-specific ---------------------------
     w = pfc.configs.c3_blob_tool(args.poses, seed=20260103 + 7919 * rank)
     m = pfc.configs.build_scenario(w, device=local_rank)
+    if args.bfs_levels >= 0:
+        m.set_option("bfs_levels", args.bfs_levels)
     n = w.n_items
     d_ins = torch.from_numpy(w.ins_ids.astype(np.int32)).to(dev)
     d_pose = torch.from_numpy(np.ascontiguousarray(w.pose)).to(dev)

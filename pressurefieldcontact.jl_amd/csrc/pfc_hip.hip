@@ -238,6 +238,7 @@ struct DfsArgs {
     const ItemRec *items;
     const WorkRec *seeds;
     const int *n_seed;   // device counter
+    int *next_seed;      // device counter (zeroed per evaluation): dynamic seed queue head
     int seed_cap;
     WorkRec *cand;
     int *ccount;
@@ -247,26 +248,50 @@ struct DfsArgs {
     int reserve;         // 3 * (max remaining depth) + 3 slots kept free for the pure depth-first mode
 };
 
+// first 64 bytes of a NodeRec (c, e, links, flags) as four 16-byte loads
+struct NodeHead {
+    double c[3], e[3];
+    int child0, child1, leaf, aabb;
+};
+__device__ __forceinline__ NodeHead load_head(const NodeRec *n) {
+    NodeHead h;
+    const double2 *p = reinterpret_cast<const double2 *>(n);
+    const double2 a = p[0], b = p[1], c = p[2];
+    const int4 l = reinterpret_cast<const int4 *>(n)[3];
+    h.c[0] = a.x; h.c[1] = a.y; h.c[2] = b.x; h.e[0] = b.y; h.e[1] = c.x; h.e[2] = c.y;
+    h.child0 = l.x; h.child1 = l.y; h.leaf = l.z; h.aabb = l.w;
+    return h;
+}
+
+// one ticket per wave from a device-wide counter: lane 0 takes it, the wave reads it back as a scalar
+__device__ __forceinline__ int next_ticket(int *ctr) {
+    int t = 0;
+    if (lane_id() == 0) t = atomicAdd(ctr, 1);
+    return __builtin_amdgcn_readfirstlane(t);
+}
+
 __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
     __shared__ int2 stk[kDfsStack];
     __shared__ int2 ob[kDfsOut];
     const int lane = threadIdx.x;
     int n_seed = *g.n_seed;
     if (n_seed > g.seed_cap) n_seed = g.seed_cap;
-    for (int sd = blockIdx.x; sd < n_seed; sd += gridDim.x) {
+    // dynamic seed queue: seeds differ in work by orders of magnitude (most of a contact lives in one subtree)
+    for (int sd = next_ticket(g.next_seed); sd < n_seed; sd = next_ticket(g.next_seed)) {
         const WorkRec s = g.seeds[sd];
         const int item = __builtin_amdgcn_readfirstlane(s.item);
         const ItemRec *it = g.items + item;
-        double R12[9], t12[3];
+        double R12[9], aR12[9], t12[3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) R12[k] = it->R12[k];
+        for (int k = 0; k < 9; ++k) { R12[k] = it->R12[k]; aR12[k] = __builtin_fabs(R12[k]) + 1.0e-14; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) t12[k] = it->t12[k];
         const NodeRec *n1 = it->nodes1, *n2 = it->nodes2;
         int sp = 1, n_out = 0, n_test = 0, n_cand = 0;
         if (lane == 0) stk[0] = make_int2(s.a, s.b);
         __syncthreads();
-        while (sp > 0) {
+        // every wave must reach its exit: the iteration guard stops a corrupt (cyclic) tree from spinning forever
+        for (int guard = 0; sp > 0 && guard < (1 << 22); ++guard) {
             // wide mode while there is room for 4 children per popped pair above the depth-first reserve
             int pw = (kDfsStack - g.reserve - sp) / 3;
             int p = sp < 64 ? sp : 64;
@@ -281,9 +306,22 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
             bool hit = false, la = false, lb = false;
             int ca0 = 0, ca1 = 0, cb0 = 0, cb1 = 0, leaf_a = 0, leaf_b = 0;
             if (act) {
-                const NodeRec a = n1[e.x];
-                const NodeRec b = n2[e.y];
-                hit = bb_bb_intersect(a, b, R12, t12);
+                const NodeHead a = load_head(n1 + e.x);
+                const NodeHead b = load_head(n2 + e.y);
+                if (a.aabb & b.aabb) {
+                    hit = bb_bb_intersect_aabb(a.c, a.e, b.c, b.e, R12, aR12, t12);
+                } else {
+                    NodeRec fa, fb;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { fa.c[k] = a.c[k]; fa.e[k] = a.e[k]; fb.c[k] = b.c[k]; fb.e[k] = b.e[k]; }
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const double id = (k % 4 == 0) ? 1.0 : 0.0;
+                        fa.R[k] = a.aabb ? id : n1[e.x].R[k];
+                        fb.R[k] = b.aabb ? id : n2[e.y].R[k];
+                    }
+                    hit = bb_bb_intersect(fa, fb, R12, t12);
+                }
                 la = a.leaf != kInternal; lb = b.leaf != kInternal;
                 ca0 = a.child0; ca1 = a.child1; cb0 = b.child0; cb1 = b.child1;
                 leaf_a = a.leaf; leaf_b = b.leaf;
@@ -328,6 +366,7 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
             }
         }
         if (lane == 0) {
+            if (sp > 0) atomicOr(g.status, kStAbort);
             atomicAdd(&g.icnt[4 * (size_t)item], n_test);
             if (n_cand) atomicAdd(&g.icnt[4 * (size_t)item + 1], n_cand);
         }
@@ -1082,7 +1121,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     const bool prof = h->opt_profile != 0;
     if (prof && !h->ev[0])
         for (int k = 0; k < EV_COUNT; ++k) HIP_TRY(h, hipEventCreate(&h->ev[k]));
-    int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *fcount = h->ctr.p + 2;
+    int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2, *fcount = h->ctr.p + 3;
     HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(int) * ((size_t)levels + 8), st));
     HIP_TRY(h, hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * 4, st));
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
@@ -1102,7 +1141,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
         L = h->opt_bfs_levels;
     } else {
         double seeds = (double)n_items;
-        while (seeds < 65536.0 && L < 8) { seeds *= 4.0; ++L; }
+        while (seeds < 2048.0 && L < 8) { seeds *= 4.0; ++L; }
     }
     if (L > levels) L = levels;
     for (int lv = 0; lv < L; ++lv) {
@@ -1118,11 +1157,12 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     {
         DfsArgs d;
         d.items = h->items.p; d.seeds = h->frontier[L & 1].p; d.n_seed = fcount + L; d.seed_cap = (int)h->fcap;
+        d.next_seed = next_seed;
         d.cand = h->cand.p; d.ccount = ccount; d.ccap = (int)h->ccap; d.icnt = h->icnt.p; d.status = h->status.p;
         d.reserve = 3 * levels + 3;
         double ub = (double)n_items * std::pow(4.0, (double)(L < 15 ? L : 15));
         size_t bound = ub > (double)h->fcap ? h->fcap : (size_t)ub;
-        hipLaunchKernelGGL(k_bp_dfs, dim3(grid_for(bound, 1, 256 * 15)), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_bp_dfs, dim3(grid_for(bound, 1, 256 * 12)), dim3(64), 0, st, d);
     }
     h->last_bfs_levels = L;
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));
@@ -1164,8 +1204,8 @@ int check_eval(pfc_context *h) {
     long long fpeak = 0;
     int used_levels = 0;
     for (int lv = 0; lv <= h->last_bfs_levels && lv <= levels; ++lv) {
-        if (ctr[2 + lv] > fpeak) fpeak = ctr[2 + lv];
-        if (ctr[2 + lv] > 0) used_levels = lv + 1;
+        if (ctr[3 + lv] > fpeak) fpeak = ctr[3 + lv];
+        if (ctr[3 + lv] > 0) used_levels = lv + 1;
     }
     h->stats[1] = ctr[0]; h->last_tslots = ctr[1]; h->stats[4] = used_levels; h->stats[5] = fpeak;
     h->stats[6] = status; h->stats[7] = h->last_n_items;
@@ -1178,6 +1218,7 @@ int check_eval(pfc_context *h) {
         return fail(h, PFC_ERR_OVERFLOW, "work list overflow (status %u): capacities grown to frontier %zu, candidates %zu, tractions %zu",
                     status, h->fcap, h->ccap, h->tcap);
     }
+    if (status & kStAbort) return fail(h, PFC_ERR_STATE, "broadphase aborted: iteration guard hit (corrupt tree?)");
     if (status & kStNonFinite) return fail(h, PFC_ERR_NONFINITE, "Non-finite vertex likely");
     // totals
     std::vector<int> ic((size_t)h->last_n_items * 4);
@@ -1283,7 +1324,7 @@ int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int
         NodeRec &r = m.nodes[k];
         for (int j = 0; j < 3; ++j) { r.c[j] = node_c[3 * k + j]; r.e[j] = node_e[3 * k + j]; }
         for (int j = 0; j < 9; ++j) r.R[j] = node_R[9 * k + j];
-        r.child0 = node_child[2 * k]; r.child1 = node_child[2 * k + 1]; r.leaf = node_leaf[k];
+        r.child0 = node_child[2 * k]; r.child1 = node_child[2 * k + 1]; r.leaf = node_leaf[k]; r.pad = 0.0;
         static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         r.aabb = std::memcmp(r.R, I9, sizeof I9) == 0 ? 1 : 0;
         if (r.leaf == kInternal) {

@@ -18,6 +18,8 @@ enum : unsigned {
     kStFrontierOvf = 2u,
     kStCandOvf = 4u,
     kStTracOvf = 8u,
+    kStBadIns = 16u,
+    kStAbort = 32u,
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -26,12 +28,14 @@ enum : unsigned {
 // pfc_finalize because meshes are immutable afterwards (src/mechanism_scenario.jl:206).
 // ---------------------------------------------------------------------------------------------------------------
 struct alignas(16) NodeRec {  // OBB{c,e,R} + bin_BB_Tree links: src/obb/box_types.jl:4-9, tree_types.jl:1-16
+    // first 64 bytes: everything an axis-aligned (merged / internal) box needs
     double c[3];
     double e[3];
-    double R[9];  // column-major
     int child0, child1;
     int leaf;   // element index or kInternal
     int aabb;   // 1 if R is exactly the identity (all merged/internal boxes: src/obb/util.jl:47-51)
+    double R[9];  // column-major; only read when aabb == 0 (tight-fitted leaves)
+    double pad;
 };
 static_assert(sizeof(NodeRec) == 144, "NodeRec layout");
 
@@ -253,6 +257,20 @@ __device__ __forceinline__ bool bb_bb_intersect(const NodeRec &a, const NodeRec 
         t[i] = ((T[i] * b.c[0] + T[i + 3] * b.c[1]) + T[i + 6] * b.c[2]) + tt[i];
     }
     return sat15(a.e, b.e, t, R, aR);
+}
+
+// BB_BB_intersect for two axis-aligned boxes (R_a = R_b = I, every internal node).  The reference still composes the
+// three 4x4 transforms (:3-7); with identity rotations that product is exactly R_tot = R_a_b and
+// t = R_a_b c_b + (t_a_b - c_a) with the same roundings (products with the structural 0/1 entries are exact), so
+// this shortcut returns the same boolean bit for bit.  aRab = |R_a_b| + 1e-14 is per item.
+__device__ __forceinline__ bool bb_bb_intersect_aabb(const double *ca, const double *ea, const double *cb,
+                                                     const double *eb, const double *Rab, const double *aRab,
+                                                     const double *tab) {
+    double t[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        t[i] = ((Rab[i] * cb[0] + Rab[i + 3] * cb[1]) + Rab[i + 6] * cb[2]) + (tab[i] - ca[i]);
+    return sat15(ea, eb, t, Rab, aRab);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
