@@ -305,23 +305,29 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
             n_test += p;
             bool hit = false, la = false, lb = false;
             int ca0 = 0, ca1 = 0, cb0 = 0, cb1 = 0, leaf_a = 0, leaf_b = 0;
+            NodeHead a, b;
+            a.aabb = 1; b.aabb = 1;
             if (act) {
-                const NodeHead a = load_head(n1 + e.x);
-                const NodeHead b = load_head(n2 + e.y);
-                if (a.aabb & b.aabb) {
-                    hit = bb_bb_intersect_aabb(a.c, a.e, b.c, b.e, R12, aR12, t12);
-                } else {
-                    NodeRec fa, fb;
+                a = load_head(n1 + e.x);
+                b = load_head(n2 + e.y);
+            }
+            // The path is chosen per wave, never per lane: popped pairs sit at similar depths, so a wave is usually
+            // all internal-internal (axis-aligned shortcut, half the flops and 128 instead of 288 bytes per pair) or
+            // reaches the tight-fitted leaves together (general composition; it is exact for identity rotations too).
+            if (__all(!act || ((a.aabb & b.aabb) != 0))) {
+                if (act) hit = bb_bb_intersect_aabb(a.c, a.e, b.c, b.e, R12, aR12, t12);
+            } else if (act) {
+                NodeRec fa, fb;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { fa.c[k] = a.c[k]; fa.e[k] = a.e[k]; fb.c[k] = b.c[k]; fb.e[k] = b.e[k]; }
+                for (int k = 0; k < 3; ++k) { fa.c[k] = a.c[k]; fa.e[k] = a.e[k]; fb.c[k] = b.c[k]; fb.e[k] = b.e[k]; }
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        const double id = (k % 4 == 0) ? 1.0 : 0.0;
-                        fa.R[k] = a.aabb ? id : n1[e.x].R[k];
-                        fb.R[k] = b.aabb ? id : n2[e.y].R[k];
-                    }
-                    hit = bb_bb_intersect(fa, fb, R12, t12);
+                for (int k = 0; k < 9; ++k) {
+                    fa.R[k] = n1[e.x].R[k];
+                    fb.R[k] = n2[e.y].R[k];
                 }
+                hit = bb_bb_intersect(fa, fb, R12, t12);
+            }
+            if (act) {
                 la = a.leaf != kInternal; lb = b.leaf != kInternal;
                 ca0 = a.child0; ca1 = a.child1; cb0 = b.child0; cb1 = b.child1;
                 leaf_a = a.leaf; leaf_b = b.leaf;
