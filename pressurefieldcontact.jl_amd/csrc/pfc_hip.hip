@@ -402,10 +402,12 @@ struct NpArgs {
     int debug;       // materialise traction points for every item
 };
 
-constexpr int kNpBlock = 64;  // one wave per block: 32 KiB of LDS polygon staging per wave
+constexpr int kNpBlock = 64;  // one wave per block: 16 KiB of LDS polygon staging per wave
 
 // weightPoly (src/math_kernel/utility.jl:21-26) on 4-vectors held in LDS slots
-#define PZ(buf, slot, c) poly[(((buf) * 8 + (slot)) * 4 + (c)) * kNpBlock + lane]
+// polygon ring in LDS: 8 physical slots x 4 coords per lane, [slot][coord][lane] layout (conflict-free per-lane
+// dynamic indexing); logical vertex k of a lane lives in physical slot (rbase + k) & 7
+#define PR(k, c) poly[((((rbase) + (k)) & 7) * 4 + (c)) * kNpBlock + lane]
 
 __device__ __forceinline__ void accumulate_items(double *acc, int item, bool any, const double *v, int n0, int n) {
     // per-item accumulation of per-lane partial sums: one atomic per run of equal items in the wave
@@ -418,7 +420,7 @@ __device__ __forceinline__ void accumulate_items(double *acc, int item, bool any
 }
 
 __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
-    __shared__ double poly[2 * 8 * 4 * kNpBlock];
+    __shared__ double poly[8 * 4 * kNpBlock];
     const int lane = threadIdx.x;
     int n_c = *g.ccount;
     if (n_c > g.ccap) n_c = g.ccap;
@@ -435,7 +437,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         const int nq = it->nq;
         const bool reg = it->model == PFC_REGULARIZED;
         const bool materialise = active && (g.debug || !reg);
-        int n_poly = 0, cur = 0;
+        int n_poly = 0, rbase = 0;
         V3 nh = mk3(0.0, 0.0, 0.0);
         // ==== phase 1 (divergent): gather, transform to tet coordinates, clip ========================================
         if (active) {
@@ -479,17 +481,17 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0);
             if (!reject) {
-                // ---- clip_in_tet_coordinates (static_clip.jl:17-23,34-201), polygon staged in LDS --------------
+                // ---- clip_in_tet_coordinates (static_clip.jl:17-23,34-201), polygon ring in LDS, clipped in place --
                 int n = 3;
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) PZ(0, k, i) = z[k][i];
+                    for (int i = 0; i < 4; ++i) PR(k, i) = z[k][i];
                 bool err = false;
                 for (int i = 0; i < 4 && n > 0; ++i) {
                     unsigned nonpos = 0, nonneg = 0;
                     for (int k = 0; k < n; ++k) {
-                        double sv = PZ(cur, k, i);
+                        double sv = PR(k, i);
                         nonpos |= (unsigned)(sv <= 0.0) << k;
                         nonneg |= (unsigned)(0.0 <= sv) << k;
                     }
@@ -505,37 +507,42 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                     int m = n;
                     while (m > 3) {
                         int k2 = st + m - 2; if (k2 >= n) k2 -= n;
-                        if (PZ(cur, k2, i) <= 0.0) --m; else break;
+                        if ((nonpos >> k2) & 1u) --m; else break;
                     }
                     int k1 = st + 1; if (k1 >= n) k1 -= n;
                     int kl = st + m - 1; if (kl >= n) kl -= n;   // z_m (last)
                     int kp = st + m - 2; if (kp >= n) kp -= n;   // z_{m-1}
-                    const double last = PZ(cur, kl, i);
-                    const bool inside = (m <= 5) ? (0.0 < last) : (0.0 <= last);   // :140,150,162 vs :176,188
-                    const int nb = cur ^ 1;
-                    // z_start = clip_node(z1, z2)
+                    // inside test of the last vertex: 0 < z for arity 3..5 (:140,150,162), 0 <= z for 6..7 (:176,188)
+                    const bool inside = (m <= 5) ? (((nonpos >> kl) & 1u) == 0) : (((nonneg >> kl) & 1u) != 0);
+                    // z_start = clip_node(z1, z2); z_end = clip_node(z1, z_m) or clip_node(z_m, z_{m-1}); both are
+                    // formed in registers before the ring is touched
+                    double zs[4], ze[4];
                     {
-                        double w1 = PZ(cur, st, i), w2 = PZ(cur, k1, i);
+                        double w1 = PR(st, i), w2 = PR(k1, i);
                         double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) PZ(nb, 0, c) = c1 * PZ(cur, k1, c) - c2 * PZ(cur, st, c);
-                    }
-                    const int ncopy = inside ? (m - 1) : (m - 2);   // z2 .. z_m  or  z2 .. z_{m-1}
-                    for (int q = 0; q < ncopy; ++q) {
-                        int ks = st + 1 + q; if (ks >= n) ks -= n;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) PZ(nb, 1 + q, c) = PZ(cur, ks, c);
+                        for (int c = 0; c < 4; ++c) zs[c] = c1 * PR(k1, c) - c2 * PR(st, c);
                     }
                     {
-                        // inside: z_end = clip_node(z1, z_m); else z_end = clip_node(z_m, z_{m-1})
                         const int kn = inside ? st : kl, kq = inside ? kl : kp;
-                        double w1 = PZ(cur, kn, i), w2 = PZ(cur, kq, i);
+                        double w1 = PR(kn, i), w2 = PR(kq, i);
                         double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) PZ(nb, 1 + ncopy, c) = c1 * PZ(cur, kq, c) - c2 * PZ(cur, kn, c);
+                        for (int c = 0; c < 4; ++c) ze[c] = c1 * PR(kq, c) - c2 * PR(kn, c);
                     }
+                    const int ncopy = inside ? (m - 1) : (m - 2);   // z2 .. z_m  or  z2 .. z_{m-1} stay in the polygon
+                    // In place: the new polygon starts at old logical st.  Kept vertices st+1 .. n-1 do not move;
+                    // kept vertices that wrapped around (old logical 0 .. ) move up by n slots, in increasing order
+                    // (a destination is either a free slot or the source of an earlier move).
+                    for (int q = n - st - 1; q < ncopy; ++q) {
+                        const int src = st + 1 + q - n, dst = st + 1 + q;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { const double t = PR(src, c); PR(dst, c) = t; }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { PR(st, c) = zs[c]; PR(st + ncopy + 1, c) = ze[c]; }
+                    rbase = (rbase + st) & 7;
                     n = ncopy + 2;
-                    cur = nb;
                     if (m == 7) break;  // the 7-vertex method returns the polygon directly (:185-195)
                 }
                 if (err) atomicOr(g.status, kStNonFinite);
@@ -577,29 +584,28 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         int n_trac_lane = 0;
         if (n_poly >= 3) {
             const int n = n_poly;
-            // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98) -> other LDS buffer (x,y,z)
-            const int ob = cur ^ 1;
+            // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98), converted in place (x, y, z)
             {
                 double V[12];
 #pragma unroll
                 for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
                 for (int k = 0; k < n; ++k) {
-                    double z0 = PZ(cur, k, 0), z1 = PZ(cur, k, 1), z2 = PZ(cur, k, 2), z3 = PZ(cur, k, 3);
+                    const double z0 = PR(k, 0), z1 = PR(k, 1), z2 = PR(k, 2), z3 = PR(k, 3);
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        PZ(ob, k, c) = ((V[c] * z0 + V[c + 3] * z1) + V[c + 6] * z2) + V[c + 9] * z3;
+                        PR(k, c) = ((V[c] * z0 + V[c + 3] * z1) + V[c + 6] * z2) + V[c + 9] * z3;
                 }
             }
             // centroid(poly_r2, n̂2) (poly_eight.jl:35-52)
             V3 cen;
             {
-                V3 a = mk3(PZ(ob, 0, 0), PZ(ob, 0, 1), PZ(ob, 0, 2));
-                V3 cc = mk3(PZ(ob, 1, 0), PZ(ob, 1, 1), PZ(ob, 1, 2));
+                V3 a = mk3(PR(0, 0), PR(0, 1), PR(0, 2));
+                V3 cc = mk3(PR(1, 0), PR(1, 1), PR(1, 2));
                 double cum_sum = 0.0;
                 V3 cum_prod = mk3(0.0, 0.0, 0.0);
                 for (int k = 2; k < n; ++k) {
                     V3 b = cc;
-                    cc = mk3(PZ(ob, k, 0), PZ(ob, k, 1), PZ(ob, k, 2));
+                    cc = mk3(PR(k, 0), PR(k, 1), PR(k, 2));
                     double ar = triangle_area(a, b, cc, nh);
                     cum_prod = cum_prod + ((a + b) + cc) * (1.0 / 3.0) * ar;
                     cum_sum += ar;
@@ -613,10 +619,10 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             const bool store = materialise && (tbase + slots <= g.tcap);
             if (materialise && !store) atomicOr(g.status, kStTracOvf);
             int tpos = tbase;
-            V3 v2 = mk3(PZ(ob, n - 1, 0), PZ(ob, n - 1, 1), PZ(ob, n - 1, 2));
+            V3 v2 = mk3(PR(n - 1, 0), PR(n - 1, 1), PR(n - 1, 2));
             for (int k = 0; k < n; ++k) {
                 V3 v1 = v2;
-                v2 = mk3(PZ(ob, k, 0), PZ(ob, k, 1), PZ(ob, k, 2));
+                v2 = mk3(PR(k, 0), PR(k, 1), PR(k, 2));
                 double area = triangle_area(v1, v2, cen, nh);
                 if (!(0.0 < area)) continue;  // :232
                 for (int q = 0; q < nq; ++q) {
@@ -717,7 +723,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         count_per_item(g.icnt, cw.item, 3, contributed, n_trac_lane);
     }
 }
-#undef PZ
+#undef PR
 
 // =================================================================================================================
 // bristle model: cop, patch stiffness, 6x6 eigen, friction pass, finalisation
