@@ -40,7 +40,10 @@ def cpu_baseline(pfc, w, budget_s: float):
     om = [O.OracleMesh(ms.mesh, ms.tree, ms.Ebar or 0.0) for ms in w.meshes]
     c = w.instructions[0]
     mu_s, mu_d = pfc.scenario.determine_mu_s_mu_d(c.mu_s, c.mu_d)
-    ins = O.make_ins(c.chi, c.n_quad_rule, O.BRISTLE, mu_s, mu_d, tau=c.tau, k_bar=c.k_bar, magic=c.magic)
+    if c.model == "regularized":
+        ins = O.make_ins(c.chi, c.n_quad_rule, O.REGULARIZED, mu_s, mu_d, v_c=c.v_tol)
+    else:
+        ins = O.make_ins(c.chi, c.n_quad_rule, O.BRISTLE, mu_s, mu_d, tau=c.tau, k_bar=c.k_bar, magic=c.magic)
     ops = items = 0
     O.evaluate(om[c.id_1], om[c.id_2], ins, w.pose[0], w.twist[0], w.s[0], debug=False)   # warm
     t0 = time.perf_counter()
@@ -64,6 +67,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--poses", type=int, default=2048, help="Monte-Carlo poses (items) per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--friction", choices=["bristle", "regularized"], default="bristle",
+                    help="friction model of the C3 instruction (BASELINE: bristle; regularized is an experiment knob)")
     ap.add_argument("--bfs-levels", type=int, default=-1, help="broadphase BFS levels before the DFS kernel (-1 = auto)")
     args = ap.parse_args()
 
@@ -92,6 +97,8 @@ def main():
 
     # ---- synthetic C3 batch; meshes are identical on every rank, poses are rank-specific ---------------------------
     w = pfc.configs.c3_blob_tool(args.poses, seed=20260103 + 7919 * rank)
+    if args.friction == "regularized":
+        w.instructions[0].model = "regularized"
     m = pfc.configs.build_scenario(w, device=local_rank)
     if args.bfs_levels >= 0:
         m.set_option("bfs_levels", args.bfs_levels)
@@ -180,7 +187,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "C3: 9680-tet blob x 5120-tri tool, bristle friction, quad rule 2, "
+            "config": {"workload": f"C3: 9680-tet blob x 5120-tri tool, {args.friction} friction, quad rule 2, "
                                    f"{args.poses} Monte-Carlo poses per GPU per step",
                        "poses_per_gpu": args.poses, "ops_per_step": ops_step, "node_tests_per_step": nodes_step,
                        "traction_points_per_step": trac_step,

@@ -9,9 +9,9 @@
 //   k_narrow        one lane per candidate (triangle, tet) pair: gather 96 B + 256 B records, transform to tet
 //                   coordinates, trivial reject in registers, Sutherland-Hodgman clip with the polygon staged in
 //                   LDS ([slot][coord][lane] layout: conflict-free per-lane dynamic indexing), fan quadrature,
-//                   pressure; regularized friction fused, bristle items materialise traction points (SoA)
-//   k_eig, k_fric   the bristle model: cop + patch stiffness from the origin moments, 6x6 symmetric eigen solve,
-//                   friction pass over the traction points
+//                   pressure; regularized friction fused; bristle items accumulate the patch moments
+//   k_eig           the bristle model: cop + patch stiffness from the origin moments, 6x6 symmetric eigen solve
+//   k_narrow<1>     bristle friction pass: clip + quadrature recomputed, calc_spatial_bristle_force integrated
 //   k_final         per item: wrench, sdot, counts
 #include "pfc_kernels.h"
 
@@ -393,6 +393,7 @@ struct NpArgs {
     const int *ccount;
     int ccap;
     double *acc;
+    const double *res; // per-item derived results (PASS 1)
     int *icnt;
     int *clip_n;     // per candidate, or null
     TracSoA trac;
@@ -400,7 +401,21 @@ struct NpArgs {
     int tcap;
     unsigned *status;
     int debug;       // materialise traction points for every item
+    unsigned long long *stamps;  // diagnostic builds: [0..5] cycles in gather / clip / reserve / integrate / reduce, rounds
 };
+
+// In-kernel phase stamps (diagnostic builds only: -DPFC_STAMPS).  s_memtime ticks = shader cycles; the sums go to a
+// buffer of their own that no kernel reads (MI355X guide: 'In-kernel stamps').
+#ifdef PFC_STAMPS
+#define STAMP(t)                                                                 \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+#else
+#define STAMP(t) do { } while (0)
+#endif
 
 constexpr int kNpBlock = 64;  // one wave per block: 16 KiB of LDS polygon staging per wave
 
@@ -409,16 +424,45 @@ constexpr int kNpBlock = 64;  // one wave per block: 16 KiB of LDS polygon stagi
 // dynamic indexing); logical vertex k of a lane lives in physical slot (rbase + k) & 7
 #define PR(k, c) poly[((((rbase) + (k)) & 7) * 4 + (c)) * kNpBlock + lane]
 
-__device__ __forceinline__ void accumulate_items(double *acc, int item, bool any, const double *v, int n0, int n) {
-    // per-item accumulation of per-lane partial sums: one atomic per run of equal items in the wave
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// Per-item accumulation of N per-lane partial sums.  Segmented scan per value, then the N totals of each run are
+// transposed onto lanes 0..N-1 (readlane from the run's tail) and leave as ONE wave-wide FP64 atomic instruction
+// on N consecutive accumulator slots: single-lane atomics are issue-bound (one wave instruction per ~50 ns per CU,
+// MI355X guide 'Global float atomics'), a 37-lane one costs the same as a 1-lane one.
+template <int N>
+__device__ __forceinline__ void accumulate_items(double *acc, int item, bool any, const double *v, int n0) {
+    static_assert(N <= 64, "one value per lane");
     if (__ballot(any) == 0) return;
     const Seg sg = seg_setup(any ? item : -1);
-    for (int k = 0; k < n; ++k) {
-        const double t = seg_sum(any ? v[k] : 0.0, sg);
-        if (sg.tail && sg.valid && t != 0.0) unsafeAtomicAdd(&acc[(size_t)item * kAccStride + n0 + k], t);
+    double tot[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) tot[k] = seg_sum(any ? v[k] : 0.0, sg);
+    unsigned long long tails = __ballot(sg.tail && sg.valid);
+    const int lane = lane_id();
+    while (tails) {
+        const int t = __builtin_ctzll(tails);
+        tails &= tails - 1;
+        const int item_t = __builtin_amdgcn_readlane(item, t);
+        double mine = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double x = readlane_f64(tot[k], t);
+            if (lane == k) mine = x;
+        }
+        if (lane < N && mine != 0.0) unsafeAtomicAdd(&acc[(size_t)item_t * kAccStride + n0 + lane], mine);
     }
 }
 
+// PASS 0: everything up to the per-item sums (regularized friction fused; bristle: normal wrench + patch moments).
+// PASS 1: bristle items only, after k_eig: the same gather / clip / quadrature is recomputed (bit-identical traction
+//         points) and calc_spatial_bristle_force (friction.jl:171-201) is integrated.  Recomputing is cheaper than
+//         materialising the TractionCache: 9 scattered 8-byte stores per traction point cost 2.7x the whole
+//         clip + quadrature (measured), and the list is only kept in debug mode (pfc_debug_tractions).
+template <int PASS>
 __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
     __shared__ double poly[8 * 4 * kNpBlock];
     const int lane = threadIdx.x;
@@ -427,6 +471,9 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
     const int stride = gridDim.x * kNpBlock;
     const int n_round = (n_c + stride - 1) / stride;
     for (int rd = 0; rd < n_round; ++rd) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+        (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5;
+        STAMP(t0);
         const int idx = rd * stride + blockIdx.x * kNpBlock + lane;
         const bool active = idx < n_c;
         WorkRec cw;
@@ -436,11 +483,13 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         const TetRec *tp = it->tet + cw.b;
         const int nq = it->nq;
         const bool reg = it->model == PFC_REGULARIZED;
-        const bool materialise = active && (g.debug || !reg);
+        const bool materialise = PASS == 0 && active && g.debug;
+        // PASS 1 skips regularized items and items without contact
+        const bool work = active && (PASS == 0 || (!reg && g.icnt[4 * (size_t)cw.item + 3] > 0));
         int n_poly = 0, rbase = 0;
         V3 nh = mk3(0.0, 0.0, 0.0);
         // ==== phase 1 (divergent): gather, transform to tet coordinates, clip ========================================
-        if (active) {
+        if (work) {
             const TriRec tr = it->tri[cw.a];
             double R21[9], t21[3];
 #pragma unroll
@@ -481,6 +530,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0);
             if (!reject) {
+                STAMP(t1);
                 // ---- clip_in_tet_coordinates (static_clip.jl:17-23,34-201), polygon ring in LDS, clipped in place --
                 int n = 3;
 #pragma unroll
@@ -553,20 +603,16 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                              (R21[2] * tr.n[0] + R21[5] * tr.n[1]) + R21[8] * tr.n[2]);
             }
         }
-        if (g.clip_n && active) g.clip_n[idx] = n_poly;
+        if (PASS == 0 && g.clip_n && active) g.clip_n[idx] = n_poly;
+        STAMP(t2);
         // ==== phase 2 (wave-uniform): reserve a contiguous run of traction slots for the whole wave ================
         // A lane with an n-gon owns n * nq consecutive slots, so the traction points of a wave (and, because the
         // candidate list is grouped by item, of an item) are contiguous: the later per-point passes then reduce
         // wave-uniformly with one atomic per wave instead of one per lane.
         const int slots = (materialise && n_poly >= 3) ? n_poly * nq : 0;
         int tbase = 0;
-        {
-            int incl = slots;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int up = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += up;
-            }
+        if (PASS == 0 && g.debug) {
+            int incl = seg_incl_scan(slots);
             const int tot = __shfl(incl, 63, 64);
             int base = 0;
             if (tot > 0) {
@@ -575,6 +621,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             }
             tbase = base + incl - slots;
         }
+        STAMP(t3);
         // ==== phase 3 (divergent): integrate_over_polygon_patch! (non_friction.jl:217-234) ============================
         double sum[10], wrr[6];
 #pragma unroll
@@ -616,6 +663,13 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             const V3 w = ld3(it->w), vl = ld3(it->v);
             const double chi = it->chi, Ebar = it->Ebar;
             const double v_c = it->v_c, mu_s = it->mu_s, mu_d = it->mu_d;
+            V3 cop = mk3(0.0, 0.0, 0.0), Da = cop, Dl = cop;
+            double tau = 0.0, k_bar = 0.0;
+            if (PASS == 1) {
+                const double *res = g.res + (size_t)cw.item * kResStride;
+                cop = ld3(res + kResCop); Da = ld3(res + kResDelta); Dl = ld3(res + kResDelta + 3);
+                tau = it->tau; k_bar = it->k_bar;
+            }
             const bool store = materialise && (tbase + slots <= g.tcap);
             if (materialise && !store) atomicOr(g.status, kStTracOvf);
             int tpos = tbase;
@@ -656,11 +710,31 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         g.trac.dA[tpos] = dA; g.trac.p[tpos] = p;
                         ++tpos;
                     }
+                    if (PASS == 1) {
+                        // calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48)
+                        V3 x = r - cop;
+                        V3 del = Dl + cross(Da, x);
+                        V3 Ts = (del + rdot * tau) * (-k_bar);
+                        Ts = vec_sub_vec_proj(Ts, nh);
+                        double m2 = dot(Ts, Ts);
+                        V3 T;
+                        if (m2 < mu_s * mu_s) {
+                            T = Ts;
+                        } else {
+                            double mg = __builtin_sqrt(m2);
+                            double mu = clamped_piecewise(mg, 2 * mu_s, 3 * mu_s, mu_s, mu_d);
+                            T = (Ts * mu) / mg;
+                        }
+                        V3 Tc = T * p_dA;
+                        V3 ta = cross(x, Tc);
+                        sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+                        sum[3] += Tc.x; sum[4] += Tc.y; sum[5] += Tc.z;
+                        continue;
+                    }
                     V3 tk;
                     if (reg) {
                         // yes_contact!(::Regularized) (friction.jl:50-72) fused
-                        V3 vel = vl + cross(w, r);
-                        V3 vt = vec_sub_vec_proj(vel, nh);
+                        V3 vt = vec_sub_vec_proj(rdot, nh);
                         double m2 = dot(vt, vt);
                         V3 T;
                         if (m2 < v_c * v_c) {
@@ -688,39 +762,50 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             if (store)  // unused slots of this lane's run (area <= 0 or p <= 0 points)
                 for (; tpos < tbase + slots; ++tpos) g.trac.item[tpos] = -1;
         }
+        STAMP(t4);
         // ==== phase 4 (wave-uniform): per-item reductions =============================================================
-        const bool contributed = active && n_trac_lane > 0;
-        accumulate_items(g.acc, cw.item, contributed, sum, 0, 10);
-        if (__any(contributed && !reg)) {
-            // second moments of the bristle patch about the frame origin; n̂ is constant over a lane's polygon, so
-            // sum w n n' = W n n', sum w (r x n) n' = (Wr x n) n', sum w (r x n)(r x n)' = [n]x Wrr [n]x'
-            const bool cb = contributed && !reg;
-            const double W = sum[6];
-            double v[27];
-            v[0] = W * nh.x * nh.x; v[1] = W * nh.x * nh.y; v[2] = W * nh.x * nh.z;
-            v[3] = W * nh.y * nh.y; v[4] = W * nh.y * nh.z; v[5] = W * nh.z * nh.z;
-            const V3 an = cross(mk3(sum[7], sum[8], sum[9]), nh);
-            v[6] = an.x * nh.x; v[7] = an.y * nh.x; v[8] = an.z * nh.x;
-            v[9] = an.x * nh.y; v[10] = an.y * nh.y; v[11] = an.z * nh.y;
-            v[12] = an.x * nh.z; v[13] = an.y * nh.z; v[14] = an.z * nh.z;
-            {
-                // M = [n]x Wrr (rows), then Saa = M [n]x'  i.e. Saa_ij = (n x (Wrr n-cross column j))...
-                const double xx = wrr[0], xy = wrr[1], xz = wrr[2], yy = wrr[3], yz = wrr[4], zz = wrr[5];
-                // columns of Wrr
-                const V3 c0 = mk3(xx, xy, xz), c1 = mk3(xy, yy, yz), c2 = mk3(xz, yz, zz);
-                // M = [n]x Wrr: column j of M = n x c_j
-                const V3 m0 = cross(nh, c0), m1 = cross(nh, c1), m2 = cross(nh, c2);
-                // Saa = M [n]x' ; row i of Saa = (row i of M) [n]x' = -(row_i x n)... use Saa_i. = n x row_i(M)
-                const V3 r0 = cross(nh, mk3(m0.x, m1.x, m2.x)), r1 = cross(nh, mk3(m0.y, m1.y, m2.y));
-                const V3 r2 = cross(nh, mk3(m0.z, m1.z, m2.z));
-                v[15] = r0.x; v[16] = r0.y; v[17] = r0.z; v[18] = r1.y; v[19] = r1.z; v[20] = r2.z;
-            }
+        const bool contributed = work && n_trac_lane > 0;
+        if (PASS == 1) {
+            accumulate_items<6>(g.acc, cw.item, contributed, sum, kAccFric);
+        } else {
+            accumulate_items<10>(g.acc, cw.item, contributed, sum, 0);
+            if (__any(contributed && !reg)) {
+                // second moments of the bristle patch about the frame origin; n̂ is constant over a lane's polygon, so
+                // sum w n n' = W n n', sum w (r x n) n' = (Wr x n) n', sum w (r x n)(r x n)' = [n]x Wrr [n]x'
+                const bool cb = contributed && !reg;
+                const double W = sum[6];
+                double v[27];
+                v[0] = W * nh.x * nh.x; v[1] = W * nh.x * nh.y; v[2] = W * nh.x * nh.z;
+                v[3] = W * nh.y * nh.y; v[4] = W * nh.y * nh.z; v[5] = W * nh.z * nh.z;
+                const V3 an = cross(mk3(sum[7], sum[8], sum[9]), nh);
+                v[6] = an.x * nh.x; v[7] = an.y * nh.x; v[8] = an.z * nh.x;
+                v[9] = an.x * nh.y; v[10] = an.y * nh.y; v[11] = an.z * nh.y;
+                v[12] = an.x * nh.z; v[13] = an.y * nh.z; v[14] = an.z * nh.z;
+                {
+                    const double xx = wrr[0], xy = wrr[1], xz = wrr[2], yy = wrr[3], yz = wrr[4], zz = wrr[5];
+                    const V3 c0 = mk3(xx, xy, xz), c1 = mk3(xy, yy, yz), c2 = mk3(xz, yz, zz);   // columns of Wrr
+                    const V3 m0 = cross(nh, c0), m1 = cross(nh, c1), m2 = cross(nh, c2);         // M = [n]x Wrr
+                    // Saa = M [n]x': row i of Saa = n x (row i of M)
+                    const V3 r0 = cross(nh, mk3(m0.x, m1.x, m2.x)), r1 = cross(nh, mk3(m0.y, m1.y, m2.y));
+                    const V3 r2 = cross(nh, mk3(m0.z, m1.z, m2.z));
+                    v[15] = r0.x; v[16] = r0.y; v[17] = r0.z; v[18] = r1.y; v[19] = r1.z; v[20] = r2.z;
+                }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) v[21 + k] = wrr[k];
-            accumulate_items(g.acc, cw.item, cb, v, kAccSnn, 27);
+                for (int k = 0; k < 6; ++k) v[21 + k] = wrr[k];
+                accumulate_items<27>(g.acc, cw.item, cb, v, kAccSnn);
+            }
+            count_per_item(g.icnt, cw.item, 2, active && n_poly >= 3);
+            count_per_item(g.icnt, cw.item, 3, contributed, n_trac_lane);
         }
-        count_per_item(g.icnt, cw.item, 2, active && n_poly >= 3);
-        count_per_item(g.icnt, cw.item, 3, contributed, n_trac_lane);
+#ifdef PFC_STAMPS
+        STAMP(t5);
+        if (lane == 0 && g.stamps) {
+            // t1 is only stamped when lane 0's wave entered the clip; fold gather+clip when it was not
+            if (t1 == 0) t1 = t2;
+            atomicAdd(&g.stamps[0], t1 - t0); atomicAdd(&g.stamps[1], t2 - t1); atomicAdd(&g.stamps[2], t3 - t2);
+            atomicAdd(&g.stamps[3], t4 - t3); atomicAdd(&g.stamps[4], t5 - t4); atomicAdd(&g.stamps[5], 1ull);
+        }
+#endif
     }
 }
 #undef PR
@@ -884,53 +969,6 @@ __global__ void __launch_bounds__(64) k_eig(BrArgs g) {
     }
 }
 
-// calc_spatial_bristle_force (friction.jl:171-201): one lane per traction point
-__global__ void __launch_bounds__(256) k_fric(BrArgs g) {
-    int n_t = *g.tcount;
-    if (n_t > g.tcap) n_t = g.tcap;
-    const int stride = gridDim.x * blockDim.x;
-    const int n_round = (n_t + stride - 1) / stride;
-    for (int rd = 0; rd < n_round; ++rd) {
-        int idx = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        bool active = idx < n_t;
-        int item = 0;
-        double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (active) {
-            item = g.trac.item[idx];
-            active = item >= 0 && g.items[item].model == PFC_BRISTLE;
-            if (item < 0) item = 0;
-        }
-        if (active) {
-            const ItemRec *it = g.items + item;
-            const double *res = g.res + (size_t)item * kResStride;
-            V3 cop = ld3(res + kResCop);
-            V3 Da = ld3(res + kResDelta), Dl = ld3(res + kResDelta + 3);
-            V3 n = mk3(g.trac.nx[idx], g.trac.ny[idx], g.trac.nz[idx]);
-            V3 r = mk3(g.trac.rx[idx], g.trac.ry[idx], g.trac.rz[idx]);
-            double p_dA = g.trac.p[idx] * g.trac.dA[idx];
-            V3 x = r - cop;
-            V3 del = Dl + cross(Da, x);
-            V3 rp = ld3(it->v) + cross(ld3(it->w), r);
-            V3 Ts = (del + rp * it->tau) * (-it->k_bar);
-            Ts = vec_sub_vec_proj(Ts, n);
-            // traction(::Bristle) (friction.jl:32-48)
-            double m2 = dot(Ts, Ts);
-            V3 T;
-            if (m2 < it->mu_s * it->mu_s) {
-                T = Ts;
-            } else {
-                double mg = __builtin_sqrt(m2);
-                double mu = clamped_piecewise(mg, 2 * it->mu_s, 3 * it->mu_s, it->mu_s, it->mu_d);
-                T = (Ts * mu) / mg;
-            }
-            V3 Tc = T * p_dA;
-            V3 ta = cross(x, Tc);
-            v[0] = ta.x; v[1] = ta.y; v[2] = ta.z; v[3] = Tc.x; v[4] = Tc.y; v[5] = Tc.z;
-        }
-        accumulate_items(g.acc, item, active, v, kAccFric, 6);
-    }
-}
-
 // yes_contact! / no_contact! epilogue (friction.jl:76-81,119-143; non_friction.jl:77-83)
 __global__ void k_final(BrArgs g) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1033,6 +1071,7 @@ struct pfc_context {
     DevBuf<double> acc, res, trac_d;   // trac_d: 8 arrays of tcap
     DevBuf<int> ctr;                   // [0]=ccount [1]=tcount [2..] fcount[levels+2]
     DevBuf<unsigned> status;
+    DevBuf<unsigned long long> stamps;   // diagnostic builds
     size_t fcap = 0, ccap = 0, tcap = 0;
     // host-pointer path staging
     DevBuf<double> h_pose, h_twist, h_s, h_wrench, h_sdot;
@@ -1100,6 +1139,7 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     if ((e = h->icnt.ensure((size_t)n_items * 4)) != hipSuccess) return e;
     if ((e = h->ctr.ensure((size_t)h->max_levels + 8)) != hipSuccess) return e;
     if ((e = h->status.ensure(4)) != hipSuccess) return e;
+    if ((e = h->stamps.ensure(8)) != hipSuccess) return e;
     size_t f = h->fcap ? h->fcap : 1u << 16;
     while (f < (size_t)n_items * 8) f *= 2;
     size_t c = h->ccap ? h->ccap : 1u << 16;
@@ -1183,7 +1223,11 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     np.items = h->items.p; np.cand = h->cand.p; np.ccount = ccount; np.ccap = (int)h->ccap; np.acc = h->acc.p;
     np.icnt = h->icnt.p; np.clip_n = h->opt_debug ? h->clip_n.p : nullptr; np.trac = trac_view(h);
     np.tcount = tcount; np.tcap = (int)h->tcap; np.status = h->status.p; np.debug = h->opt_debug;
-    hipLaunchKernelGGL(k_narrow, dim3(grid_for(h->ccap, kNpBlock, 256 * 20)), dim3(kNpBlock), 0, st, np);
+    np.stamps = h->stamps.p;
+    HIP_TRY(h, hipMemsetAsync(h->stamps.p, 0, sizeof(unsigned long long) * 8, st));
+    np.res = h->res.p;
+    const int np_grid = grid_for(h->ccap, kNpBlock, 256 * 16);
+    hipLaunchKernelGGL(k_narrow<0>, dim3(np_grid), dim3(kNpBlock), 0, st, np);
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_NP], st));
 
     BrArgs br;
@@ -1192,7 +1236,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     br.counts = d_counts;
     if (h->any_bristle) {
         hipLaunchKernelGGL(k_eig, dim3(grid_for(n_items, 64, 1 << 20)), dim3(64), 0, st, br);
-        hipLaunchKernelGGL(k_fric, dim3(grid_for(h->tcap, 256, 2048)), dim3(256), 0, st, br);
+        hipLaunchKernelGGL(k_narrow<1>, dim3(np_grid), dim3(kNpBlock), 0, st, np);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BR], st));
     hipLaunchKernelGGL(k_final, dim3(grid_for(n_items, 128, 1 << 20)), dim3(128), 0, st, br);
@@ -1279,7 +1323,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->d_ins) (void)hipFree(h->d_ins);
     h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
     h->clip_n.release(); h->icnt.release(); h->trac_item.release(); h->acc.release(); h->res.release();
-    h->trac_d.release(); h->ctr.release(); h->status.release();
+    h->trac_d.release(); h->ctr.release(); h->status.release(); h->stamps.release();
     h->h_pose.release(); h->h_twist.release(); h->h_s.release(); h->h_wrench.release(); h->h_sdot.release();
     h->h_ins.release(); h->h_counts.release();
     for (int k = 0; k < EV_COUNT; ++k)
@@ -1588,6 +1632,15 @@ int pfc_debug_stiffness(pfc_handle h, int item, double *K36, double *Kis36, doub
     if (Sinv6) std::memcpy(Sinv6, r.data() + kResSinv, sizeof(double) * 6);
     if (cop3) std::memcpy(cop3, r.data() + kResCop, sizeof(double) * 3);
     return 1;
+}
+
+int pfc_debug_stamps(pfc_handle h, long long *out8) {
+    if (!h || !out8) return PFC_ERR_BAD_ARG;
+    if (h->pending) { int rc = check_eval(h); if (rc) return rc; }
+    unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (h->stamps.p) HIP_TRY(h, hipMemcpy(v, h->stamps.p, sizeof v, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) out8[k] = (long long)v[k];
+    return PFC_OK;
 }
 
 int pfc_selftest_math(pfc_handle h, int n, const double *x, const double *y, double *out3n) {

@@ -288,12 +288,16 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Segmented wave reduction.  Work lists are grouped by item in runs (a seed's candidates, a polygon's traction
 // points), so the 64 lanes of a wave hold a few runs of equal keys.  seg_setup() finds the runs with one ballot;
-// seg_sum() is a segmented inclusive scan (6 shuffle steps, all runs at once) whose value on the last lane of each
-// run is the run's total; that lane issues the run's single atomic.  key < 0 marks a lane without contribution.
+// seg_sum() is a segmented inclusive scan whose value on the last lane of each run is the run's total; that lane
+// issues the run's single atomic.  key < 0 marks a lane without contribution.
+//
+// The scan runs on DPP (data-parallel primitives: VALU cross-lane moves, no LDS round trip): row_shr 1/2/4/8 inside
+// the four 16-lane rows, then row_bcast:15 (last lane of a row into the next row; rows 1 and 3) and row_bcast:31
+// (lane 31 into lanes 32..63).  A step's contribution is added only if its source lane lies inside the lane's run.
 struct Seg {
-    int start;   // first lane of this lane's run
-    bool tail;   // last lane of its run
-    bool valid;  // key >= 0
+    unsigned steps;  // bit k set: step k of the scan (shr1, shr2, shr4, shr8, bcast15, bcast31) stays inside the run
+    bool tail;       // last lane of its run
+    bool valid;      // key >= 0
 };
 __device__ __forceinline__ Seg seg_setup(int key) {
     const int lane = lane_id();
@@ -301,28 +305,50 @@ __device__ __forceinline__ Seg seg_setup(int key) {
     const bool head = (lane == 0) || (key != prev);
     const unsigned long long H = __ballot(head);
     const unsigned long long below = H & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int start = 63 - __builtin_clzll(below);
     Seg s;
-    s.start = 63 - __builtin_clzll(below);
+    s.steps = 0;
+    s.steps |= (lane - 1 >= start) ? 1u : 0u;
+    s.steps |= (lane - 2 >= start) ? 2u : 0u;
+    s.steps |= (lane - 4 >= start) ? 4u : 0u;
+    s.steps |= (lane - 8 >= start) ? 8u : 0u;
+    s.steps |= ((lane & 16) && ((lane & ~15) - 1 >= start)) ? 16u : 0u;
+    s.steps |= (lane >= 32 && 31 >= start) ? 32u : 0u;
     s.tail = (lane == 63) || (((H >> (lane + 1)) & 1ull) != 0);
     s.valid = key >= 0;
     return s;
 }
-__device__ __forceinline__ double seg_sum(double v, const Seg &s) {
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_move(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, kCtrl, kRowMask, 0xF, true);
+}
+// plain (unsegmented) inclusive scan of an int over the wave, same DPP steps
+__device__ __forceinline__ int seg_incl_scan(int v) {
     const int lane = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_up(v, o, 64);
-        if (lane - o >= s.start) v += t;
-    }
+    int t;
+    t = dpp_move<0x111, 0xF>(v); v += t;
+    t = dpp_move<0x112, 0xF>(v); v += t;
+    t = dpp_move<0x114, 0xF>(v); v += t;
+    t = dpp_move<0x118, 0xF>(v); v += t;
+    t = dpp_move<0x142, 0xA>(v); v += (lane & 16) ? t : 0;
+    t = dpp_move<0x143, 0xC>(v); v += (lane >= 32) ? t : 0;
     return v;
 }
-__device__ __forceinline__ int seg_sum(int v, const Seg &s) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o, 64);
-        if (lane - o >= s.start) v += t;
-    }
+template <class T>
+__device__ __forceinline__ T seg_sum(T v, const Seg &s) {
+    T t;
+    t = dpp_move<0x111, 0xF>(v); v += (s.steps & 1u) ? t : T(0);   // row_shr:1
+    t = dpp_move<0x112, 0xF>(v); v += (s.steps & 2u) ? t : T(0);   // row_shr:2
+    t = dpp_move<0x114, 0xF>(v); v += (s.steps & 4u) ? t : T(0);   // row_shr:4
+    t = dpp_move<0x118, 0xF>(v); v += (s.steps & 8u) ? t : T(0);   // row_shr:8
+    t = dpp_move<0x142, 0xA>(v); v += (s.steps & 16u) ? t : T(0);  // row_bcast:15 into rows 1, 3
+    t = dpp_move<0x143, 0xC>(v); v += (s.steps & 32u) ? t : T(0);  // row_bcast:31 into rows 2, 3
     return v;
 }
 

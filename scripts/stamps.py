@@ -1,0 +1,18 @@
+"""Diagnostic: per-phase cycle shares of k_narrow (needs a -DPFC_STAMPS build: scripts/build_stamps.sh)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, pfc_pkg
+pfc = pfc_pkg.load()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+w = pfc.configs.c3_blob_tool(n)
+m = pfc.configs.build_scenario(w)
+for _ in range(3):
+    m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+out = (C.c_longlong * 8)()
+pfc._lib.lib().pfc_debug_stamps(m._h, out)
+v = [int(x) for x in out]
+names = ["gather", "clip", "reserve", "integrate", "reduce"]
+tot = sum(v[:5])
+print("rounds", v[5], "cycles/round", tot / max(v[5], 1))
+for k, nm in enumerate(names):
+    print(f"  {nm:10s} {v[k] / max(v[5], 1):10.0f} cycles/round  {100.0 * v[k] / max(tot, 1):5.1f} %")
