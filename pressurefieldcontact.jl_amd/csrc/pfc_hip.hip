@@ -135,10 +135,10 @@ struct BpArgs {
     int level, fcap, ccap;
 };
 
-__device__ __forceinline__ void count_per_item(int *icnt, int item, int slot, bool flag, int n = 1) {
+__device__ __forceinline__ void count_per_item(int *icnt, int item, int slot, bool listed, bool flag, int n = 1) {
     // per-item integer counter: one atomic per run of equal items in the wave
     if (__ballot(flag) == 0) return;
-    const Seg sg = seg_setup(flag ? item : -1);
+    const Seg sg = seg_setup(listed ? item : -1);
     const int t = seg_sum(flag ? n : 0, sg);
     if (sg.tail && sg.valid && t != 0) atomicAdd(&icnt[4 * (size_t)item + slot], t);
 }
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
             ca0 = a.child0; ca1 = a.child1; cb0 = b.child0; cb1 = b.child1;
             leaf_a = a.leaf; leaf_b = b.leaf;
         }
-        count_per_item(g.icnt, w.item, 0, active);
+        count_per_item(g.icnt, w.item, 0, active, active);
         bool is_cand = hit && la && lb;
         bool two = hit && (la != lb);
         bool four = hit && !la && !lb;
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
                     atomicOr(g.status, kStCandOvf);
                 }
             }
-            count_per_item(g.icnt, w.item, 1, is_cand);
+            count_per_item(g.icnt, w.item, 1, active, is_cand);
         }
         // children
         if (m2 | m4) {
@@ -394,6 +394,9 @@ struct NpArgs {
     int ccap;
     double *acc;
     const double *res; // per-item derived results (PASS 1)
+    double *rec;       // moment records (PASS 0, bristle)
+    int *rcount;
+    int rcap;
     int *icnt;
     int *clip_n;     // per candidate, or null
     TracSoA trac;
@@ -434,10 +437,12 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // on N consecutive accumulator slots: single-lane atomics are issue-bound (one wave instruction per ~50 ns per CU,
 // MI355X guide 'Global float atomics'), a 37-lane one costs the same as a 1-lane one.
 template <int N>
-__device__ __forceinline__ void accumulate_items(double *acc, int item, bool any, const double *v, int n0) {
+__device__ __forceinline__ void accumulate_items(double *acc, int item, bool listed, bool any, const double *v, int n0) {
+    // listed: the lane holds a work-list entry (its item keys the run even if it contributes nothing, so empty
+    // polygons do not chop an item's run into pieces); any: the lane has a contribution
     static_assert(N <= 64, "one value per lane");
     if (__ballot(any) == 0) return;
-    const Seg sg = seg_setup(any ? item : -1);
+    const Seg sg = seg_setup(listed ? item : -1);
     double tot[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) tot[k] = seg_sum(any ? v[k] : 0.0, sg);
@@ -623,11 +628,13 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         }
         STAMP(t3);
         // ==== phase 3 (divergent): integrate_over_polygon_patch! (non_friction.jl:217-234) ============================
-        double sum[10], wrr[6];
+        double sum[10], wr1[3], wrr[6];   // wr1, wrr: first / second moments of w about the polygon centroid
 #pragma unroll
         for (int k = 0; k < 10; ++k) sum[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) wrr[k] = 0.0;
+        wr1[0] = wr1[1] = wr1[2] = 0.0;
+        V3 cen = mk3(0.0, 0.0, 0.0);
         int n_trac_lane = 0;
         if (n_poly >= 3) {
             const int n = n_poly;
@@ -644,7 +651,6 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 }
             }
             // centroid(poly_r2, n̂2) (poly_eight.jl:35-52)
-            V3 cen;
             {
                 V3 a = mk3(PR(0, 0), PR(0, 1), PR(0, 2));
                 V3 cc = mk3(PR(1, 0), PR(1, 1), PR(1, 2));
@@ -748,11 +754,13 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                     } else {
                         // normal_wrench_cop (normal.jl:17-34) fused: pass 1 of the bristle model
                         tk = nh * p_dA;
-                        const double wx = p_dA * r.x, wy = p_dA * r.y, wz = p_dA * r.z;
                         sum[6] += p_dA;
-                        sum[7] += wx; sum[8] += wy; sum[9] += wz;
-                        wrr[0] += wx * r.x; wrr[1] += wx * r.y; wrr[2] += wx * r.z;
-                        wrr[3] += wy * r.y; wrr[4] += wy * r.z; wrr[5] += wz * r.z;
+                        sum[7] += p_dA * r.x; sum[8] += p_dA * r.y; sum[9] += p_dA * r.z;
+                        const V3 rc = r - cen;
+                        const double wx = p_dA * rc.x, wy = p_dA * rc.y, wz = p_dA * rc.z;
+                        wr1[0] += wx; wr1[1] += wy; wr1[2] += wz;
+                        wrr[0] += wx * rc.x; wrr[1] += wx * rc.y; wrr[2] += wx * rc.z;
+                        wrr[3] += wy * rc.y; wrr[4] += wy * rc.z; wrr[5] += wz * rc.z;
                     }
                     V3 ta = cross(r, tk);
                     sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
@@ -766,36 +774,82 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         // ==== phase 4 (wave-uniform): per-item reductions =============================================================
         const bool contributed = work && n_trac_lane > 0;
         if (PASS == 1) {
-            accumulate_items<6>(g.acc, cw.item, contributed, sum, kAccFric);
+            accumulate_items<6>(g.acc, cw.item, active, contributed, sum, kAccFric);
         } else {
-            accumulate_items<10>(g.acc, cw.item, contributed, sum, 0);
+            accumulate_items<10>(g.acc, cw.item, active, contributed, sum, 0);
             if (__any(contributed && !reg)) {
-                // second moments of the bristle patch about the frame origin; n̂ is constant over a lane's polygon, so
-                // sum w n n' = W n n', sum w (r x n) n' = (Wr x n) n', sum w (r x n)(r x n)' = [n]x Wrr [n]x'
+                // ---- patch-stiffness moments of the bristle model, one record per run of an item in this wave ----
                 const bool cb = contributed && !reg;
+                const Seg sg = seg_setup(active ? cw.item : -1);
+                // the run's own pressure centroid c_w = sum w r / sum w, broadcast from the run's tail
+                double Wt = seg_sum(cb ? sum[6] : 0.0, sg);
+                double cx = seg_sum(cb ? sum[7] : 0.0, sg), cy = seg_sum(cb ? sum[8] : 0.0, sg);
+                double cz = seg_sum(cb ? sum[9] : 0.0, sg);
+                Wt = __shfl(Wt, sg.tail_lane, 64);
+                cx = __shfl(cx, sg.tail_lane, 64); cy = __shfl(cy, sg.tail_lane, 64); cz = __shfl(cz, sg.tail_lane, 64);
+                const double iW = (Wt > 0.0) ? 1.0 / Wt : 0.0;
+                const V3 cwv = mk3(cx * iW, cy * iW, cz * iW);
+                // lane moments: polygon centroid -> c_w (parallel axis; |d| is at most the patch size)
                 const double W = sum[6];
+                const V3 d = cen - cwv;
+                const V3 m1 = mk3(wr1[0] + W * d.x, wr1[1] + W * d.y, wr1[2] + W * d.z);   // sum w (r - c_w)
+                double q[6];                                                              // sum w (r-c_w)(r-c_w)'
+                q[0] = wrr[0] + 2.0 * wr1[0] * d.x + W * d.x * d.x;
+                q[1] = wrr[1] + wr1[0] * d.y + wr1[1] * d.x + W * d.x * d.y;
+                q[2] = wrr[2] + wr1[0] * d.z + wr1[2] * d.x + W * d.x * d.z;
+                q[3] = wrr[3] + 2.0 * wr1[1] * d.y + W * d.y * d.y;
+                q[4] = wrr[4] + wr1[1] * d.z + wr1[2] * d.y + W * d.y * d.z;
+                q[5] = wrr[5] + 2.0 * wr1[2] * d.z + W * d.z * d.z;
+                // n̂ is constant over a lane's polygon: sum w n n' = W n n', sum w (x x n) n' = (m1 x n) n',
+                // sum w (x x n)(x x n)' = [n]x Q [n]x'
                 double v[27];
                 v[0] = W * nh.x * nh.x; v[1] = W * nh.x * nh.y; v[2] = W * nh.x * nh.z;
                 v[3] = W * nh.y * nh.y; v[4] = W * nh.y * nh.z; v[5] = W * nh.z * nh.z;
-                const V3 an = cross(mk3(sum[7], sum[8], sum[9]), nh);
+                const V3 an = cross(m1, nh);
                 v[6] = an.x * nh.x; v[7] = an.y * nh.x; v[8] = an.z * nh.x;
                 v[9] = an.x * nh.y; v[10] = an.y * nh.y; v[11] = an.z * nh.y;
                 v[12] = an.x * nh.z; v[13] = an.y * nh.z; v[14] = an.z * nh.z;
                 {
-                    const double xx = wrr[0], xy = wrr[1], xz = wrr[2], yy = wrr[3], yz = wrr[4], zz = wrr[5];
-                    const V3 c0 = mk3(xx, xy, xz), c1 = mk3(xy, yy, yz), c2 = mk3(xz, yz, zz);   // columns of Wrr
-                    const V3 m0 = cross(nh, c0), m1 = cross(nh, c1), m2 = cross(nh, c2);         // M = [n]x Wrr
+                    const V3 c0 = mk3(q[0], q[1], q[2]), c1 = mk3(q[1], q[3], q[4]), c2 = mk3(q[2], q[4], q[5]);
+                    const V3 m0 = cross(nh, c0), m1c = cross(nh, c1), m2 = cross(nh, c2);       // M = [n]x Q
                     // Saa = M [n]x': row i of Saa = n x (row i of M)
-                    const V3 r0 = cross(nh, mk3(m0.x, m1.x, m2.x)), r1 = cross(nh, mk3(m0.y, m1.y, m2.y));
-                    const V3 r2 = cross(nh, mk3(m0.z, m1.z, m2.z));
+                    const V3 r0 = cross(nh, mk3(m0.x, m1c.x, m2.x)), r1 = cross(nh, mk3(m0.y, m1c.y, m2.y));
+                    const V3 r2 = cross(nh, mk3(m0.z, m1c.z, m2.z));
                     v[15] = r0.x; v[16] = r0.y; v[17] = r0.z; v[18] = r1.y; v[19] = r1.z; v[20] = r2.z;
                 }
 #pragma unroll
-                for (int k = 0; k < 6; ++k) v[21 + k] = wrr[k];
-                accumulate_items<27>(g.acc, cw.item, cb, v, kAccSnn);
+                for (int k = 0; k < 6; ++k) v[21 + k] = q[k];
+                double tot[27];
+#pragma unroll
+                for (int k = 0; k < 27; ++k) tot[k] = seg_sum(cb ? v[k] : 0.0, sg);
+                unsigned long long tails = __ballot(sg.tail && sg.valid && Wt > 0.0);
+                while (tails) {
+                    const int t = __builtin_ctzll(tails);
+                    tails &= tails - 1;
+                    // lanes 0..31 assemble the record: item, W, c_w, 27 moments
+                    double mine = 0.0;
+                    if (lane == 0) mine = (double)__builtin_amdgcn_readlane(cw.item, t);
+                    { const double x = readlane_f64(Wt, t); if (lane == 1) mine = x; }
+                    { const double x = readlane_f64(cwv.x, t); if (lane == 2) mine = x; }
+                    { const double x = readlane_f64(cwv.y, t); if (lane == 3) mine = x; }
+                    { const double x = readlane_f64(cwv.z, t); if (lane == 4) mine = x; }
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) {
+                        const double x = readlane_f64(tot[k], t);
+                        if (lane == 5 + k) mine = x;
+                    }
+                    int slot = 0;
+                    if (lane == 0) slot = atomicAdd(g.rcount, 1);
+                    slot = __builtin_amdgcn_readfirstlane(slot);
+                    if (slot < g.rcap) {
+                        if (lane < kRecStride) g.rec[(size_t)slot * kRecStride + lane] = mine;
+                    } else if (lane == 0) {
+                        atomicOr(g.status, kStRecOvf);
+                    }
+                }
             }
-            count_per_item(g.icnt, cw.item, 2, active && n_poly >= 3);
-            count_per_item(g.icnt, cw.item, 3, contributed, n_trac_lane);
+            count_per_item(g.icnt, cw.item, 2, active, active && n_poly >= 3);
+            count_per_item(g.icnt, cw.item, 3, active, contributed, n_trac_lane);
         }
 #ifdef PFC_STAMPS
         STAMP(t5);
@@ -825,6 +879,84 @@ struct BrArgs {
     double *wrench, *sdot;
     int *counts;
 };
+
+// Moves every moment record from its run centroid c_w to the item's cop and adds it to the item accumulators.
+// With d = c_w - cop and sum w (r - c_w) = 0 by construction of c_w:
+//   Snn' = Snn            San' = San + [d]x Snn            Srr' = Srr + W d d'
+//   Saa' = Saa + San [d]x' + [d]x San' + [d]x Snn [d]x'
+// One lane computes one record, the block transposes through LDS so that each record leaves as ONE 27-lane atomic.
+struct ShiftArgs {
+    const double *rec;
+    const int *rcount;
+    int rcap;
+    double *acc;
+};
+__global__ void __launch_bounds__(64) k_shift(ShiftArgs g) {
+    __shared__ double out[64 * 28];
+    __shared__ int items[64];
+    int n_r = *g.rcount;
+    if (n_r > g.rcap) n_r = g.rcap;
+    const int lane = threadIdx.x;
+    for (int base = blockIdx.x * 64; base < n_r; base += gridDim.x * 64) {
+        const int i = base + lane;
+        if (i < n_r) {
+            const double *r = g.rec + (size_t)i * kRecStride;
+            const int item = (int)r[0];
+            const double W = r[1];
+            const double *a = g.acc + (size_t)item * kAccStride;
+            const double S = a[kAccIp];
+            const double d[3] = {r[2] - a[kAccIpc] / S, r[3] - a[kAccIpc + 1] / S, r[4] - a[kAccIpc + 2] / S};
+            const int s6[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+            double Snn[9], San[9], Saa[9], Srr[9];
+            const double dx[9] = {0.0, d[2], -d[1], -d[2], 0.0, d[0], d[1], -d[0], 0.0};   // [d]x column-major
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                Snn[k] = r[5 + s6[k]]; San[k] = r[11 + k]; Saa[k] = r[20 + s6[k]]; Srr[k] = r[26 + s6[k]];
+            }
+            double dS[9], Sd[9], dSd[9];   // [d]x Snn,  San [d]x',  [d]x Snn [d]x'
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii) {
+                    double x = 0.0, y = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { x += dx[ii + 3 * k] * Snn[k + 3 * j]; y += San[ii + 3 * k] * dx[j + 3 * k]; }
+                    dS[ii + 3 * j] = x; Sd[ii + 3 * j] = y;
+                }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii) {
+                    double x = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) x += dS[ii + 3 * k] * dx[j + 3 * k];
+                    dSd[ii + 3 * j] = x;
+                }
+            double *o = out + lane * 28;
+            const int u6[6] = {0, 3, 6, 4, 7, 8};   // xx xy xz yy yz zz in a column-major 3x3
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = Snn[u6[k]];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[6 + k] = San[k] + dS[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int ii = u6[k] % 3, j = u6[k] / 3;
+                o[15 + k] = Saa[u6[k]] + Sd[ii + 3 * j] + Sd[j + 3 * ii] + dSd[u6[k]];
+                o[21 + k] = Srr[u6[k]] + W * d[ii] * d[j];
+            }
+            items[lane] = item;
+        }
+        __syncthreads();
+        const int n_here = (n_r - base < 64) ? (n_r - base) : 64;
+        for (int q = 0; q < n_here; ++q) {
+            if (lane < 27) {
+                const double x = out[q * 28 + lane];
+                if (x != 0.0) unsafeAtomicAdd(&g.acc[(size_t)items[q] * kAccStride + kAccSnn + lane], x);
+            }
+        }
+        __syncthreads();
+    }
+}
 
 // cyclic Jacobi, symmetric 6x6 (stands in for LAPACK eigen!(Hermitian), friction.jl:88).  Every index is a
 // compile-time constant after unrolling so A and V live in registers (runtime-indexed arrays would go to scratch).
@@ -884,45 +1016,24 @@ __global__ void __launch_bounds__(64) k_eig(BrArgs g) {
     const double S = a[kAccIp];
     const double c[3] = {a[kAccIpc] / S, a[kAccIpc + 1] / S, a[kAccIpc + 2] / S};
     r[kResCop] = c[0]; r[kResCop + 1] = c[1]; r[kResCop + 2] = c[2];
-    // calc_patch_spatial_stiffness! (friction.jl:147-169) from the origin moments, shifted to the cop:
-    //   K22 = S I - Snn
-    //   K12 = -(San - [c]x Snn)                               (sum w r = 0 about the cop)
-    //   K11 = -(Crr - tr(Crr) I + Saa - San [c]x' - [c]x San' + [c]x Snn [c]x'),  Crr = Srr - S c c'
+    // calc_patch_spatial_stiffness! (friction.jl:147-169) from the moments about the cop (x = r - cop):
+    //   K22 = S I - sum w n n'      K12 = -sum w (x x n) n'   (sum w [x]x = 0 about the cop)
+    //   K11 = -(sum w x x' - tr(.) I + sum w (x x n)(x x n)')
     const int s6[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};  // symmetric 3x3 from 6 unique
-    double Snn[9], San[9], Saa[9], Crr[9], cx[9] = {0.0, c[2], -c[1], -c[2], 0.0, c[0], c[1], -c[0], 0.0};
+    double Snn[9], San[9], Saa[9], Srr[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        Snn[k] = a[kAccSnn + s6[k]]; Saa[k] = a[kAccSaa + s6[k]]; San[k] = a[kAccSan + k];
-        Crr[k] = a[kAccSrr + s6[k]] - S * c[k % 3] * c[k / 3];
+        Snn[k] = a[kAccSnn + s6[k]]; Saa[k] = a[kAccSaa + s6[k]]; San[k] = a[kAccSan + k]; Srr[k] = a[kAccSrr + s6[k]];
     }
-    double cS[9], Sc[9], cSc[9];   // [c]x Snn,  San [c]x',  [c]x Snn [c]x'
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii) {
-            double x = 0.0, y = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { x += cx[ii + 3 * k] * Snn[k + 3 * j]; y += San[ii + 3 * k] * cx[j + 3 * k]; }
-            cS[ii + 3 * j] = x; Sc[ii + 3 * j] = y;
-        }
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii) {
-            double x = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) x += cS[ii + 3 * k] * cx[j + 3 * k];
-            cSc[ii + 3 * j] = x;
-        }
-    const double trC = Crr[0] + Crr[4] + Crr[8];
+    const double trC = Srr[0] + Srr[4] + Srr[8];
     double K[36];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int ii = 0; ii < 3; ++ii) {
             const double I = (ii == j) ? 1.0 : 0.0;
-            const double k11 = -(Crr[ii + 3 * j] - trC * I + Saa[ii + 3 * j] - Sc[ii + 3 * j] - Sc[j + 3 * ii] + cSc[ii + 3 * j]);
-            const double k12 = -(San[ii + 3 * j] - cS[ii + 3 * j]);
+            const double k11 = -(Srr[ii + 3 * j] - trC * I + Saa[ii + 3 * j]);
+            const double k12 = -San[ii + 3 * j];
             const double k22 = S * I - Snn[ii + 3 * j];
             K[ii + 6 * j] = k11;
             K[ii + 6 * (j + 3)] = k12;
@@ -1068,11 +1179,11 @@ struct pfc_context {
     DevBuf<ItemRec> items;
     DevBuf<WorkRec> frontier[2], cand;
     DevBuf<int> clip_n, icnt, trac_item;
-    DevBuf<double> acc, res, trac_d;   // trac_d: 8 arrays of tcap
+    DevBuf<double> acc, res, trac_d, rec;   // trac_d: 8 arrays of tcap; rec: moment records of kRecStride doubles
     DevBuf<int> ctr;                   // [0]=ccount [1]=tcount [2..] fcount[levels+2]
     DevBuf<unsigned> status;
     DevBuf<unsigned long long> stamps;   // diagnostic builds
-    size_t fcap = 0, ccap = 0, tcap = 0;
+    size_t fcap = 0, ccap = 0, tcap = 0, rcap = 0;
     // host-pointer path staging
     DevBuf<double> h_pose, h_twist, h_s, h_wrench, h_sdot;
     DevBuf<int> h_ins, h_counts;
@@ -1145,7 +1256,10 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     size_t c = h->ccap ? h->ccap : 1u << 16;
     while (c < (size_t)n_items * 4) c *= 2;
     size_t t = h->tcap ? h->tcap : 1u << 16;
-    h->fcap = f; h->ccap = c; h->tcap = t;
+    size_t rc = h->rcap ? h->rcap : 1u << 12;
+    while (rc < c / 32 + (size_t)n_items * 2) rc *= 2;   // about one record per wave round and item boundary
+    h->fcap = f; h->ccap = c; h->tcap = t; h->rcap = rc;
+    if ((e = h->rec.ensure(rc * kRecStride)) != hipSuccess) return e;
     if ((e = h->frontier[0].ensure(f)) != hipSuccess) return e;
     if ((e = h->frontier[1].ensure(f)) != hipSuccess) return e;
     if ((e = h->cand.ensure(c)) != hipSuccess) return e;
@@ -1173,7 +1287,8 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     const bool prof = h->opt_profile != 0;
     if (prof && !h->ev[0])
         for (int k = 0; k < EV_COUNT; ++k) HIP_TRY(h, hipEventCreate(&h->ev[k]));
-    int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2, *fcount = h->ctr.p + 3;
+    int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2, *rcount = h->ctr.p + 3;
+    int *fcount = h->ctr.p + 4;
     HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(int) * ((size_t)levels + 8), st));
     HIP_TRY(h, hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * 4, st));
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
@@ -1225,7 +1340,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     np.tcount = tcount; np.tcap = (int)h->tcap; np.status = h->status.p; np.debug = h->opt_debug;
     np.stamps = h->stamps.p;
     HIP_TRY(h, hipMemsetAsync(h->stamps.p, 0, sizeof(unsigned long long) * 8, st));
-    np.res = h->res.p;
+    np.res = h->res.p; np.rec = h->rec.p; np.rcount = rcount; np.rcap = (int)h->rcap;
     const int np_grid = grid_for(h->ccap, kNpBlock, 256 * 16);
     hipLaunchKernelGGL(k_narrow<0>, dim3(np_grid), dim3(kNpBlock), 0, st, np);
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_NP], st));
@@ -1235,6 +1350,9 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     br.trac = trac_view(h); br.tcount = tcount; br.tcap = (int)h->tcap; br.wrench = d_wrench; br.sdot = d_sdot;
     br.counts = d_counts;
     if (h->any_bristle) {
+        ShiftArgs sh;
+        sh.rec = h->rec.p; sh.rcount = rcount; sh.rcap = (int)h->rcap; sh.acc = h->acc.p;
+        hipLaunchKernelGGL(k_shift, dim3(grid_for(h->rcap, 64, 2048)), dim3(64), 0, st, sh);
         hipLaunchKernelGGL(k_eig, dim3(grid_for(n_items, 64, 1 << 20)), dim3(64), 0, st, br);
         hipLaunchKernelGGL(k_narrow<1>, dim3(np_grid), dim3(kNpBlock), 0, st, np);
     }
@@ -1260,17 +1378,18 @@ int check_eval(pfc_context *h) {
     long long fpeak = 0;
     int used_levels = 0;
     for (int lv = 0; lv <= h->last_bfs_levels && lv <= levels; ++lv) {
-        if (ctr[3 + lv] > fpeak) fpeak = ctr[3 + lv];
-        if (ctr[3 + lv] > 0) used_levels = lv + 1;
+        if (ctr[4 + lv] > fpeak) fpeak = ctr[4 + lv];
+        if (ctr[4 + lv] > 0) used_levels = lv + 1;
     }
     h->stats[1] = ctr[0]; h->last_tslots = ctr[1]; h->stats[4] = used_levels; h->stats[5] = fpeak;
     h->stats[6] = status; h->stats[7] = h->last_n_items;
     if (status & 16u) return fail(h, PFC_ERR_BAD_ARG, "instruction id out of range in ins_ids");
-    if (status & (kStFrontierOvf | kStCandOvf | kStTracOvf)) {
+    if (status & (kStFrontierOvf | kStCandOvf | kStTracOvf | kStRecOvf)) {
         // VectorCache-style growth (src/obb/vector_cache.jl:13-17): at least double, at least the observed need
         if (status & kStFrontierOvf) { size_t f = h->fcap * 2; while (f < (size_t)fpeak) f *= 2; h->fcap = f; }
         if (status & kStCandOvf) { size_t c = h->ccap * 2; while (c < (size_t)ctr[0]) c *= 2; h->ccap = c; }
         if (status & kStTracOvf) { size_t t = h->tcap * 2; while (t < (size_t)ctr[1]) t *= 2; h->tcap = t; }
+        if (status & kStRecOvf) { size_t r = h->rcap * 2; while (r < (size_t)ctr[3]) r *= 2; h->rcap = r; }
         return fail(h, PFC_ERR_OVERFLOW, "work list overflow (status %u): capacities grown to frontier %zu, candidates %zu, tractions %zu",
                     status, h->fcap, h->ccap, h->tcap);
     }
@@ -1323,7 +1442,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->d_ins) (void)hipFree(h->d_ins);
     h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
     h->clip_n.release(); h->icnt.release(); h->trac_item.release(); h->acc.release(); h->res.release();
-    h->trac_d.release(); h->ctr.release(); h->status.release(); h->stamps.release();
+    h->trac_d.release(); h->rec.release(); h->ctr.release(); h->status.release(); h->stamps.release();
     h->h_pose.release(); h->h_twist.release(); h->h_s.release(); h->h_wrench.release(); h->h_sdot.release();
     h->h_ins.release(); h->h_counts.release();
     for (int k = 0; k < EV_COUNT; ++k)

@@ -20,6 +20,7 @@ enum : unsigned {
     kStTracOvf = 8u,
     kStBadIns = 16u,
     kStAbort = 32u,
+    kStRecOvf = 64u,
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -82,18 +83,22 @@ struct alignas(16) WorkRec {  // frontier entry (item, node_a, node_b) or candid
 };
 
 // per-item accumulator slots (doubles).  The bristle model's patch stiffness (calc_patch_spatial_stiffness!,
-// src/contact_algorithms_friction.jl:147-169) is a sum over traction points of polynomials in r - cop; it is
-// accumulated about the frame origin in the same pass that finds the cop and shifted to the cop algebraically
-// afterwards (k_eig), which removes one full pass over the traction points.
+// src/contact_algorithms_friction.jl:147-169) is a sum over traction points of polynomials in r - cop.  It is
+// accumulated in the same pass that finds the cop, without cancellation: every lane sums its polygon's moments about
+// the polygon centroid, a wave run shifts them to the run's own pressure centroid c_w and writes one 32-double
+// record, and k_shift moves each record from c_w to the item's cop (parallel-axis terms only: all shift distances
+// are of the order of the patch size) before adding it here.
 constexpr int kAccWrench = 0;   // 6: regularized total wrench, or bristle normal wrench [ang; lin]
 constexpr int kAccIp = 6;       // 1: S   = sum w            (w = p dA)
-constexpr int kAccIpc = 7;      // 3: Sr  = sum w r
+constexpr int kAccIpc = 7;      // 3: Sr  = sum w r          (about the frame origin: gives the cop)
 constexpr int kAccSnn = 10;     // 6: sum w n n'             (xx xy xz yy yz zz)
-constexpr int kAccSan = 16;     // 9: sum w (r x n) n'       (column-major 3x3)
-constexpr int kAccSaa = 25;     // 6: sum w (r x n)(r x n)'
-constexpr int kAccSrr = 31;     // 6: sum w r r'
+constexpr int kAccSan = 16;     // 9: sum w (x x n) n'       (column-major 3x3), x = r - cop
+constexpr int kAccSaa = 25;     // 6: sum w (x x n)(x x n)'
+constexpr int kAccSrr = 31;     // 6: sum w x x'
 constexpr int kAccFric = 37;    // 6: friction wrench about the cop [ang; lin]
 constexpr int kAccStride = 44;
+// moment record of one wave run: item, W, c_w(3), Snn 6, San 9, Saa 6, Srr 6 (about c_w)
+constexpr int kRecStride = 32;
 // per-item derived results (doubles)
 constexpr int kResCop = 0;      // 3
 constexpr int kResSinv = 3;     // 6
@@ -298,6 +303,7 @@ struct Seg {
     unsigned steps;  // bit k set: step k of the scan (shr1, shr2, shr4, shr8, bcast15, bcast31) stays inside the run
     bool tail;       // last lane of its run
     bool valid;      // key >= 0
+    int tail_lane;   // lane index of the last lane of this lane's run
 };
 __device__ __forceinline__ Seg seg_setup(int key) {
     const int lane = lane_id();
@@ -316,6 +322,8 @@ __device__ __forceinline__ Seg seg_setup(int key) {
     s.steps |= (lane >= 32 && 31 >= start) ? 32u : 0u;
     s.tail = (lane == 63) || (((H >> (lane + 1)) & 1ull) != 0);
     s.valid = key >= 0;
+    const unsigned long long above = (lane == 63) ? 0ull : (H >> (lane + 1));
+    s.tail_lane = above ? lane + __builtin_ctzll(above) : 63;
     return s;
 }
 template <int kCtrl, int kRowMask>
