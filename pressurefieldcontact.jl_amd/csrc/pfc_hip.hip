@@ -958,47 +958,77 @@ __global__ void __launch_bounds__(64) k_shift(ShiftArgs g) {
     }
 }
 
-// cyclic Jacobi, symmetric 6x6 (stands in for LAPACK eigen!(Hermitian), friction.jl:88).  Every index is a
-// compile-time constant after unrolling so A and V live in registers (runtime-indexed arrays would go to scratch).
+// Jacobi eigen-solver for a symmetric 6x6 (stands in for LAPACK eigen!(Hermitian), friction.jl:88).  One thread per
+// item, so the kernel's duration is the length of the serial dependency chain: the sweep uses the round-robin
+// ordering (5 rounds of 3 index-disjoint pairs).  The three rotations of a round read disjoint entries of A, so their
+// angle computations (the sqrt / divide chains) are independent and overlap; every index is a compile-time constant
+// after unrolling, so A and V live in registers (runtime-indexed arrays would go to scratch).
+__device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq, double &cs, double &sn) {
+    // apq == 0: identity rotation
+    const double theta = (aqq - app) / (2.0 * apq);
+    double t = (theta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
+    if (apq == 0.0) t = 0.0;
+    cs = 1.0 / __builtin_sqrt(t * t + 1.0);
+    sn = t * cs;
+}
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_apply(double *A, double *V, double cs, double sn) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double akp = A[k + 6 * P], akq = A[k + 6 * Q];
+        A[k + 6 * P] = cs * akp - sn * akq; A[k + 6 * Q] = sn * akp + cs * akq;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double apk = A[P + 6 * k], aqk = A[Q + 6 * k];
+        A[P + 6 * k] = cs * apk - sn * aqk; A[Q + 6 * k] = sn * apk + cs * aqk;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double vkp = V[k + 6 * P], vkq = V[k + 6 * Q];
+        V[k + 6 * P] = cs * vkp - sn * vkq; V[k + 6 * Q] = sn * vkp + cs * vkq;
+    }
+}
+template <int P0, int Q0, int P1, int Q1, int P2, int Q2>
+__device__ __forceinline__ void jacobi_round(double *A, double *V) {
+    double c0, s0, c1, s1, c2, s2;
+    jacobi_angle(A[7 * P0], A[7 * Q0], A[P0 + 6 * Q0], c0, s0);
+    jacobi_angle(A[7 * P1], A[7 * Q1], A[P1 + 6 * Q1], c1, s1);
+    jacobi_angle(A[7 * P2], A[7 * Q2], A[P2 + 6 * Q2], c2, s2);
+    jacobi_apply<P0, Q0>(A, V, c0, s0);
+    jacobi_apply<P1, Q1>(A, V, c1, s1);
+    jacobi_apply<P2, Q2>(A, V, c2, s2);
+}
 __device__ __forceinline__ void jacobi6(double *A, double *V, double *w) {
 #pragma unroll
     for (int i = 0; i < 36; ++i) V[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) V[7 * i] = 1.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, dia = 0.0;
+    double off_prev = 1.79769313486231570815e308;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        // Converged when every off-diagonal entry is below the rounding floor of the matrix (eps * largest diagonal)
+        // or negligible against its own two diagonal entries; also stop once (after 4 sweeps) a sweep no longer
+        // halves the off-diagonal mass (nothing but rounding noise is left to annihilate).  Waiting for an absolute 1e-17
+        // would spin through all sweeps: entries coupled to the large eigenvalues never get below eps * |A|.
+        double off = 0.0, dmax = 0.0;
+        bool done = true;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 6; ++i) dmax = fmax(dmax, __builtin_fabs(A[7 * i]));
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
-                if (i != j) off += A[i + 6 * j] * A[i + 6 * j]; else dia += A[7 * i] * A[7 * i];
-        if (off <= 1e-300 || off <= 1e-34 * dia) break;
+        for (int i = 0; i < 5; ++i)
 #pragma unroll
-        for (int p = 0; p < 5; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 6; ++q) {
-                const double apq = A[p + 6 * q];
-                // apq == 0: identity rotation (t = 0), same result as skipping the pair
-                const double theta = (A[7 * q] - A[7 * p]) / (2.0 * apq);
-                double t = (theta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
-                if (apq == 0.0) t = 0.0;
-                const double cs = 1.0 / __builtin_sqrt(t * t + 1.0), sn = t * cs;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const double akp = A[k + 6 * p], akq = A[k + 6 * q];
-                    A[k + 6 * p] = cs * akp - sn * akq; A[k + 6 * q] = sn * akp + cs * akq;
-                }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const double apk = A[p + 6 * k], aqk = A[q + 6 * k];
-                    A[p + 6 * k] = cs * apk - sn * aqk; A[q + 6 * k] = sn * apk + cs * aqk;
-                }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const double vkp = V[k + 6 * p], vkq = V[k + 6 * q];
-                    V[k + 6 * p] = cs * vkp - sn * vkq; V[k + 6 * q] = sn * vkp + cs * vkq;
-                }
+            for (int j = i + 1; j < 6; ++j) {
+                const double a = __builtin_fabs(A[i + 6 * j]);
+                off += a * a;
+                done &= a <= 2.3e-16 * dmax || a * a <= 1e-30 * __builtin_fabs(A[7 * i] * A[7 * j]);
             }
+        if (done || (sweep >= 4 && !(off < 0.5 * off_prev))) break;
+        off_prev = off;
+        jacobi_round<0, 5, 1, 4, 2, 3>(A, V);
+        jacobi_round<0, 4, 3, 5, 1, 2>(A, V);
+        jacobi_round<0, 3, 2, 4, 1, 5>(A, V);
+        jacobi_round<0, 2, 1, 3, 4, 5>(A, V);
+        jacobi_round<0, 1, 2, 5, 3, 4>(A, V);
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) w[i] = A[7 * i];
