@@ -86,7 +86,7 @@ __global__ void k_setup_items(EvalArgs g) {
     int id = g.ins_ids ? g.ins_ids[i] : i;
     ItemRec r;
     if (id < 0 || id >= g.n_ins) {
-        atomicOr(g.status, 16u);
+        atomicOr(g.status, kStBadIns);
         id = 0;
     }
     const InsDev in = g.ins[id];
@@ -1145,6 +1145,26 @@ __global__ void k_final(BrArgs g) {
     }
 }
 
+// Gathers everything the host needs to judge an evaluation into one small block (one D2H copy instead of five):
+// tail[0..3] status words, tail[4..11] totals {node tests, non-empty pairs, traction points, 0} as 64-bit,
+// tail[12..] the counter block (candidates, traction slots, seed ticket, records, frontier sizes per level).
+__global__ void __launch_bounds__(256) k_pack(int n_items, const int *icnt, const int *ctr, int n_ctr,
+                                               const unsigned *status, int *tail) {
+    __shared__ unsigned long long tot[3];
+    if (threadIdx.x < 3) tot[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long a = 0, b = 0, c = 0;
+    for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
+        a += (unsigned)icnt[4 * (size_t)i]; b += (unsigned)icnt[4 * (size_t)i + 2]; c += (unsigned)icnt[4 * (size_t)i + 3];
+    }
+    atomicAdd(&tot[0], a); atomicAdd(&tot[1], b); atomicAdd(&tot[2], c);
+    __syncthreads();
+    if (threadIdx.x < 4) tail[threadIdx.x] = (int)status[threadIdx.x];
+    if (threadIdx.x < 3) reinterpret_cast<unsigned long long *>(tail + 4)[threadIdx.x] = tot[threadIdx.x];
+    if (threadIdx.x == 3) reinterpret_cast<unsigned long long *>(tail + 4)[3] = 0ull;
+    for (int k = threadIdx.x; k < n_ctr; k += blockDim.x) tail[12 + k] = ctr[k];
+}
+
 __global__ void k_selftest(int n, const double *x, const double *y, double *out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1213,6 +1233,22 @@ struct pfc_context {
     DevBuf<int> ctr;                   // [0]=ccount [1]=tcount [2..] fcount[levels+2]
     DevBuf<unsigned> status;
     DevBuf<unsigned long long> stamps;   // diagnostic builds
+    DevBuf<int> tail;                    // k_pack output (status, totals, counters)
+    int *h_tail = nullptr;               // pinned host mirror of tail
+    size_t h_tail_cap = 0;
+    void *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-buffer path
+    size_t pin_in_cap = 0, pin_out_cap = 0;
+    unsigned long long epoch = 0;        // bumped whenever a device work buffer is reallocated
+    // captured launch sequence (hipGraph) of the last evaluation shape
+    hipGraphExec_t gexec = nullptr;
+    struct GraphKey {
+        int n_items, levels, L, debug, bristle;
+        const void *p[7];
+        void *stream;
+        unsigned long long epoch;
+    } gkey = {};
+    bool ghave = false;
+    int opt_graph = 1;
     size_t fcap = 0, ccap = 0, tcap = 0, rcap = 0;
     // host-pointer path staging
     DevBuf<double> h_pose, h_twist, h_s, h_wrench, h_sdot;
@@ -1274,6 +1310,9 @@ int grid_for(size_t n, int block, int max_blocks) {
 
 hipError_t ensure_work(pfc_context *h, int n_items) {
     hipError_t e;
+    const size_t caps0[] = {h->items.cap, h->acc.cap, h->res.cap, h->icnt.cap, h->ctr.cap, h->frontier[0].cap,
+                            h->frontier[1].cap, h->cand.cap, h->clip_n.cap, h->trac_item.cap, h->trac_d.cap, h->rec.cap,
+                            h->tail.cap};
     if ((e = h->items.ensure(n_items)) != hipSuccess) return e;
     if ((e = h->acc.ensure((size_t)n_items * kAccStride)) != hipSuccess) return e;
     if ((e = h->res.ensure((size_t)n_items * kResStride)) != hipSuccess) return e;
@@ -1296,6 +1335,18 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     if ((e = h->clip_n.ensure(c)) != hipSuccess) return e;
     if ((e = h->trac_item.ensure(t)) != hipSuccess) return e;
     if ((e = h->trac_d.ensure(t * 8)) != hipSuccess) return e;
+    if ((e = h->tail.ensure((size_t)h->max_levels + 32)) != hipSuccess) return e;
+    if (h->h_tail_cap < (size_t)h->max_levels + 32) {
+        if (h->h_tail) (void)hipHostFree(h->h_tail);
+        h->h_tail = nullptr; h->h_tail_cap = 0;
+        if ((e = hipHostMalloc((void **)&h->h_tail, sizeof(int) * ((size_t)h->max_levels + 32))) != hipSuccess) return e;
+        h->h_tail_cap = (size_t)h->max_levels + 32;
+    }
+    const size_t caps1[] = {h->items.cap, h->acc.cap, h->res.cap, h->icnt.cap, h->ctr.cap, h->frontier[0].cap,
+                            h->frontier[1].cap, h->cand.cap, h->clip_n.cap, h->trac_item.cap, h->trac_d.cap, h->rec.cap,
+                            h->tail.cap};
+    for (size_t k = 0; k < sizeof caps0 / sizeof caps0[0]; ++k)
+        if (caps0[k] != caps1[k]) { ++h->epoch; break; }
     return hipSuccess;
 }
 
@@ -1310,13 +1361,21 @@ TracSoA trac_view(pfc_context *h) {
 }
 
 // Enqueue one evaluation.  All pointers are device pointers.
-int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
-                 const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st) {
-    HIP_TRY(h, ensure_work(h, n_items));
+int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
+    int L = 0;
+    if (h->opt_bfs_levels >= 0) {
+        L = h->opt_bfs_levels;
+    } else {
+        double seeds = (double)n_items;
+        while (seeds < 2048.0 && L < 8) { seeds *= 4.0; ++L; }
+    }
+    return L > levels ? levels : L;
+}
+
+// The launch sequence of one evaluation on stream st (eagerly, or while st is being captured into a graph).
+int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
+                const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st, bool prof) {
     const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
-    const bool prof = h->opt_profile != 0;
-    if (prof && !h->ev[0])
-        for (int k = 0; k < EV_COUNT; ++k) HIP_TRY(h, hipEventCreate(&h->ev[k]));
     int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2, *rcount = h->ctr.p + 3;
     int *fcount = h->ctr.p + 4;
     HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(int) * ((size_t)levels + 8), st));
@@ -1333,14 +1392,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
 
     // broadphase: a few level-synchronous expansions to get enough independent seed pairs, then the per-wave
     // depth-first kernel for everything below
-    int L = 0;
-    if (h->opt_bfs_levels >= 0) {
-        L = h->opt_bfs_levels;
-    } else {
-        double seeds = (double)n_items;
-        while (seeds < 2048.0 && L < 8) { seeds *= 4.0; ++L; }
-    }
-    if (L > levels) L = levels;
+    const int L = bfs_levels_for(h, n_items, levels);
     for (int lv = 0; lv < L; ++lv) {
         BpArgs b;
         b.items = h->items.p; b.fin = h->frontier[lv & 1].p; b.fout = h->frontier[(lv + 1) & 1].p;
@@ -1361,7 +1413,6 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
         size_t bound = ub > (double)h->fcap ? h->fcap : (size_t)ub;
         hipLaunchKernelGGL(k_bp_dfs, dim3(grid_for(bound, 1, 256 * 12)), dim3(64), 0, st, d);
     }
-    h->last_bfs_levels = L;
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));
 
     NpArgs np;
@@ -1369,7 +1420,9 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     np.icnt = h->icnt.p; np.clip_n = h->opt_debug ? h->clip_n.p : nullptr; np.trac = trac_view(h);
     np.tcount = tcount; np.tcap = (int)h->tcap; np.status = h->status.p; np.debug = h->opt_debug;
     np.stamps = h->stamps.p;
+#ifdef PFC_STAMPS
     HIP_TRY(h, hipMemsetAsync(h->stamps.p, 0, sizeof(unsigned long long) * 8, st));
+#endif
     np.res = h->res.p; np.rec = h->rec.p; np.rcount = rcount; np.rcap = (int)h->rcap;
     const int np_grid = grid_for(h->ccap, kNpBlock, 256 * 16);
     hipLaunchKernelGGL(k_narrow<0>, dim3(np_grid), dim3(kNpBlock), 0, st, np);
@@ -1389,7 +1442,52 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BR], st));
     hipLaunchKernelGGL(k_final, dim3(grid_for(n_items, 128, 1 << 20)), dim3(128), 0, st, br);
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_FIN], st));
+    hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, st, n_items, h->icnt.p, h->ctr.p, levels + 8, h->status.p, h->tail.p);
     HIP_TRY(h, hipGetLastError());
+    return PFC_OK;
+}
+
+// Enqueue one evaluation.  All pointers are device pointers.  The fixed launch sequence (2 memsets + 8..20 small
+// kernels) is captured into a hipGraph the first time a shape is seen and replayed afterwards: for the reference's
+// own scene sizes (a handful of instructions per calcXd!) launch overhead, not kernel time, is what an evaluation
+// costs.  Profiling (HIP events between stages) uses the eager path.
+int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
+                 const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st) {
+    HIP_TRY(h, ensure_work(h, n_items));
+    const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
+    const bool prof = h->opt_profile != 0;
+    if (prof && !h->ev[0])
+        for (int k = 0; k < EV_COUNT; ++k) HIP_TRY(h, hipEventCreate(&h->ev[k]));
+    const int L = bfs_levels_for(h, n_items, levels);
+    bool use_graph = h->opt_graph && !prof;
+#ifdef PFC_STAMPS
+    use_graph = false;
+#endif
+    if (use_graph) {
+        pfc_context::GraphKey key = {};
+        key.n_items = n_items; key.levels = levels; key.L = L; key.debug = h->opt_debug; key.bristle = h->any_bristle;
+        key.p[0] = d_ins_ids; key.p[1] = d_pose; key.p[2] = d_twist; key.p[3] = d_s; key.p[4] = d_wrench;
+        key.p[5] = d_sdot; key.p[6] = d_counts; key.stream = (void *)st; key.epoch = h->epoch;
+        if (!h->ghave || std::memcmp(&key, &h->gkey, sizeof key) != 0) {
+            if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+            h->ghave = false;
+            hipGraph_t graph = nullptr;
+            HIP_TRY(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = record_eval(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st, false);
+            hipError_t e = hipStreamEndCapture(st, &graph);
+            if (rc != PFC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (e != hipSuccess) return fail(h, PFC_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            e = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) return fail(h, PFC_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+            h->gkey = key; h->ghave = true;
+        }
+        HIP_TRY(h, hipGraphLaunch(h->gexec, st));
+    } else {
+        int rc = record_eval(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st, prof);
+        if (rc != PFC_OK) return rc;
+    }
+    h->last_bfs_levels = L;
     h->last_n_items = n_items; h->last_levels = levels; h->pending = true; h->last_stream = st;
     h->ev_valid = prof;
     return PFC_OK;
@@ -1398,13 +1496,15 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
 // Synchronise, read counters, grow on overflow.
 int check_eval(pfc_context *h) {
     if (!h->pending) return PFC_OK;
+    const int levels = h->last_levels;
+    const size_t n_tail = (size_t)levels + 8 + 12;
+    HIP_TRY(h, hipMemcpyAsync(h->h_tail, h->tail.p, sizeof(int) * n_tail, hipMemcpyDeviceToHost, h->last_stream));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     h->pending = false;
-    const int levels = h->last_levels;
-    std::vector<int> ctr((size_t)levels + 8);
-    unsigned status = 0;
-    HIP_TRY(h, hipMemcpy(ctr.data(), h->ctr.p, sizeof(int) * ctr.size(), hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(&status, h->status.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+    const int *tail = h->h_tail;
+    const unsigned status = (unsigned)tail[0];
+    const unsigned long long *tot = reinterpret_cast<const unsigned long long *>(tail + 4);
+    const int *ctr = tail + 12;
     long long fpeak = 0;
     int used_levels = 0;
     for (int lv = 0; lv <= h->last_bfs_levels && lv <= levels; ++lv) {
@@ -1413,26 +1513,19 @@ int check_eval(pfc_context *h) {
     }
     h->stats[1] = ctr[0]; h->last_tslots = ctr[1]; h->stats[4] = used_levels; h->stats[5] = fpeak;
     h->stats[6] = status; h->stats[7] = h->last_n_items;
-    if (status & 16u) return fail(h, PFC_ERR_BAD_ARG, "instruction id out of range in ins_ids");
+    if (status & kStBadIns) return fail(h, PFC_ERR_BAD_ARG, "instruction id out of range in ins_ids");
     if (status & (kStFrontierOvf | kStCandOvf | kStTracOvf | kStRecOvf)) {
         // VectorCache-style growth (src/obb/vector_cache.jl:13-17): at least double, at least the observed need
         if (status & kStFrontierOvf) { size_t f = h->fcap * 2; while (f < (size_t)fpeak) f *= 2; h->fcap = f; }
         if (status & kStCandOvf) { size_t c = h->ccap * 2; while (c < (size_t)ctr[0]) c *= 2; h->ccap = c; }
         if (status & kStTracOvf) { size_t t = h->tcap * 2; while (t < (size_t)ctr[1]) t *= 2; h->tcap = t; }
         if (status & kStRecOvf) { size_t r = h->rcap * 2; while (r < (size_t)ctr[3]) r *= 2; h->rcap = r; }
-        return fail(h, PFC_ERR_OVERFLOW, "work list overflow (status %u): capacities grown to frontier %zu, candidates %zu, tractions %zu",
-                    status, h->fcap, h->ccap, h->tcap);
+        return fail(h, PFC_ERR_OVERFLOW, "work list overflow (status %u): capacities grown to frontier %zu, candidates %zu, tractions %zu, records %zu",
+                    status, h->fcap, h->ccap, h->tcap, h->rcap);
     }
     if (status & kStAbort) return fail(h, PFC_ERR_STATE, "broadphase aborted: iteration guard hit (corrupt tree?)");
     if (status & kStNonFinite) return fail(h, PFC_ERR_NONFINITE, "Non-finite vertex likely");
-    // totals
-    std::vector<int> ic((size_t)h->last_n_items * 4);
-    if (!ic.empty()) HIP_TRY(h, hipMemcpy(ic.data(), h->icnt.p, sizeof(int) * ic.size(), hipMemcpyDeviceToHost));
-    long long nt = 0, ne = 0, np = 0;
-    for (int i = 0; i < h->last_n_items; ++i) {
-        nt += ic[4 * (size_t)i]; ne += ic[4 * (size_t)i + 2]; np += ic[4 * (size_t)i + 3];
-    }
-    h->stats[0] = nt; h->stats[2] = ne; h->stats[3] = np;
+    h->stats[0] = (long long)tot[0]; h->stats[2] = (long long)tot[1]; h->stats[3] = (long long)tot[2];
     return PFC_OK;
 }
 
@@ -1477,6 +1570,11 @@ void pfc_destroy(pfc_handle h) {
     h->h_ins.release(); h->h_counts.release();
     for (int k = 0; k < EV_COUNT; ++k)
         if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->h_tail) (void)hipHostFree(h->h_tail);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
+    h->tail.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1667,26 +1765,46 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     if (!pose || !twist || !wrench || !sdot) return fail(h, PFC_ERR_BAD_ARG, "null buffer");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t n = (size_t)n_items;
-    HIP_TRY(h, h->h_pose.ensure(n * 24)); HIP_TRY(h, h->h_twist.ensure(n * 6)); HIP_TRY(h, h->h_s.ensure(n * 6));
-    HIP_TRY(h, h->h_wrench.ensure(n * 6)); HIP_TRY(h, h->h_sdot.ensure(n * 6)); HIP_TRY(h, h->h_counts.ensure(n * 4));
-    HIP_TRY(h, h->h_ins.ensure(n));
+    // one pinned block in (pose | twist | s | ins_ids), one pinned block out (wrench | sdot | counts): two async
+    // copies around the launch sequence and a single synchronisation
+    const size_t in_d = n * 36, in_bytes = in_d * sizeof(double) + n * sizeof(int);
+    const size_t out_d = n * 12, out_bytes = out_d * sizeof(double) + n * 4 * sizeof(int);
+    if (h->pin_in_cap < in_bytes) {
+        if (h->pin_in) (void)hipHostFree(h->pin_in);
+        h->pin_in = nullptr; h->pin_in_cap = 0;
+        HIP_TRY(h, hipHostMalloc(&h->pin_in, in_bytes * 2));
+        h->pin_in_cap = in_bytes * 2;
+    }
+    if (h->pin_out_cap < out_bytes) {
+        if (h->pin_out) (void)hipHostFree(h->pin_out);
+        h->pin_out = nullptr; h->pin_out_cap = 0;
+        HIP_TRY(h, hipHostMalloc(&h->pin_out, out_bytes * 2));
+        h->pin_out_cap = out_bytes * 2;
+    }
+    HIP_TRY(h, h->h_pose.ensure(in_d + (n + 1) / 2 + 1));      // device mirror of the input block (doubles)
+    HIP_TRY(h, h->h_wrench.ensure(out_d + 2 * n + 1));         // device mirror of the output block
+    double *pi = (double *)h->pin_in;
+    std::memcpy(pi, pose, sizeof(double) * n * 24);
+    std::memcpy(pi + n * 24, twist, sizeof(double) * n * 6);
+    if (s) std::memcpy(pi + n * 30, s, sizeof(double) * n * 6); else std::memset(pi + n * 30, 0, sizeof(double) * n * 6);
+    if (ins_ids) std::memcpy(pi + in_d, ins_ids, sizeof(int) * n);
     hipStream_t st = h->stream;
-    HIP_TRY(h, hipMemcpyAsync(h->h_pose.p, pose, sizeof(double) * n * 24, hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipMemcpyAsync(h->h_twist.p, twist, sizeof(double) * n * 6, hipMemcpyHostToDevice, st));
-    if (s) HIP_TRY(h, hipMemcpyAsync(h->h_s.p, s, sizeof(double) * n * 6, hipMemcpyHostToDevice, st));
-    if (ins_ids) HIP_TRY(h, hipMemcpyAsync(h->h_ins.p, ins_ids, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    double *di = h->h_pose.p, *dout = h->h_wrench.p;
+    HIP_TRY(h, hipMemcpyAsync(di, pi, ins_ids ? in_bytes : in_d * sizeof(double), hipMemcpyHostToDevice, st));
     int rc = PFC_OK;
     for (int attempt = 0; attempt < 40; ++attempt) {
-        rc = pfc_eval_device(h, n_items, ins_ids ? h->h_ins.p : nullptr, h->h_pose.p, h->h_twist.p,
-                             s ? h->h_s.p : nullptr, h->h_wrench.p, h->h_sdot.p, h->h_counts.p, st);
+        rc = pfc_eval_device(h, n_items, ins_ids ? (const int *)(di + in_d) : nullptr, di, di + n * 24,
+                             s ? di + n * 30 : nullptr, dout, dout + n * 6, (int *)(dout + out_d), st);
         if (rc != PFC_OK) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->pin_out, dout, out_bytes, hipMemcpyDeviceToHost, st));
         rc = check_eval(h);
         if (rc != PFC_ERR_OVERFLOW) break;
     }
     if (rc != PFC_OK) return rc;
-    HIP_TRY(h, hipMemcpy(wrench, h->h_wrench.p, sizeof(double) * n * 6, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(sdot, h->h_sdot.p, sizeof(double) * n * 6, hipMemcpyDeviceToHost));
-    if (counts) HIP_TRY(h, hipMemcpy(counts, h->h_counts.p, sizeof(int) * n * 4, hipMemcpyDeviceToHost));
+    const double *po = (const double *)h->pin_out;
+    std::memcpy(wrench, po, sizeof(double) * n * 6);
+    std::memcpy(sdot, po + n * 6, sizeof(double) * n * 6);
+    if (counts) std::memcpy(counts, po + out_d, sizeof(int) * n * 4);
     return PFC_OK;
 }
 
@@ -1696,6 +1814,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "profile")) h->opt_profile = value != 0;
     else if (!std::strcmp(name, "max_levels")) h->opt_max_levels = (int)value;
     else if (!std::strcmp(name, "bfs_levels")) h->opt_bfs_levels = (int)value;
+    else if (!std::strcmp(name, "graph")) h->opt_graph = value != 0;
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;
 }

@@ -1,0 +1,23 @@
+"""Latency of one forceAllElasticIntersections! evaluation for the small reference-sized scenes (C1, C2):
+this is what a Radau stage evaluation pays.  Host-buffer path (pfc_eval: H2D copy, kernels, D2H copy, sync)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, pfc_pkg
+pfc = pfc_pkg.load()
+for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
+                ("C2 box on plane (1 instruction, 972 tets)", pfc.configs.c2_box_on_plane(1)),
+                ("C3 single pose (bristle)", pfc.configs.c3_blob_tool(1)),
+                ("C4 256 scenes", pfc.configs.c2_box_on_plane(256, montecarlo=True)),
+                ("C5 pile 2016 instructions", pfc.configs.c5_pile())):
+    m = pfc.configs.build_scenario(w)
+    for _ in range(5):
+        m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    n = 100
+    t0 = time.perf_counter()
+    for _ in range(n):
+        wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    dt = (time.perf_counter() - t0) / n
+    st = m.stats()
+    print(f"{name:45s} {dt*1e6:9.1f} us/eval   ops {st['candidates']:8d}  node tests {st['node_tests']:9d}  "
+          f"-> {st['candidates']/dt:.3g} ops/s, {w.n_items/dt:.3g} contact pairs/s")
+    m.close()
