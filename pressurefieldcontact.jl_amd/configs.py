@@ -212,6 +212,42 @@ def c5_pile(n_side: int = 4, seed: int = 20260102, n_divs=(3, 5, 14), overlap: f
                     np.array(twist), np.array(s), {"n_body": n_body})
 
 
+def vol_vol(n_poses: int = 4, seed: int = 20260104, n_div: int = 4, model: str = "regularized") -> Workload:
+    """Volume-volume (tet-tet) contact, src/contact_algorithms_non_friction.jl:166-194: (a) the test_vol_vol.jl
+    geometry, a compliant box (12 tets) on the compliant half-plane tet, and (b) two compliant spheres
+    (20 n_div^2 tets each, different Ē) overlapping by 5 % of the radius, random relative pose per item."""
+    r = 0.05
+    plane = G.as_tet_emesh(G.emesh_half_plane())
+    box = G.as_tet_emesh(G.emesh_box(r))
+    sph = G.as_tet_emesh(G.emesh_sphere(0.1, n_div))
+    meshes = [_mesh("plane", plane, 1.0e6), _mesh("box", box, 1.0e6), _mesh("sphere_a", sph, 1.0e6),
+              _mesh("sphere_b", sph, 3.0e6)]
+    kw = dict(chi=0.5, mu_d=0.3)
+    ins = [InsSpec(1, 0, model, **kw), InsSpec(2, 3, model, **kw)]
+    ids, pose, twist, s = [], [], [], []
+    for k in range(n_poses):
+        g = _rng(seed, k)
+        # box on plane: body 1 = box, body 2 = plane (world)
+        Rb = rot_z(g.uniform(0, 2 * np.pi)) @ rot_y(np.deg2rad(g.uniform(-2, 2))) @ rot_x(np.deg2rad(g.uniform(-2, 2)))
+        tb = np.array([g.uniform(-0.2, 0.2), g.uniform(-0.2, 0.2), r - g.uniform(0.5e-3, 3e-3)])
+        ang, lin = g.uniform(-1, 1, size=3), g.uniform(-0.1, 0.1, size=3)
+        ids.append(0)
+        pose.append(relative_pose(Rb, tb, np.eye(3), np.zeros(3)))
+        twist.append(relative_twist(np.eye(3), np.zeros(3), np.concatenate([ang, lin - np.cross(ang, tb)]), np.zeros(6)))
+        s.append(g.standard_normal(6) * 1.0e-2)
+        # sphere on sphere
+        Ra, Rs = random_rotation(g), random_rotation(g)
+        u = g.standard_normal(3); u /= np.linalg.norm(u)
+        ta = 0.195 * u
+        ang, lin = g.uniform(-1, 1, size=3), g.uniform(-0.1, 0.1, size=3)
+        ids.append(1)
+        pose.append(relative_pose(Ra, ta, Rs, np.zeros(3)))
+        twist.append(relative_twist(Rs, np.zeros(3), np.concatenate([ang, lin - np.cross(ang, ta)]), np.zeros(6)))
+        s.append(g.standard_normal(6) * 1.0e-2)
+    return Workload("vol-vol (tet-tet)", meshes, ins, np.asarray(ids, dtype=np.int32), np.array(pose), np.array(twist),
+                    np.array(s))
+
+
 # ----------------------------------------------------------------------------------------------------------------
 def build_scenario(w: Workload, device: int = 0, debug: bool = False) -> MechanismScenario:
     """Workload -> finalized MechanismScenario on the HIP device."""

@@ -11,7 +11,7 @@
 //                   LDS ([slot][coord][lane] layout: conflict-free per-lane dynamic indexing), fan quadrature,
 //                   pressure; regularized friction fused; bristle items accumulate the patch moments
 //   k_eig           the bristle model: cop + patch stiffness from the origin moments, 6x6 symmetric eigen solve
-//   k_narrow<1>     bristle friction pass: clip + quadrature recomputed, calc_spatial_bristle_force integrated
+//   k_narrow<1,..>  bristle friction pass: clip + quadrature recomputed, calc_spatial_bristle_force integrated
 //   k_final         per item: wrench, sdot, counts
 #include "pfc_kernels.h"
 
@@ -41,7 +41,8 @@ __global__ void k_prep_tri(int n, const double *__restrict__ pt, const int *__re
 }
 
 __global__ void k_prep_tet(int n, const double *__restrict__ pt, const double *__restrict__ eps,
-                           const int *__restrict__ tet, TetRec *__restrict__ out, unsigned *status) {
+                           const int *__restrict__ tet, TetRec *__restrict__ out, double *__restrict__ out_eps,
+                           unsigned *status) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     double A[16], e[4];
@@ -52,6 +53,7 @@ __global__ void k_prep_tet(int n, const double *__restrict__ pt, const double *_
         A[4 * j] = pt[3 * v]; A[4 * j + 1] = pt[3 * v + 1]; A[4 * j + 2] = pt[3 * v + 2]; A[4 * j + 3] = 1.0;
         r.xrz[3 * j] = A[4 * j]; r.xrz[3 * j + 1] = A[4 * j + 1]; r.xrz[3 * j + 2] = A[4 * j + 2];
         e[j] = eps[v];
+        out_eps[4 * (size_t)k + j] = e[j];
     }
     double id = inv4(A, r.xzr);
     if (!(__builtin_fabs(id) <= 1.79769313486231570815e308)) atomicOr(status, kStNonFinite);
@@ -104,6 +106,7 @@ __global__ void k_setup_items(EvalArgs g) {
     r.chi = in.chi; r.Ebar = m2.Ebar;  // Ē of mesh_2 only: non_friction.jl:131
     r.mu_s = in.mu_s; r.mu_d = in.mu_d; r.v_c = in.v_c; r.tau = in.tau; r.k_bar = in.k_bar; r.magic = in.magic;
     r.nodes1 = m1.nodes; r.nodes2 = m2.nodes; r.tri = m1.tri; r.tet = m2.tet;
+    r.tet1 = m1.tri ? nullptr : m1.tet; r.eps1 = m1.tet_eps; r.eps2 = m2.tet_eps; r.Ebar1 = m1.Ebar;
     r.model = in.model; r.nq = (in.nq == 1) ? 1 : 3;  // quadrature POINTS of rule 1 / rule 2 (quadrature.jl:22,31)
     r.ins = id; r.pad = 0;
     bool finite = true;
@@ -467,7 +470,10 @@ __device__ __forceinline__ void accumulate_items(double *acc, int item, bool lis
 //         points) and calc_spatial_bristle_force (friction.jl:171-201) is integrated.  Recomputing is cheaper than
 //         materialising the TractionCache: 9 scattered 8-byte stores per traction point cost 2.7x the whole
 //         clip + quadrature (measured), and the list is only kept in debug mode (pfc_debug_tractions).
-template <int PASS>
+//
+// TT: the scenario contains tet-tet instructions (non_friction.jl:166-194); compiled out otherwise so that the common
+// tri-tet-only scenario does not pay the registers of the plane / tet intersection.
+template <int PASS, bool TT>
 __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
     __shared__ double poly[8 * 4 * kNpBlock];
     const int lane = threadIdx.x;
@@ -495,18 +501,22 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         V3 nh = mk3(0.0, 0.0, 0.0);
         // ==== phase 1 (divergent): gather, transform to tet coordinates, clip ========================================
         if (work) {
-            const TriRec tr = it->tri[cw.a];
             double R21[9], t21[3];
 #pragma unroll
             for (int k = 0; k < 9; ++k) R21[k] = it->R21[k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) t21[k] = it->t21[k];
-            // x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (non_friction.jl:204); last row of x_r2_r1.mat is (0 0 0 1)
-            double X[16];
-            {
-                double Z[16];
+            double z[4][4];      // input polygon (3 or 4 vertices) in the coordinates of tet 2
+            int n_in = 0;
+            V3 nh_in = mk3(0.0, 0.0, 0.0);
+            double Z[16];        // x_ζ2_r2
 #pragma unroll
-                for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
+            for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
+            if (!TT || it->tet1 == nullptr) {
+                // ---- tri-tet op (non_friction.jl:196-215) -----------------------------------------------------------
+                const TriRec tr = it->tri[cw.a];
+                // x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (:204); last row of x_r2_r1.mat is (0 0 0 1)
+                double X[16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -514,34 +524,132 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
                     X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + Z[i + 12];
                 }
-            }
-            // v_k = x_ζ2_r1 * onePad(vert_k) (:205-207)
-            double z[3][4];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    z[k][i] = ((X[i] * tr.v[3 * k] + X[i + 4] * tr.v[3 * k + 1]) + X[i + 8] * tr.v[3 * k + 2]) + X[i + 12];
-            bool finite = true;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) finite &= (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
-            if (!finite) atomicOr(g.status, kStNonFinite);
-            // Trivial reject: if all three vertices are non-positive on some plane the clip is empty.  Bit-exact
-            // shortcut: every clipped vertex is c1*p2 - c2*p1 with c1 >= 0 >= c2 (static_clip.jl:197-201), whose
-            // sign on that plane is exact, so Sutherland-Hodgman returns the empty polygon at that plane (:44).
-            bool reject = !finite;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0);
-            if (!reject) {
-                STAMP(t1);
-                // ---- clip_in_tet_coordinates (static_clip.jl:17-23,34-201), polygon ring in LDS, clipped in place --
-                int n = 3;
+                // v_k = x_ζ2_r1 * onePad(vert_k) (:205-207)
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) PR(k, i) = z[k][i];
+                    for (int i = 0; i < 4; ++i)
+                        z[k][i] = ((X[i] * tr.v[3 * k] + X[i + 4] * tr.v[3 * k + 1]) + X[i + 8] * tr.v[3 * k + 2]) + X[i + 12];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[3][i] = 0.0;
+                n_in = 3;
+                // n̂2 = R(x_r2_r1) * n̂_r1 (:211-212)
+                nh_in = mk3((R21[0] * tr.n[0] + R21[3] * tr.n[1]) + R21[6] * tr.n[2],
+                            (R21[1] * tr.n[0] + R21[4] * tr.n[1]) + R21[7] * tr.n[2],
+                            (R21[2] * tr.n[0] + R21[5] * tr.n[1]) + R21[8] * tr.n[2]);
+            } else {
+                // ---- tet-tet op (non_friction.jl:166-194) -----------------------------------------------------------
+                const TetRec *t1 = it->tet1 + cw.a;
+                double plane[4];
+                {
+                    // ϵ_plane_r2 = (Ē2 ϵ2) x_ζ2_r2 - (Ē1 ϵ1) (x_ζ1_r1 x_r1_r2)   (find_plane_tet :164, :174-177)
+                    double R12[9], t12[3], Z1[16], X1[16];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) R12[k] = it->R12[k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t12[k] = it->t12[k];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) Z1[k] = t1->xzr[k];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            X1[i + 4 * j] = (Z1[i] * R12[3 * j] + Z1[i + 4] * R12[3 * j + 1]) + Z1[i + 8] * R12[3 * j + 2];
+                        X1[i + 12] = ((Z1[i] * t12[0] + Z1[i + 4] * t12[1]) + Z1[i + 8] * t12[2]) + Z1[i + 12];
+                    }
+                    double Ee1[4], Ee2[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        Ee1[j] = it->Ebar1 * it->eps1[4 * (size_t)cw.a + j];
+                        Ee2[j] = it->Ebar * it->eps2[4 * (size_t)cw.b + j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double p1 = ((Ee1[0] * X1[4 * j] + Ee1[1] * X1[4 * j + 1]) + Ee1[2] * X1[4 * j + 2]) + Ee1[3] * X1[4 * j + 3];
+                        const double p2 = ((Ee2[0] * Z[4 * j] + Ee2[1] * Z[4 * j + 1]) + Ee2[2] * Z[4 * j + 2]) + Ee2[3] * Z[4 * j + 3];
+                        plane[j] = p2 - p1;
+                    }
+                }
+                // x_r2_ζ1 = x_r2_r1.mat * x_r1_ζ1: the vertices of tet 1 in frame r2 (:180); proj = plane * tet (:19)
+                V3 P[4];
+                double proj[4];
+                int n_neg = 0, n_pos = 0;
+                unsigned posm = 0, negm = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double vx = t1->xrz[3 * j], vy = t1->xrz[3 * j + 1], vz = t1->xrz[3 * j + 2];
+                    P[j] = mk3(((R21[0] * vx + R21[3] * vy) + R21[6] * vz) + t21[0],
+                               ((R21[1] * vx + R21[4] * vy) + R21[7] * vz) + t21[1],
+                               ((R21[2] * vx + R21[5] * vy) + R21[8] * vz) + t21[2]);
+                    proj[j] = ((plane[0] * P[j].x + plane[1] * P[j].y) + plane[2] * P[j].z) + plane[3];
+                    if (proj[j] < 0.0) { ++n_neg; negm |= 1u << j; }
+                    if (0.0 < proj[j]) { ++n_pos; posm |= 1u << j; }
+                }
+                // clip_plane_tet (plane_tet_intersection.jl:9-106).  weightPoly(v[i1], v[i2], proj[i1], proj[i2]) does
+                // not depend on the order of (i1, i2) bit for bit, so one edge function serves every case.
+                V3 q[4];
+                q[0] = q[1] = q[2] = q[3] = mk3(0.0, 0.0, 0.0);
+                int n_q = 0;
+#define PW_(i1, i2) (P[i2] * (proj[i1] / (proj[i1] - proj[i2])) - P[i1] * (proj[i2] / (proj[i1] - proj[i2])))
+                if (n_pos != 0 && n_neg != 0) {
+                    int lone = -1;
+                    if (n_pos == 1) lone = __builtin_ctz(posm);
+                    else if (n_neg == 1) lone = __builtin_ctz(negm);
+                    if (lone >= 0) {
+                        V3 a, b, c;   // :52-79
+                        if (lone == 0) { a = PW_(1, 0); b = PW_(3, 0); c = PW_(2, 0); }
+                        else if (lone == 1) { a = PW_(0, 1); b = PW_(2, 1); c = PW_(3, 1); }
+                        else if (lone == 2) { a = PW_(0, 2); b = PW_(3, 2); c = PW_(1, 2); }
+                        else { a = PW_(0, 3); b = PW_(1, 3); c = PW_(2, 3); }
+                        double pl = (lone == 0) ? proj[0] : (lone == 1) ? proj[1] : (lone == 2) ? proj[2] : proj[3];
+                        n_q = 3;
+                        if (0.0 < pl) { q[0] = a; q[1] = b; q[2] = c; } else { q[0] = c; q[1] = b; q[2] = a; }
+                    } else {
+                        V3 a, b, c, d;   // :81-106
+                        const bool p0 = (posm & 1u) != 0, p1 = (posm & 2u) != 0, p2 = (posm & 4u) != 0;
+                        if (p0 == p1) { a = PW_(1, 2); b = PW_(1, 3); c = PW_(0, 3); d = PW_(0, 2); }
+                        else if (p0 == p2) { a = PW_(0, 1); b = PW_(0, 3); c = PW_(2, 3); d = PW_(2, 1); }
+                        else { a = PW_(0, 2); b = PW_(0, 1); c = PW_(3, 1); d = PW_(3, 2); }
+                        n_q = 4;
+                        if (0.0 < proj[0]) { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+                        else { q[0] = d; q[1] = c; q[2] = b; q[3] = a; }
+                    }
+                }
+#undef PW_
+                // poly_ζ2 = one_pad_then_mul(x_ζ2_r2, poly_r2), then zero_small_coordinates (:184-187)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double v = ((Z[i] * q[k].x + Z[i + 4] * q[k].y) + Z[i + 8] * q[k].z) + Z[i + 12];
+                        z[k][i] = v * ((1.0e-14 < __builtin_fabs(v)) ? 1.0 : 0.0);
+                    }
+                n_in = n_q;
+                nh_in = normalize(mk3(plane[0], plane[1], plane[2]));   // :190
+            }
+            bool finite = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) finite &= (k >= n_in) || (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
+            if (!finite) atomicOr(g.status, kStNonFinite);
+            // Trivial reject: if every vertex is non-positive on some plane the clip is empty.  Bit-exact shortcut:
+            // every clipped vertex is c1*p2 - c2*p1 with c1 >= 0 >= c2 (static_clip.jl:197-201), whose sign on that
+            // plane is exact, so Sutherland-Hodgman returns the empty polygon at that plane (:44).
+            bool reject = !finite || n_in < 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0) && (n_in < 4 || z[3][i] <= 0.0);
+            if (!reject) {
+                STAMP(t1);
+                // ---- clip_in_tet_coordinates (static_clip.jl:7-23,34-201), polygon ring in LDS, clipped in place ---
+                int n = n_in;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < n_in) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) PR(k, i) = z[k][i];
+                    }
                 bool err = false;
                 for (int i = 0; i < 4 && n > 0; ++i) {
                     unsigned nonpos = 0, nonneg = 0;
@@ -602,10 +710,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 }
                 if (err) atomicOr(g.status, kStNonFinite);
                 n_poly = n;
-                if (n >= 3)  // n̂2 = R(x_r2_r1) * n̂_r1 (:211-212)
-                    nh = mk3((R21[0] * tr.n[0] + R21[3] * tr.n[1]) + R21[6] * tr.n[2],
-                             (R21[1] * tr.n[0] + R21[4] * tr.n[1]) + R21[7] * tr.n[2],
-                             (R21[2] * tr.n[0] + R21[5] * tr.n[1]) + R21[8] * tr.n[2]);
+                if (n >= 3) nh = nh_in;
             }
         }
         if (PASS == 0 && g.clip_n && active) g.clip_n[idx] = n_poly;
@@ -1206,6 +1311,7 @@ struct HostMesh {
     NodeRec *d_nodes = nullptr;
     TriRec *d_tri = nullptr;
     TetRec *d_tet = nullptr;
+    double *d_tet_eps = nullptr;
 };
 
 enum { EV_START = 0, EV_SETUP, EV_BP, EV_NP, EV_BR, EV_FIN, EV_COUNT };
@@ -1222,7 +1328,7 @@ struct pfc_context {
     MeshDev *d_meshes = nullptr;
     InsDev *d_ins = nullptr;
     int max_levels = 1;
-    bool any_bristle = false;
+    bool any_bristle = false, any_tet_tet = false;
     // options
     int opt_debug = 0, opt_profile = 0, opt_max_levels = 0, opt_bfs_levels = -1;
     // work buffers
@@ -1425,7 +1531,8 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
 #endif
     np.res = h->res.p; np.rec = h->rec.p; np.rcount = rcount; np.rcap = (int)h->rcap;
     const int np_grid = grid_for(h->ccap, kNpBlock, 256 * 16);
-    hipLaunchKernelGGL(k_narrow<0>, dim3(np_grid), dim3(kNpBlock), 0, st, np);
+    if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<0, true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+    else hipLaunchKernelGGL((k_narrow<0, false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_NP], st));
 
     BrArgs br;
@@ -1437,7 +1544,8 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         sh.rec = h->rec.p; sh.rcount = rcount; sh.rcap = (int)h->rcap; sh.acc = h->acc.p;
         hipLaunchKernelGGL(k_shift, dim3(grid_for(h->rcap, 64, 2048)), dim3(64), 0, st, sh);
         hipLaunchKernelGGL(k_eig, dim3(grid_for(n_items, 64, 1 << 20)), dim3(64), 0, st, br);
-        hipLaunchKernelGGL(k_narrow<1>, dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<1, true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        else hipLaunchKernelGGL((k_narrow<1, false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BR], st));
     hipLaunchKernelGGL(k_final, dim3(grid_for(n_items, 128, 1 << 20)), dim3(128), 0, st, br);
@@ -1465,7 +1573,8 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
 #endif
     if (use_graph) {
         pfc_context::GraphKey key = {};
-        key.n_items = n_items; key.levels = levels; key.L = L; key.debug = h->opt_debug; key.bristle = h->any_bristle;
+        key.n_items = n_items; key.levels = levels; key.L = L; key.debug = h->opt_debug;
+        key.bristle = (h->any_bristle ? 1 : 0) | (h->any_tet_tet ? 2 : 0);
         key.p[0] = d_ins_ids; key.p[1] = d_pose; key.p[2] = d_twist; key.p[3] = d_s; key.p[4] = d_wrench;
         key.p[5] = d_sdot; key.p[6] = d_counts; key.stream = (void *)st; key.epoch = h->epoch;
         if (!h->ghave || std::memcmp(&key, &h->gkey, sizeof key) != 0) {
@@ -1560,6 +1669,7 @@ void pfc_destroy(pfc_handle h) {
         if (m.d_nodes) (void)hipFree(m.d_nodes);
         if (m.d_tri) (void)hipFree(m.d_tri);
         if (m.d_tet) (void)hipFree(m.d_tet);
+        if (m.d_tet_eps) (void)hipFree(m.d_tet_eps);
     }
     if (h->d_meshes) (void)hipFree(h->d_meshes);
     if (h->d_ins) (void)hipFree(h->d_ins);
@@ -1652,8 +1762,6 @@ int pfc_add_instruction(pfc_handle h, int id_1, int id_2, double chi, int n_quad
         return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_instruction: bad mesh id");
     if (h->meshes[id_2].n_tet == 0)  // id_2 is always a tet mesh: src/mechanism_scenario.jl:402-416
         return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_instruction: id_2 must be a tet mesh");
-    if (h->meshes[id_1].n_tri == 0)
-        return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_instruction: tet-tet instructions are not implemented in this build (id_1 must be a triangle mesh)");
     if (n_quad < 1 || n_quad > 2)  // src/mechanism_scenario.jl:45
         return -fail(h, PFC_ERR_BAD_ARG, "only quadrature rules 1 and 2 are currently implemented");
     if (model != PFC_REGULARIZED && model != PFC_BRISTLE) return -fail(h, PFC_ERR_BAD_ARG, "unknown friction model");
@@ -1699,14 +1807,15 @@ int pfc_finalize(pfc_handle h) {
             HIP_TRY(h, hipMalloc((void **)&d_eps, sizeof(double) * m.eps.size()));
             HIP_TRY(h, hipMemcpy(d_eps, m.eps.data(), sizeof(double) * m.eps.size(), hipMemcpyHostToDevice));
             HIP_TRY(h, hipMalloc((void **)&m.d_tet, sizeof(TetRec) * m.n_tet));
+            HIP_TRY(h, hipMalloc((void **)&m.d_tet_eps, sizeof(double) * 4 * m.n_tet));
             hipLaunchKernelGGL(k_prep_tet, dim3((m.n_tet + 127) / 128), dim3(128), 0, h->stream, m.n_tet, d_xyz, d_eps, d_idx,
-                               m.d_tet, h->status.p);
+                               m.d_tet, m.d_tet_eps, h->status.p);
         }
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         (void)hipFree(d_xyz); (void)hipFree(d_idx);
         if (d_eps) (void)hipFree(d_eps);
-        md[k].nodes = m.d_nodes; md[k].tri = m.d_tri; md[k].tet = m.d_tet; md[k].Ebar = m.Ebar;
+        md[k].nodes = m.d_nodes; md[k].tri = m.d_tri; md[k].tet = m.d_tet; md[k].tet_eps = m.d_tet_eps; md[k].Ebar = m.Ebar;
         md[k].n_tri = m.n_tri; md[k].n_tet = m.n_tet; md[k].n_node = m.n_node; md[k].depth = m.depth;
     }
     unsigned status = 0;
@@ -1722,6 +1831,7 @@ int pfc_finalize(pfc_handle h) {
         int lv = h->meshes[in.m1].depth + h->meshes[in.m2].depth + 1;
         if (lv > h->max_levels) h->max_levels = lv;
         if (in.model == PFC_BRISTLE) h->any_bristle = true;
+        if (h->meshes[in.m1].n_tri == 0) h->any_tet_tet = true;
     }
     // the depth-first broadphase keeps 3 * levels + 3 stack slots in reserve (k_bp_dfs)
     if (3 * h->max_levels + 3 > kDfsStack - 128)

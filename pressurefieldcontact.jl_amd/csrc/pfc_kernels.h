@@ -57,6 +57,7 @@ struct MeshDev {
     const NodeRec *nodes;
     const TriRec *tri;
     const TetRec *tet;
+    const double *tet_eps;   // 4 per tet: raw ϵ of the tet's vertices (needed by the tet-tet equal-pressure plane)
     double Ebar;
     int n_tri, n_tet, n_node, depth;
 };
@@ -73,8 +74,11 @@ struct alignas(16) ItemRec {  // per (instruction, pose) item: outputs of refres
     double s[6];              // bristle state
     double chi, Ebar, mu_s, mu_d, v_c, tau, k_bar, magic;
     const NodeRec *nodes1, *nodes2;
-    const TriRec *tri;
-    const TetRec *tet;
+    const TriRec *tri;       // mesh_1 triangles, or null for a tet-tet instruction
+    const TetRec *tet;       // mesh_2 tets
+    const TetRec *tet1;      // mesh_1 tets (tet-tet) or null
+    const double *eps1, *eps2;
+    double Ebar1;
     int model, nq, ins, pad;  // nq = number of quadrature points (1 or 3)
 };
 

@@ -133,3 +133,48 @@ def test_no_contact_and_empty(pfc):
                                                    np.zeros(0, dtype=np.int32))
     assert w0.shape == (0, 6)
     m.close()
+
+
+@pytest.mark.parametrize("model", ["regularized", "bristle"])
+def test_tet_tet_vol_vol(pfc, model):
+    """Volume-volume contact (non_friction.jl:166-194): equal-pressure plane, clip_plane_tet, zero_small_coordinates,
+    quad / triangle Sutherland-Hodgman; compliant box on the compliant half-plane (test_vol_vol.jl geometry) and two
+    compliant spheres of different stiffness."""
+    w = pfc.configs.vol_vol(6, n_div=5, model=model)
+    m, wrench, sdot, counts = _eval(pfc, w)
+    ref = H.oracle_run(pfc, w)
+    assert sum(int(r.counts[3] > 0) for r in ref) >= 8
+    for k, r in enumerate(ref):
+        _assert_item_parity(m, k, r, wrench, sdot, counts, 1e-8)
+    t_gpu = m.debug_tractions(1)
+    t_ref = ref[1].trac
+    assert t_gpu.shape == t_ref.shape and t_ref.shape[0] > 0
+    key = lambda t: np.lexsort(tuple(t[:, c] for c in range(7, -1, -1)))
+    assert np.array_equal(t_gpu[key(t_gpu)], t_ref[key(t_ref)]), "traction points are not bit-identical"
+    m.close()
+
+
+def test_mixed_tri_tet_and_tet_tet_instructions(pfc):
+    """One scenario holding tri-tet and tet-tet instructions with both friction models in one evaluation."""
+    G, Cf = pfc.geometry, pfc.configs
+    sph = G.emesh_sphere(0.1, 4)
+    meshes = [Cf.MeshSpec("tet_a", G.as_tet_emesh(sph), G.build_tree(G.as_tet_emesh(sph)), 1.0e6),
+              Cf.MeshSpec("tri_b", G.as_tri_emesh(sph), G.build_tree(G.as_tri_emesh(sph)), None),
+              Cf.MeshSpec("tet_c", G.as_tet_emesh(sph), G.build_tree(G.as_tet_emesh(sph)), 2.0e6)]
+    ins = [Cf.InsSpec(1, 0, "bristle"), Cf.InsSpec(2, 0, "regularized"), Cf.InsSpec(1, 2, "regularized"),
+           Cf.InsSpec(0, 2, "bristle")]
+    rng = np.random.default_rng(8)
+    ids, pose, twist, s = [], [], [], []
+    for k in range(12):
+        R1, R2 = Cf.random_rotation(rng), Cf.random_rotation(rng)
+        u = rng.standard_normal(3); u /= np.linalg.norm(u)
+        ids.append(k % 4)
+        pose.append(pfc.relative_pose(R1, 0.19 * u, R2, np.zeros(3)))
+        twist.append(rng.uniform(-0.5, 0.5, 6))
+        s.append(rng.standard_normal(6) * 1e-2)
+    w = Cf.Workload("mixed", meshes, ins, np.asarray(ids, dtype=np.int32), np.array(pose), np.array(twist), np.array(s))
+    m, wrench, sdot, counts = _eval(pfc, w)
+    ref = H.oracle_run(pfc, w)
+    for k, r in enumerate(ref):
+        _assert_item_parity(m, k, r, wrench, sdot, counts, 1e-8)
+    m.close()
