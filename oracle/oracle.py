@@ -65,6 +65,10 @@ def lib():
         L.pfo_eval.restype = C.c_int
         L.pfo_eval.argtypes = [C.POINTER(_Mesh), C.POINTER(_Mesh), C.POINTER(_Ins), _dp, _dp, _dp, _dp, _dp, _ip,
                                C.POINTER(_Debug)]
+        L.pfo_eval_batch.restype = C.c_int
+        L.pfo_eval_batch.argtypes = [C.c_int, C.POINTER(_Mesh), C.POINTER(_Ins), _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp,
+                                     _ip, C.c_int]
+        L.pfo_max_threads.restype = C.c_int
         L.pfo_calc_clamped_piecewise.restype = C.c_double
         L.pfo_calc_clamped_piecewise.argtypes = [C.c_double] * 5
         L.pfo_traction_regularized.argtypes = [C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp]
@@ -182,3 +186,18 @@ def make_pose(R21, t21) -> np.ndarray:
     R12 = R21.T
     t12 = -(R12 @ t21)
     return np.concatenate([R21.reshape(-1, order="F"), t21, R12.reshape(-1, order="F"), t12])
+
+
+def evaluate_batch(meshes, ins_list, ins_m1, ins_m2, ins_ids, pose, twist, s, n_threads: int = 1):
+    """pfo_eval_batch: all items of a workload, serially (n_threads = 1) or over OpenMP threads.
+    meshes: list of OracleMesh; ins_list: list of _Ins; ins_m1 / ins_m2: mesh ids per instruction."""
+    L = lib()
+    n = int(np.asarray(ins_ids).shape[0])
+    marr = (_Mesh * len(meshes))(*[m.c for m in meshes])
+    iarr = (_Ins * len(ins_list))(*ins_list)
+    m1_a, m1_p = _i(ins_m1); m2_a, m2_p = _i(ins_m2); id_a, id_p = _i(ins_ids)
+    po_a, po_p = _d(pose); tw_a, tw_p = _d(twist); s_a, s_p = _d(s)
+    wrench = np.zeros((n, 6)); sdot = np.zeros((n, 6)); counts = np.zeros((n, 4), dtype=np.int32)
+    st = L.pfo_eval_batch(n, marr, iarr, m1_p, m2_p, id_p, po_p, tw_p, s_p, wrench.ctypes.data_as(_dp),
+                          sdot.ctypes.data_as(_dp), counts.ctypes.data_as(_ip), int(n_threads))
+    return st, wrench, sdot, counts

@@ -901,3 +901,61 @@ int pfo_eval(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const d
     if (own) pfo_debug_free(own);
     return err;
 }
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Batch driver for the CPU baseline: items are independent, so they are spread over host threads   */
+/* with OpenMP when the library is built with -fopenmp (n_threads <= 1: plain serial loop, the reference's own  */
+/* execution model).  meshes: array of pfo_mesh; ins: array of pfo_ins; item k uses ins[ins_ids[k]] whose      */
+/* meshes are (id_1[.], id_2[.]).  Returns the first non-zero status.                                            */
+/* ------------------------------------------------------------------------------------------------------------ */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int pfo_eval_batch(int n_items, const pfo_mesh *meshes, const pfo_ins *ins, const int *ins_m1, const int *ins_m2,
+                   const int *ins_ids, const double *pose, const double *twist, const double *s, double *wrench,
+                   double *sdot, int *counts, int n_threads)
+{
+    int status = 0;
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads)
+    {
+        pfo_debug *d = pfo_debug_new();
+#pragma omp for schedule(dynamic, 4)
+        for (int k = 0; k < n_items; ++k) {
+            int id = ins_ids ? ins_ids[k] : k;
+            int rc = d ? pfo_eval(&meshes[ins_m1[id]], &meshes[ins_m2[id]], &ins[id], pose + 24 * (size_t)k,
+                                  twist + 6 * (size_t)k, s ? s + 6 * (size_t)k : NULL, wrench + 6 * (size_t)k,
+                                  sdot + 6 * (size_t)k, counts ? counts + 4 * (size_t)k : NULL, d)
+                        : PFO_ERR_NOMEM;
+            if (rc) {
+#pragma omp critical
+                if (!status) status = rc;
+            }
+        }
+        pfo_debug_free(d);
+    }
+#else
+    (void)n_threads;
+    pfo_debug *d = pfo_debug_new();
+    if (!d) return PFO_ERR_NOMEM;
+    for (int k = 0; k < n_items; ++k) {
+        int id = ins_ids ? ins_ids[k] : k;
+        int rc = pfo_eval(&meshes[ins_m1[id]], &meshes[ins_m2[id]], &ins[id], pose + 24 * (size_t)k, twist + 6 * (size_t)k,
+                          s ? s + 6 * (size_t)k : NULL, wrench + 6 * (size_t)k, sdot + 6 * (size_t)k,
+                          counts ? counts + 4 * (size_t)k : NULL, d);
+        if (rc && !status) status = rc;
+    }
+    pfo_debug_free(d);
+#endif
+    return status;
+}
+
+int pfo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

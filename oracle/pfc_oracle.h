@@ -77,6 +77,12 @@ void pfo_debug_free(pfo_debug *);
 int pfo_eval(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *twist,
              const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg);
 
+/* Batch driver (CPU baseline): independent items over n_threads OpenMP threads (1 = the reference's serial model). */
+int pfo_eval_batch(int n_items, const pfo_mesh *meshes, const pfo_ins *ins, const int *ins_m1, const int *ins_m2,
+                   const int *ins_ids, const double *pose, const double *twist, const double *s, double *wrench,
+                   double *sdot, int *counts, int n_threads);
+int pfo_max_threads(void);
+
 /* Unit entry points used by the restated reference tests */
 double pfo_calc_clamped_piecewise(double x, double x1, double x2, double y1, double y2);
 void pfo_traction_regularized(double mu_s, double mu_d, double v_c, const double vel_t[3], double p_dA, double out[3]);
