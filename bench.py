@@ -108,6 +108,8 @@ def main():
     m = pfc.configs.build_scenario(w, device=local_rank)
     if args.bfs_levels >= 0:
         m.set_option("bfs_levels", args.bfs_levels)
+    if os.environ.get("PFC_NO_FILTER"):
+        m.set_option("no_filter", int(os.environ["PFC_NO_FILTER"]))     # experiment knob (1: FP64 only, 2: skip R loads - wrong results)
     n = w.n_items
     d_ins = torch.from_numpy(w.ins_ids.astype(np.int32)).to(dev)
     d_pose = torch.from_numpy(np.ascontiguousarray(w.pose)).to(dev)

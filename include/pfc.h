@@ -133,9 +133,10 @@ int pfc_debug_pairs(pfc_handle h, int item, int *pairs, int *clip_n, int cap);
 int pfc_debug_tractions(pfc_handle h, int item, double *buf, int cap);
 int pfc_debug_stiffness(pfc_handle h, int item, double *K36, double *Kbar_inv_sqrt36, double *Sinv6, double *cop3);
 
-/* Diagnostic builds only (-DPFC_STAMPS): cycles the narrowphase waves spent per phase in the last evaluation,
- * out[0..5] = {gather+transform, clip, slot reservation, integration, reductions, wave rounds}; zeros otherwise. */
-int pfc_debug_stamps(pfc_handle h, long long *out8);
+/* Diagnostic builds only (-DPFC_STAMPS): cycles the waves spent per phase in the last evaluation; zeros otherwise.
+ * out[0..5]  narrowphase {gather+transform, clip, slot reservation, integration, reductions, wave rounds}
+ * out[8..12] broadphase  {pop + node loads, SAT, push + flush, iterations, node pairs tested} */
+int pfc_debug_stamps(pfc_handle h, long long *out16);
 
 /* Device arithmetic self-test: out[0..n) = x/y, out[n..2n) = sqrt(|x|), out[2n..3n) = fma(x, y, x) computed on the
  * GPU, so tests can check that device division / sqrt / fma are correctly rounded (bitwise = host). */

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
             const NodeRec b = it->nodes2[w.b];
             hit = bb_bb_intersect(a, b, it->R12, it->t12);
             la = a.leaf != kInternal; lb = b.leaf != kInternal;
-            ca0 = a.child0; ca1 = a.child1; cb0 = b.child0; cb1 = b.child1;
+            ca0 = node_index(a.child0); ca1 = node_index(a.child1); cb0 = node_index(b.child0); cb1 = node_index(b.child1);
             leaf_a = a.leaf; leaf_b = b.leaf;
         }
         count_per_item(g.icnt, w.item, 0, active, active);
@@ -234,6 +234,19 @@ __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
 // atomics per test: a seed's candidates leave in runs of up to kDfsOut records (one atomic per flush), which also
 // keeps the candidate list grouped by item for the reductions downstream.
 // =================================================================================================================
+// In-kernel phase stamps (diagnostic builds only: -DPFC_STAMPS).  s_memtime ticks = shader cycles; the sums go to a
+// buffer of their own that no kernel reads (MI355X guide: 'In-kernel stamps').
+#ifdef PFC_STAMPS
+#define STAMP(t)                                                                 \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+#else
+#define STAMP(t) do { } while (0)
+#endif
+
 constexpr int kDfsStack = 1024;  // node pairs per wave (8 KiB)
 constexpr int kDfsOut = 320;     // staged candidates per wave (2.5 KiB)
 
@@ -249,6 +262,8 @@ struct DfsArgs {
     int *icnt;
     unsigned *status;
     int reserve;         // 3 * (max remaining depth) + 3 slots kept free for the pure depth-first mode
+    unsigned long long *stamps;  // diagnostic builds: [8..12] cycles in pop+load / SAT / push+flush, iterations, lanes
+    int no_filter;       // 1: skip the FP32 filter (every pair runs the Float64 test); for A/B checks
 };
 
 // first 64 bytes of a NodeRec (c, e, links, flags) as four 16-byte loads
@@ -291,10 +306,21 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
         for (int k = 0; k < 3; ++k) t12[k] = it->t12[k];
         const NodeRec *n1 = it->nodes1, *n2 = it->nodes2;
         int sp = 1, n_out = 0, n_test = 0, n_cand = 0;
-        if (lane == 0) stk[0] = make_int2(s.a, s.b);
+        // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
+        if (lane == 0) {
+            const int sa = (n1[s.a].leaf != kInternal) ? ~s.a : s.a;
+            const int sb = (n2[s.b].leaf != kInternal) ? ~s.b : s.b;
+            stk[0] = make_int2(sa, sb);
+        }
         __syncthreads();
+#ifdef PFC_STAMPS
+        unsigned long long c_load = 0, c_sat = 0, c_push = 0, c_iter = 0, c_lanes = 0;
+#endif
         // every wave must reach its exit: the iteration guard stops a corrupt (cyclic) tree from spinning forever
         for (int guard = 0; sp > 0 && guard < (1 << 22); ++guard) {
+            unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+            (void)u0; (void)u1; (void)u2; (void)u3;
+            STAMP(u0);
             // wide mode while there is room for 4 children per popped pair above the depth-first reserve
             int pw = (kDfsStack - g.reserve - sp) / 3;
             int p = sp < 64 ? sp : 64;
@@ -306,39 +332,72 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
             __syncthreads();
             sp -= p;
             n_test += p;
-            bool hit = false, la = false, lb = false;
-            int ca0 = 0, ca1 = 0, cb0 = 0, cb1 = 0, leaf_a = 0, leaf_b = 0;
-            NodeHead a, b;
-            a.aabb = 1; b.aabb = 1;
-            if (act) {
-                a = load_head(n1 + e.x);
-                b = load_head(n2 + e.y);
-            }
+            const bool la = act && e.x < 0, lb = act && e.y < 0;
+            const int ia = node_index(e.x), ib = node_index(e.y);
             // The path is chosen per wave, never per lane: popped pairs sit at similar depths, so a wave is usually
-            // all internal-internal (axis-aligned shortcut, half the flops and 128 instead of 288 bytes per pair) or
-            // reaches the tight-fitted leaves together (general composition; it is exact for identity rotations too).
-            if (__all(!act || ((a.aabb & b.aabb) != 0))) {
-                if (act) hit = bb_bb_intersect_aabb(a.c, a.e, b.c, b.e, R12, aR12, t12);
-            } else if (act) {
+            // all internal-internal (axis-aligned shortcut: R_tot = R_a_b, 128 bytes per pair) or reaches the
+            // tight-fitted leaves together (general composition; exact for identity rotations too).  Leaf-ness comes
+            // with the link, so all loads of the iteration are issued before the first use.
+            const bool general = __any(la || lb);
+            NodeHead a, b;
+            a.leaf = kInternal; b.leaf = kInternal; a.child0 = a.child1 = b.child0 = b.child1 = 0; a.aabb = b.aabb = 1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a.c[k] = a.e[k] = b.c[k] = b.e[k] = 0.0; }
+            double Ra[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0}, Rb[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+            if (act) {
+                a = load_head(n1 + ia);
+                b = load_head(n2 + ib);
+                if (general) {
+                    if (la) {
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) Ra[k] = n1[ia].R[k];
+                    }
+                    if (lb) {
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) Rb[k] = n2[ib].R[k];
+                    }
+                }
+            }
+#ifdef PFC_STAMPS
+            { double keep = a.c[0] + b.c[0] + Ra[4] + Rb[4]; asm volatile("" ::"v"(keep)); }   // the loads have landed
+#endif
+            STAMP(u1);
+            // The Float64 composition gives R_tot and t; the 15 axes are decided by the single-precision filter
+            // (sat15_f32) and only undecided pairs (within ~1e-6 of touching) run the Float64 test.
+            double Rt[9], aRt[9], tt3[3];
+            if (!general) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { Rt[k] = R12[k]; aRt[k] = aR12[k]; }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    tt3[i] = ((R12[i] * b.c[0] + R12[i + 3] * b.c[1]) + R12[i + 6] * b.c[2]) + (t12[i] - a.c[i]);
+            } else {
                 NodeRec fa, fb;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { fa.c[k] = a.c[k]; fa.e[k] = a.e[k]; fb.c[k] = b.c[k]; fb.e[k] = b.e[k]; }
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    fa.R[k] = n1[e.x].R[k];
-                    fb.R[k] = n2[e.y].R[k];
-                }
-                hit = bb_bb_intersect(fa, fb, R12, t12);
+                for (int k = 0; k < 9; ++k) { fa.R[k] = Ra[k]; fb.R[k] = Rb[k]; }
+                bb_compose(fa, fb, R12, t12, Rt, aRt, tt3);
             }
-            if (act) {
-                la = a.leaf != kInternal; lb = b.leaf != kInternal;
-                ca0 = a.child0; ca1 = a.child1; cb0 = b.child0; cb1 = b.child1;
-                leaf_a = a.leaf; leaf_b = b.leaf;
+            bool hit = false;
+            int verdict = 0;
+            if (act) verdict = (g.no_filter & 1) ? 2 : sat15_f32(a.e, b.e, tt3, Rt);
+            hit = verdict == 1;
+            if (verdict == 2) hit = sat15(a.e, b.e, tt3, Rt, aRt);
+#ifdef PFC_STAMPS
+            {
+                const unsigned long long mu = __ballot(verdict == 2);
+                if (lane == 0 && mu && g.stamps) { atomicAdd(&g.stamps[13], (unsigned long long)__builtin_popcountll(mu)); atomicAdd(&g.stamps[14], 1ull); }
+                if (lane == 0 && general && g.stamps) atomicAdd(&g.stamps[15], 1ull);
             }
+#endif
+            const int ca0 = a.child0, ca1 = a.child1, cb0 = b.child0, cb1 = b.child1;   // links (sign = leaf)
+            const int leaf_a = a.leaf, leaf_b = b.leaf;
             const bool is_cand = hit && la && lb;
             const bool two = hit && (la != lb);
             const bool four = hit && !la && !lb;
             const unsigned long long mc = __ballot(is_cand), m2 = __ballot(two), m4 = __ballot(four);
+            STAMP(u2);
             if (is_cand) ob[n_out + prefix_count(mc)] = make_int2(leaf_a, leaf_b);
             n_out += __builtin_popcountll(mc);
             if (two | four) {
@@ -373,7 +432,17 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
                 n_out = 0;
                 __syncthreads();
             }
+#ifdef PFC_STAMPS
+            STAMP(u3);
+            c_load += u1 - u0; c_sat += u2 - u1; c_push += u3 - u2; c_iter += 1; c_lanes += p;
+#endif
         }
+#ifdef PFC_STAMPS
+        if (lane == 0 && g.stamps) {
+            atomicAdd(&g.stamps[8], c_load); atomicAdd(&g.stamps[9], c_sat); atomicAdd(&g.stamps[10], c_push);
+            atomicAdd(&g.stamps[11], c_iter); atomicAdd(&g.stamps[12], c_lanes);
+        }
+#endif
         if (lane == 0) {
             if (sp > 0) atomicOr(g.status, kStAbort);
             atomicAdd(&g.icnt[4 * (size_t)item], n_test);
@@ -409,19 +478,6 @@ struct NpArgs {
     int debug;       // materialise traction points for every item
     unsigned long long *stamps;  // diagnostic builds: [0..5] cycles in gather / clip / reserve / integrate / reduce, rounds
 };
-
-// In-kernel phase stamps (diagnostic builds only: -DPFC_STAMPS).  s_memtime ticks = shader cycles; the sums go to a
-// buffer of their own that no kernel reads (MI355X guide: 'In-kernel stamps').
-#ifdef PFC_STAMPS
-#define STAMP(t)                                                                 \
-    do {                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                       \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); \
-        __builtin_amdgcn_sched_barrier(0);                                       \
-    } while (0)
-#else
-#define STAMP(t) do { } while (0)
-#endif
 
 constexpr int kNpBlock = 64;  // one wave per block: 16 KiB of LDS polygon staging per wave
 
@@ -1330,7 +1386,7 @@ struct pfc_context {
     int max_levels = 1;
     bool any_bristle = false, any_tet_tet = false;
     // options
-    int opt_debug = 0, opt_profile = 0, opt_max_levels = 0, opt_bfs_levels = -1;
+    int opt_debug = 0, opt_profile = 0, opt_max_levels = 0, opt_bfs_levels = -1, opt_no_filter = 0;
     // work buffers
     DevBuf<ItemRec> items;
     DevBuf<WorkRec> frontier[2], cand;
@@ -1425,7 +1481,7 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     if ((e = h->icnt.ensure((size_t)n_items * 4)) != hipSuccess) return e;
     if ((e = h->ctr.ensure((size_t)h->max_levels + 8)) != hipSuccess) return e;
     if ((e = h->status.ensure(4)) != hipSuccess) return e;
-    if ((e = h->stamps.ensure(8)) != hipSuccess) return e;
+    if ((e = h->stamps.ensure(16)) != hipSuccess) return e;
     size_t f = h->fcap ? h->fcap : 1u << 16;
     while (f < (size_t)n_items * 8) f *= 2;
     size_t c = h->ccap ? h->ccap : 1u << 16;
@@ -1486,6 +1542,9 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     int *fcount = h->ctr.p + 4;
     HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(int) * ((size_t)levels + 8), st));
     HIP_TRY(h, hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * 4, st));
+#ifdef PFC_STAMPS
+    HIP_TRY(h, hipMemsetAsync(h->stamps.p, 0, sizeof(unsigned long long) * 16, st));
+#endif
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_START], st));
 
     EvalArgs ea;
@@ -1515,6 +1574,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         d.next_seed = next_seed;
         d.cand = h->cand.p; d.ccount = ccount; d.ccap = (int)h->ccap; d.icnt = h->icnt.p; d.status = h->status.p;
         d.reserve = 3 * levels + 3;
+        d.stamps = h->stamps.p; d.no_filter = h->opt_no_filter;
         double ub = (double)n_items * std::pow(4.0, (double)(L < 15 ? L : 15));
         size_t bound = ub > (double)h->fcap ? h->fcap : (size_t)ub;
         hipLaunchKernelGGL(k_bp_dfs, dim3(grid_for(bound, 1, 256 * 12)), dim3(64), 0, st, d);
@@ -1526,9 +1586,6 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     np.icnt = h->icnt.p; np.clip_n = h->opt_debug ? h->clip_n.p : nullptr; np.trac = trac_view(h);
     np.tcount = tcount; np.tcap = (int)h->tcap; np.status = h->status.p; np.debug = h->opt_debug;
     np.stamps = h->stamps.p;
-#ifdef PFC_STAMPS
-    HIP_TRY(h, hipMemsetAsync(h->stamps.p, 0, sizeof(unsigned long long) * 8, st));
-#endif
     np.res = h->res.p; np.rec = h->rec.p; np.rcount = rcount; np.rcap = (int)h->rcap;
     const int np_grid = grid_for(h->ccap, kNpBlock, 256 * 16);
     if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<0, true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
@@ -1750,6 +1807,13 @@ int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int
     }
     m.depth = tree_depth(m.nodes);
     if (m.depth < 0) return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: the node array is not a tree");
+    // Device encoding: a child link to a LEAF is stored as ~index (negative), so the broadphase knows from the link
+    // alone whether the child needs its rotation R (tight-fitted leaf) and can issue every load of an iteration at once.
+    for (NodeRec &r : m.nodes)
+        if (r.leaf == kInternal) {
+            if (m.nodes[r.child0].leaf != kInternal) r.child0 = ~r.child0;
+            if (m.nodes[r.child1].leaf != kInternal) r.child1 = ~r.child1;
+        }
     h->meshes.push_back(std::move(m));
     return (int)h->meshes.size() - 1;
 }
@@ -1925,6 +1989,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "max_levels")) h->opt_max_levels = (int)value;
     else if (!std::strcmp(name, "bfs_levels")) h->opt_bfs_levels = (int)value;
     else if (!std::strcmp(name, "graph")) h->opt_graph = value != 0;
+    else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave = false; }
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;
 }
@@ -2012,12 +2077,12 @@ int pfc_debug_stiffness(pfc_handle h, int item, double *K36, double *Kis36, doub
     return 1;
 }
 
-int pfc_debug_stamps(pfc_handle h, long long *out8) {
-    if (!h || !out8) return PFC_ERR_BAD_ARG;
+int pfc_debug_stamps(pfc_handle h, long long *out16) {
+    if (!h || !out16) return PFC_ERR_BAD_ARG;
     if (h->pending) { int rc = check_eval(h); if (rc) return rc; }
-    unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long v[16] = {0};
     if (h->stamps.p) HIP_TRY(h, hipMemcpy(v, h->stamps.p, sizeof v, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 8; ++k) out8[k] = (long long)v[k];
+    for (int k = 0; k < 16; ++k) out16[k] = (long long)v[k];
     return PFC_OK;
 }
 

@@ -32,13 +32,15 @@ struct alignas(16) NodeRec {  // OBB{c,e,R} + bin_BB_Tree links: src/obb/box_typ
     // first 64 bytes: everything an axis-aligned (merged / internal) box needs
     double c[3];
     double e[3];
-    int child0, child1;
+    int child0, child1;   // links: index of an internal child, ~index of a leaf child
     int leaf;   // element index or kInternal
     int aabb;   // 1 if R is exactly the identity (all merged/internal boxes: src/obb/util.jl:47-51)
     double R[9];  // column-major; only read when aabb == 0 (tight-fitted leaves)
     double pad;
 };
 static_assert(sizeof(NodeRec) == 144, "NodeRec layout");
+// child links on the device: ~index (negative) marks a LEAF child (encoded at pfc_add_mesh)
+__host__ __device__ inline int node_index(int link) { return link < 0 ? ~link : link; }
 
 struct alignas(16) TriRec {  // triangle_vertices (non_friction.jl:145) + triangleNormal (geometry_kernel.jl:10)
     double v[9];  // v1, v2, v3 in frame r1
@@ -239,6 +241,72 @@ __device__ __forceinline__ bool sat15(const double *ea, const double *eb, const 
     return !sep;
 }
 
+// Single-precision filter in front of sat15().  The reference's predicate is "separated on axis L iff
+// (r_a + r_b) < |T.L|" in Float64.  With d = |T.L| - (r_a + r_b) evaluated in FP32 from inputs rounded to FP32, the
+// absolute error of d is below 16 u S, u = 2^-24, S = |t|_1 + sum e_a + sum e_b (every axis is <= 12 roundings of
+// terms bounded by S, |R| <= 1; the +1e-14 of abs_R is far below u).  So d > E proves separation, d < -E on all 15
+// axes proves overlap, anything else is undecided and goes to the Float64 test: the boolean returned for a node pair
+// is bit for bit the reference's.  t and R come from the Float64 composition, i.e. t is the centre offset of two
+// nearby boxes, so S is of the order of the box sizes and the undecided band is ~1e-6 of the typical margin.
+// FP32 vector ops issue at twice the FP64 rate on CDNA4 and use explicit fma.
+// returns 0 = separated, 1 = overlapping, 2 = undecided
+__device__ __forceinline__ int sat15_f32(const double *ea64, const double *eb64, const double *t64, const double *R64) {
+    float ea[3], eb[3], t[3], R[9], aR[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ea[k] = (float)ea64[k]; eb[k] = (float)eb64[k]; t[k] = (float)t64[k]; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { R[k] = (float)R64[k]; aR[k] = __builtin_fabsf(R[k]); }
+    const float S = ((__builtin_fabsf(t[0]) + __builtin_fabsf(t[1])) + __builtin_fabsf(t[2])) + ((ea[0] + ea[1]) + ea[2]) +
+                    ((eb[0] + eb[1]) + eb[2]);
+    const float E = 9.6e-7f * S;   // 16 * 2^-24 = 9.54e-7
+    bool sep = false, hit = true;
+#define R_(i, j) R[(i) + 3 * (j)]
+#define AR_(i, j) aR[(i) + 3 * (j)]
+#define AXIS_(tl, rsum)                      \
+    do {                                     \
+        const float d_ = (tl) - (rsum);      \
+        sep |= d_ > E;                       \
+        hit &= d_ < -E;                      \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float rb = __builtin_fmaf(AR_(i, 2), eb[2], __builtin_fmaf(AR_(i, 1), eb[1], AR_(i, 0) * eb[0]));
+        AXIS_(__builtin_fabsf(t[i]), ea[i] + rb);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float tl = __builtin_fabsf(__builtin_fmaf(R_(2, j), t[2], __builtin_fmaf(R_(1, j), t[1], R_(0, j) * t[0])));
+        const float ra = __builtin_fmaf(AR_(2, j), ea[2], __builtin_fmaf(AR_(1, j), ea[1], AR_(0, j) * ea[0]));
+        AXIS_(tl, ra + eb[j]);
+    }
+    constexpr int i100[3] = {1, 0, 0}, i221[3] = {2, 2, 1};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float tl = __builtin_fabsf(__builtin_fmaf(t[2], R_(1, j), -(t[1] * R_(2, j))));
+        const float ra = __builtin_fmaf(ea[1], AR_(2, j), ea[2] * AR_(1, j));
+        const float rb = __builtin_fmaf(eb[i100[j]], AR_(0, i221[j]), eb[i221[j]] * AR_(0, i100[j]));
+        AXIS_(tl, ra + rb);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float tl = __builtin_fabsf(__builtin_fmaf(t[0], R_(2, j), -(t[2] * R_(0, j))));
+        const float ra = __builtin_fmaf(ea[0], AR_(2, j), ea[2] * AR_(0, j));
+        const float rb = __builtin_fmaf(eb[i100[j]], AR_(1, i221[j]), eb[i221[j]] * AR_(1, i100[j]));
+        AXIS_(tl, ra + rb);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float tl = __builtin_fabsf(__builtin_fmaf(t[1], R_(0, j), -(t[0] * R_(1, j))));
+        const float ra = __builtin_fmaf(ea[0], AR_(1, j), ea[1] * AR_(0, j));
+        const float rb = __builtin_fmaf(eb[i100[j]], AR_(2, i221[j]), eb[i221[j]] * AR_(2, i100[j]));
+        AXIS_(tl, ra + rb);
+    }
+#undef AXIS_
+#undef R_
+#undef AR_
+    return sep ? 0 : (hit ? 1 : 2);
+}
+
 // BB_BB_intersect(tt, a, b) (:2-12): dh_final = inv(dh_a) * dh_a_b * dh_b, then the 15-axis test.
 __device__ __forceinline__ bool bb_bb_intersect(const NodeRec &a, const NodeRec &b, const double *Rab,
                                                 const double *tab) {
@@ -266,6 +334,30 @@ __device__ __forceinline__ bool bb_bb_intersect(const NodeRec &a, const NodeRec 
         t[i] = ((T[i] * b.c[0] + T[i + 3] * b.c[1]) + T[i + 6] * b.c[2]) + tt[i];
     }
     return sat15(a.e, b.e, t, R, aR);
+}
+
+// The same composition without the test: R_tot, |R_tot| + 1e-14 and t of dh_final (:7-10)
+__device__ __forceinline__ void bb_compose(const NodeRec &a, const NodeRec &b, const double *Rab, const double *tab,
+                                           double *R, double *aR, double *t) {
+    double T[9], tt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double r0 = a.R[3 * i], r1 = a.R[3 * i + 1], r2 = a.R[3 * i + 2];
+        double nt = ((-r0) * a.c[0] + (-r1) * a.c[1]) + (-r2) * a.c[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T[i + 3 * j] = (r0 * Rab[3 * j] + r1 * Rab[3 * j + 1]) + r2 * Rab[3 * j + 2];
+        tt[i] = ((r0 * tab[0] + r1 * tab[1]) + r2 * tab[2]) + nt;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double r = (T[i] * b.R[3 * j] + T[i + 3] * b.R[3 * j + 1]) + T[i + 6] * b.R[3 * j + 2];
+            R[i + 3 * j] = r;
+            aR[i + 3 * j] = __builtin_fabs(r) + 1.0e-14;
+        }
+        t[i] = ((T[i] * b.c[0] + T[i + 3] * b.c[1]) + T[i + 6] * b.c[2]) + tt[i];
+    }
 }
 
 // BB_BB_intersect for two axis-aligned boxes (R_a = R_b = I, every internal node).  The reference still composes the

@@ -8,7 +8,7 @@ w = pfc.configs.c3_blob_tool(n)
 m = pfc.configs.build_scenario(w)
 for _ in range(3):
     m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
-out = (C.c_longlong * 8)()
+out = (C.c_longlong * 16)()
 pfc._lib.lib().pfc_debug_stamps(m._h, out)
 v = [int(x) for x in out]
 names = ["gather", "clip", "reserve", "integrate", "reduce"]
@@ -16,3 +16,10 @@ tot = sum(v[:5])
 print("rounds", v[5], "cycles/round", tot / max(v[5], 1))
 for k, nm in enumerate(names):
     print(f"  {nm:10s} {v[k] / max(v[5], 1):10.0f} cycles/round  {100.0 * v[k] / max(tot, 1):5.1f} %")
+
+it = max(v[11], 1)
+print("broadphase iterations", v[11], "lanes/iteration %.1f" % (v[12] / it))
+for k, nm in ((8, "pop+load"), (9, "SAT"), (10, "push+flush")):
+    print(f"  {nm:10s} {v[k] / it:10.0f} cycles/iteration  {100.0 * v[k] / max(v[8] + v[9] + v[10], 1):5.1f} %")
+print("undecided by the FP32 filter: %d pairs (%.4f %% of tests) in %d iterations (%.2f %%); general-path iterations %.1f %%" % (
+    v[13], 100.0 * v[13] / max(v[12], 1), v[14], 100.0 * v[14] / it, 100.0 * v[15] / it))
