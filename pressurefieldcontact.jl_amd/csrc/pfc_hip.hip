@@ -105,7 +105,7 @@ __global__ void k_setup_items(EvalArgs g) {
     for (int k = 0; k < 6; ++k) r.s[k] = (g.s && in.model == PFC_BRISTLE) ? g.s[6 * (size_t)i + k] : 0.0;
     r.chi = in.chi; r.Ebar = m2.Ebar;  // Ē of mesh_2 only: non_friction.jl:131
     r.mu_s = in.mu_s; r.mu_d = in.mu_d; r.v_c = in.v_c; r.tau = in.tau; r.k_bar = in.k_bar; r.magic = in.magic;
-    r.nodes1 = m1.nodes; r.nodes2 = m2.nodes; r.tri = m1.tri; r.tet = m2.tet;
+    r.nodes1 = m1.nodes; r.nodes2 = m2.nodes; r.nf1 = m1.nodesf; r.nf2 = m2.nodesf; r.tri = m1.tri; r.tet = m2.tet;
     r.tet1 = m1.tri ? nullptr : m1.tet; r.eps1 = m1.tet_eps; r.eps2 = m2.tet_eps; r.Ebar1 = m1.Ebar;
     r.model = in.model; r.nq = (in.nq == 1) ? 1 : 3;  // quadrature POINTS of rule 1 / rule 2 (quadrature.jl:22,31)
     r.ins = id; r.pad = 0;
@@ -263,8 +263,239 @@ struct DfsArgs {
     unsigned *status;
     int reserve;         // 3 * (max remaining depth) + 3 slots kept free for the pure depth-first mode
     unsigned long long *stamps;  // diagnostic builds: [8..12] cycles in pop+load / SAT / push+flush, iterations, lanes
-    int no_filter;       // 1: skip the FP32 filter (every pair runs the Float64 test); for A/B checks
+    int no_filter;       // 1: skip the FP32 filter (every pair runs the Float64 test)
+    int resolver;        // 1: seeds are undecided pairs of k_bp_dfs32 (links already encoded, first test is a re-test)
 };
+
+// one ticket per wave from a device-wide counter: lane 0 takes it, the wave reads it back as a scalar
+__device__ __forceinline__ int next_ticket(int *ctr) {
+    int t = 0;
+    if (lane_id() == 0) t = atomicAdd(ctr, 1);
+    return __builtin_amdgcn_readfirstlane(t);
+}
+
+// =================================================================================================================
+// broadphase main kernel: the same wave-cooperative depth-first descent as k_bp_dfs, in single precision on one
+// 64-byte NodeF line per node.  Measured (in-kernel stamps): the Float64 kernel is latency-bound at 2 waves per SIMD
+// (246 VGPRs, two 144-byte scattered records per lane and iteration), not ALU-bound; the Float32 kernel needs a
+// third of the registers and a third of the cache-line requests, and is exact in the following sense.
+//
+// For a node pair it forms v = R_a_b c_b + (t_a_b - c_a) in Float64 (the centre offset, of the order of the box
+// sizes), everything else in Float32: R_a, R_b from unit quaternions (|err| <= 8 u per entry, u = 2^-24, checked on
+// the host when the quaternion is made), T = R_a' R_a_b, t = R_a' v, R = T R_b, then the 15 axes
+// d = |T.L| - (r_a + r_b).  The error of R is below 72 u, so |d_float - d_reference| < 192 u S with
+// S = |v|_1 + sum e_a + sum e_b (internal-internal pairs carry no quaternion error: 16 u S).  d > E proves
+// separation, d < -E on all 15 axes proves overlap; an undecided pair (~1e-5 of its margin scale) is NOT decided here:
+// it is appended to the `und` list and re-tested, with the whole subtree below it, by the Float64 kernel.  The
+// candidate set and the node-test counts therefore equal the reference's bit for bit (tests/test_gpu_*.py).
+// =================================================================================================================
+struct Dfs32Args {
+    const ItemRec *items;
+    const WorkRec *seeds;
+    const int *n_seed;
+    int *next_seed;
+    int seed_cap;
+    WorkRec *cand;
+    int *ccount;
+    int ccap;
+    WorkRec *und;        // undecided node pairs (links encoded): seeds of the Float64 resolver
+    int *ucount;
+    int ucap;
+    int *icnt;
+    unsigned *status;
+    int reserve;
+};
+
+__device__ __forceinline__ NodeF load_nodef(const NodeF *n) {
+    // four 16-byte loads of one 64-byte line
+    const int4 *p = reinterpret_cast<const int4 *>(n);
+    union { int4 v[4]; NodeF f; } u;
+    u.v[0] = p[0]; u.v[1] = p[1]; u.v[2] = p[2]; u.v[3] = p[3];
+    return u.f;
+}
+
+// one node pair of k_bp_dfs32: returns 0 = separated, 1 = overlapping, 2 = undecided
+__device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, bool any_leaf, const double *R12,
+                                             const float *R12f, const double *t12) {
+    // centre offset in Float64, then everything in Float32
+    float v[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        v[i] = (float)(((R12[i] * b.c[0] + R12[i + 3] * b.c[1]) + R12[i + 6] * b.c[2]) + (t12[i] - a.c[i]));
+    float Ra[9], Rb[9], T[9], R[9], t[3];
+    quat_to_R(a.q, Ra);
+    quat_to_R(b.q, Rb);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float r0 = Ra[3 * i], r1 = Ra[3 * i + 1], r2 = Ra[3 * i + 2];   // row i of R_a' = column i of R_a
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            T[i + 3 * j] = __builtin_fmaf(r2, R12f[3 * j + 2], __builtin_fmaf(r1, R12f[3 * j + 1], r0 * R12f[3 * j]));
+        t[i] = __builtin_fmaf(r2, v[2], __builtin_fmaf(r1, v[1], r0 * v[0]));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            R[i + 3 * j] = __builtin_fmaf(T[i + 6], Rb[3 * j + 2], __builtin_fmaf(T[i + 3], Rb[3 * j + 1], T[i] * Rb[3 * j]));
+    const float S = ((__builtin_fabsf(v[0]) + __builtin_fabsf(v[1])) + __builtin_fabsf(v[2])) +
+                    ((a.e[0] + a.e[1]) + a.e[2]) + ((b.e[0] + b.e[1]) + b.e[2]);
+    const float E = (any_leaf ? 1.15e-5f : 9.6e-7f) * S;   // 192 u, 16 u
+    int verdict = sat15_f32_core(a.e, b.e, t, R, E);
+    if (a.exact_only | b.exact_only) verdict = 2;
+    return verdict;
+}
+
+// One WORKGROUP (4 waves) per seed, one shared LDS stack: a seed of the 2 048-pose C3 batch is ~45 k node tests, i.e.
+// ~700 dependent iterations for a single wave -- that serial chain, not ALU or memory, bounded the one-wave-per-seed
+// version (every variant of its inner loop ran 2.0 ms).  Four waves pop 256 pairs per iteration from the same stack.
+constexpr int kDfsBlock = 256;
+constexpr int kDfsWaves = kDfsBlock / 64;
+constexpr int kDfsStack32 = 4096;   // node pairs per workgroup (32 KiB)
+constexpr int kDfsOut32 = 1280;     // staged candidates per workgroup (10 KiB)
+
+// one ticket per workgroup: thread 0 takes it, LDS broadcast between two barriers
+__device__ __forceinline__ int next_ticket_block(int *ctr, int *slot) {
+    if (threadIdx.x == 0) *slot = atomicAdd(ctr, 1);
+    __syncthreads();
+    const int t = *slot;
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ void flush_candidates(const Dfs32Args &g, const int2 *ob, int n_out, int item, int tid,
+                                                 int *s_base) {
+    // all threads of the workgroup call this (n_out is uniform)
+    if (tid == 0) *s_base = atomicAdd(g.ccount, n_out);
+    __syncthreads();
+    const int base = *s_base;
+    if (base + n_out <= g.ccap) {
+        for (int j = tid; j < n_out; j += kDfsBlock) {
+            WorkRec c;
+            c.item = item; c.a = ob[j].x; c.b = ob[j].y; c.pad = 0;
+            g.cand[base + j] = c;
+        }
+    } else if (tid == 0) {
+        atomicOr(g.status, kStCandOvf);
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kDfsBlock) k_bp_dfs32(Dfs32Args g) {
+    __shared__ int2 stk[kDfsStack32];
+    __shared__ int2 ob[kDfsOut32];
+    __shared__ int s_cnt[kDfsWaves][2];   // per wave: candidates, pushed pairs of the current iteration
+    __shared__ int s_seed, s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int n_seed = *g.n_seed;
+    if (n_seed > g.seed_cap) n_seed = g.seed_cap;
+    // one ticket per workgroup (same loop shape as k_bp_dfs: condition in the for header, no break)
+    for (int sd = next_ticket_block(g.next_seed, &s_seed); sd < n_seed; sd = next_ticket_block(g.next_seed, &s_seed)) {
+        const WorkRec s = g.seeds[sd];
+        const int item = s.item;
+        const ItemRec *it = g.items + item;
+        double R12[9], t12[3];
+        float R12f[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { R12[k] = it->R12[k]; R12f[k] = (float)R12[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t12[k] = it->t12[k];
+        const NodeF *n1 = it->nf1, *n2 = it->nf2;
+        int sp = 1, n_out = 0, n_test = 0, n_cand = 0;
+        if (tid == 0) {
+            // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
+            const int sa = (it->nodes1[s.a].leaf != kInternal) ? ~s.a : s.a;
+            const int sb = (it->nodes2[s.b].leaf != kInternal) ? ~s.b : s.b;
+            stk[0] = make_int2(sa, sb);
+        }
+        __syncthreads();
+        // every workgroup must reach its exit: the iteration guard stops a corrupt (cyclic) tree from spinning forever
+        for (int guard = 0; sp > 0 && guard < (1 << 22); ++guard) {
+            // pop up to 256 pairs, but never more than the stack can take back as children (4 per pair)
+            int pw = (kDfsStack32 - g.reserve - sp) / 3;
+            int p = sp < kDfsBlock ? sp : kDfsBlock;
+            if (pw < 1) pw = 1;
+            if (p > pw) p = pw;
+            const bool act = tid < p;
+            int2 e = make_int2(0, 0);
+            if (act) e = stk[sp - 1 - tid];
+            __syncthreads();
+            sp -= p;
+            n_test += p;
+            const bool la = act && e.x < 0, lb = act && e.y < 0;
+            int verdict = 0, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            if (act) {
+                const NodeF a = load_nodef(n1 + node_index(e.x));
+                const NodeF b = load_nodef(n2 + node_index(e.y));
+                a0 = a.link0; a1 = a.link1; b0 = b.link0; b1 = b.link1;
+                verdict = test_pair_f32(a, b, la || lb, R12, R12f, t12);
+            }
+            const bool hit = verdict == 1;
+            // undecided pairs: to the Float64 resolver (rare: one atomic per wave that has any)
+            {
+                const unsigned long long mu = __ballot(verdict == 2);
+                if (mu) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(g.ucount, __builtin_popcountll(mu));
+                    base = __shfl(base, 0, 64);
+                    if (verdict == 2) {
+                        const int pos = base + prefix_count(mu);
+                        if (pos < g.ucap) {
+                            WorkRec c;
+                            c.item = item; c.a = e.x; c.b = e.y; c.pad = 0;
+                            g.und[pos] = c;
+                        } else {
+                            atomicOr(g.status, kStUndOvf);
+                        }
+                    }
+                }
+            }
+            const bool is_cand = hit && la && lb;
+            const bool two = hit && (la != lb);
+            const bool four = hit && !la && !lb;
+            const unsigned long long mc = __ballot(is_cand), m2 = __ballot(two), m4 = __ballot(four);
+            if (lane == 0) {
+                s_cnt[wave][0] = __builtin_popcountll(mc);
+                s_cnt[wave][1] = 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
+            }
+            __syncthreads();
+            int c_off = 0, p_off = 0, c_tot = 0, p_tot = 0;
+#pragma unroll
+            for (int w = 0; w < kDfsWaves; ++w) {
+                const int c = s_cnt[w][0], q = s_cnt[w][1];
+                if (w < wave) { c_off += c; p_off += q; }
+                c_tot += c; p_tot += q;
+            }
+            if (is_cand) ob[n_out + c_off + prefix_count(mc)] = make_int2(a0, b0);   // leaf: link0 = element index
+            if (two | four) {
+                const int pos = sp + p_off + 2 * prefix_count(m2) + 4 * prefix_count(m4);
+                if (two) {
+                    if (la) {  // leaf_1: descend tree_2 (:97-98)
+                        stk[pos] = make_int2(e.x, b0); stk[pos + 1] = make_int2(e.x, b1);
+                    } else {   // leaf_2: descend tree_1 (:101-103)
+                        stk[pos] = make_int2(a0, e.y); stk[pos + 1] = make_int2(a1, e.y);
+                    }
+                } else {       // (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107)
+                    stk[pos] = make_int2(a0, b0); stk[pos + 1] = make_int2(a1, b0);
+                    stk[pos + 2] = make_int2(a0, b1); stk[pos + 3] = make_int2(a1, b1);
+                }
+            }
+            n_out += c_tot;
+            sp += p_tot;
+            __syncthreads();
+            if (n_out > kDfsOut32 - kDfsBlock || (sp == 0 && n_out > 0)) {
+                flush_candidates(g, ob, n_out, item, tid, &s_base);
+                n_cand += n_out;
+                n_out = 0;
+            }
+        }
+        if (tid == 0) {
+            if (sp > 0) atomicOr(g.status, kStAbort);
+            atomicAdd(&g.icnt[4 * (size_t)item], n_test);
+            if (n_cand) atomicAdd(&g.icnt[4 * (size_t)item + 1], n_cand);
+        }
+    }
+}
 
 // first 64 bytes of a NodeRec (c, e, links, flags) as four 16-byte loads
 struct NodeHead {
@@ -279,13 +510,6 @@ __device__ __forceinline__ NodeHead load_head(const NodeRec *n) {
     h.c[0] = a.x; h.c[1] = a.y; h.c[2] = b.x; h.e[0] = b.y; h.e[1] = c.x; h.e[2] = c.y;
     h.child0 = l.x; h.child1 = l.y; h.leaf = l.z; h.aabb = l.w;
     return h;
-}
-
-// one ticket per wave from a device-wide counter: lane 0 takes it, the wave reads it back as a scalar
-__device__ __forceinline__ int next_ticket(int *ctr) {
-    int t = 0;
-    if (lane_id() == 0) t = atomicAdd(ctr, 1);
-    return __builtin_amdgcn_readfirstlane(t);
 }
 
 __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
@@ -308,10 +532,14 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
         int sp = 1, n_out = 0, n_test = 0, n_cand = 0;
         // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
         if (lane == 0) {
-            const int sa = (n1[s.a].leaf != kInternal) ? ~s.a : s.a;
-            const int sb = (n2[s.b].leaf != kInternal) ? ~s.b : s.b;
+            int sa = s.a, sb = s.b;
+            if (!g.resolver) {
+                sa = (n1[s.a].leaf != kInternal) ? ~s.a : s.a;
+                sb = (n2[s.b].leaf != kInternal) ? ~s.b : s.b;
+            }
             stk[0] = make_int2(sa, sb);
         }
+        if (g.resolver) n_test = -1;   // the seed pair was already counted by k_bp_dfs32
         __syncthreads();
 #ifdef PFC_STAMPS
         unsigned long long c_load = 0, c_sat = 0, c_push = 0, c_iter = 0, c_lanes = 0;
@@ -445,7 +673,7 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
 #endif
         if (lane == 0) {
             if (sp > 0) atomicOr(g.status, kStAbort);
-            atomicAdd(&g.icnt[4 * (size_t)item], n_test);
+            if (n_test) atomicAdd(&g.icnt[4 * (size_t)item], n_test);
             if (n_cand) atomicAdd(&g.icnt[4 * (size_t)item + 1], n_cand);
         }
     }
@@ -1364,7 +1592,9 @@ struct HostMesh {
     std::vector<double> xyz, eps;
     std::vector<int> tri, tet;
     std::vector<NodeRec> nodes;
+    std::vector<NodeF> nodesf;
     NodeRec *d_nodes = nullptr;
+    NodeF *d_nodesf = nullptr;
     TriRec *d_tri = nullptr;
     TetRec *d_tet = nullptr;
     double *d_tet_eps = nullptr;
@@ -1389,7 +1619,7 @@ struct pfc_context {
     int opt_debug = 0, opt_profile = 0, opt_max_levels = 0, opt_bfs_levels = -1, opt_no_filter = 0;
     // work buffers
     DevBuf<ItemRec> items;
-    DevBuf<WorkRec> frontier[2], cand;
+    DevBuf<WorkRec> frontier[2], cand, und;
     DevBuf<int> clip_n, icnt, trac_item;
     DevBuf<double> acc, res, trac_d, rec;   // trac_d: 8 arrays of tcap; rec: moment records of kRecStride doubles
     DevBuf<int> ctr;                   // [0]=ccount [1]=tcount [2..] fcount[levels+2]
@@ -1411,7 +1641,7 @@ struct pfc_context {
     } gkey = {};
     bool ghave = false;
     int opt_graph = 1;
-    size_t fcap = 0, ccap = 0, tcap = 0, rcap = 0;
+    size_t fcap = 0, ccap = 0, tcap = 0, rcap = 0, ucap = 0;
     // host-pointer path staging
     DevBuf<double> h_pose, h_twist, h_s, h_wrench, h_sdot;
     DevBuf<int> h_ins, h_counts;
@@ -1420,6 +1650,7 @@ struct pfc_context {
     bool pending = false;
     hipStream_t last_stream = nullptr;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long last_undecided = 0;      // node pairs the Float32 broadphase left to the Float64 resolver
     long long last_tslots = 0;         // traction slots used by the last evaluation (>= traction points)
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
@@ -1479,7 +1710,7 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     if ((e = h->acc.ensure((size_t)n_items * kAccStride)) != hipSuccess) return e;
     if ((e = h->res.ensure((size_t)n_items * kResStride)) != hipSuccess) return e;
     if ((e = h->icnt.ensure((size_t)n_items * 4)) != hipSuccess) return e;
-    if ((e = h->ctr.ensure((size_t)h->max_levels + 8)) != hipSuccess) return e;
+    if ((e = h->ctr.ensure((size_t)h->max_levels + 12)) != hipSuccess) return e;
     if ((e = h->status.ensure(4)) != hipSuccess) return e;
     if ((e = h->stamps.ensure(16)) != hipSuccess) return e;
     size_t f = h->fcap ? h->fcap : 1u << 16;
@@ -1489,7 +1720,9 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     size_t t = h->tcap ? h->tcap : 1u << 16;
     size_t rc = h->rcap ? h->rcap : 1u << 12;
     while (rc < c / 32 + (size_t)n_items * 2) rc *= 2;   // about one record per wave round and item boundary
-    h->fcap = f; h->ccap = c; h->tcap = t; h->rcap = rc;
+    size_t uc = h->ucap ? h->ucap : 1u << 14;
+    h->fcap = f; h->ccap = c; h->tcap = t; h->rcap = rc; h->ucap = uc;
+    if ((e = h->und.ensure(uc)) != hipSuccess) return e;
     if ((e = h->rec.ensure(rc * kRecStride)) != hipSuccess) return e;
     if ((e = h->frontier[0].ensure(f)) != hipSuccess) return e;
     if ((e = h->frontier[1].ensure(f)) != hipSuccess) return e;
@@ -1497,16 +1730,16 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     if ((e = h->clip_n.ensure(c)) != hipSuccess) return e;
     if ((e = h->trac_item.ensure(t)) != hipSuccess) return e;
     if ((e = h->trac_d.ensure(t * 8)) != hipSuccess) return e;
-    if ((e = h->tail.ensure((size_t)h->max_levels + 32)) != hipSuccess) return e;
-    if (h->h_tail_cap < (size_t)h->max_levels + 32) {
+    if ((e = h->tail.ensure((size_t)h->max_levels + 40)) != hipSuccess) return e;
+    if (h->h_tail_cap < (size_t)h->max_levels + 40) {
         if (h->h_tail) (void)hipHostFree(h->h_tail);
         h->h_tail = nullptr; h->h_tail_cap = 0;
-        if ((e = hipHostMalloc((void **)&h->h_tail, sizeof(int) * ((size_t)h->max_levels + 32))) != hipSuccess) return e;
-        h->h_tail_cap = (size_t)h->max_levels + 32;
+        if ((e = hipHostMalloc((void **)&h->h_tail, sizeof(int) * ((size_t)h->max_levels + 40))) != hipSuccess) return e;
+        h->h_tail_cap = (size_t)h->max_levels + 40;
     }
     const size_t caps1[] = {h->items.cap, h->acc.cap, h->res.cap, h->icnt.cap, h->ctr.cap, h->frontier[0].cap,
                             h->frontier[1].cap, h->cand.cap, h->clip_n.cap, h->trac_item.cap, h->trac_d.cap, h->rec.cap,
-                            h->tail.cap};
+                            h->tail.cap, h->und.cap};
     for (size_t k = 0; k < sizeof caps0 / sizeof caps0[0]; ++k)
         if (caps0[k] != caps1[k]) { ++h->epoch; break; }
     return hipSuccess;
@@ -1539,8 +1772,8 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
                 const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st, bool prof) {
     const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
     int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2, *rcount = h->ctr.p + 3;
-    int *fcount = h->ctr.p + 4;
-    HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(int) * ((size_t)levels + 8), st));
+    int *ucount = h->ctr.p + 4, *next_seed2 = h->ctr.p + 5, *fcount = h->ctr.p + 6;
+    HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(int) * ((size_t)levels + 12), st));
     HIP_TRY(h, hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * 4, st));
 #ifdef PFC_STAMPS
     HIP_TRY(h, hipMemsetAsync(h->stamps.p, 0, sizeof(unsigned long long) * 16, st));
@@ -1569,15 +1802,28 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         hipLaunchKernelGGL(k_bp_expand, dim3(grid_for(bound, 256, 2048)), dim3(256), 0, st, b);
     }
     {
-        DfsArgs d;
-        d.items = h->items.p; d.seeds = h->frontier[L & 1].p; d.n_seed = fcount + L; d.seed_cap = (int)h->fcap;
-        d.next_seed = next_seed;
-        d.cand = h->cand.p; d.ccount = ccount; d.ccap = (int)h->ccap; d.icnt = h->icnt.p; d.status = h->status.p;
-        d.reserve = 3 * levels + 3;
-        d.stamps = h->stamps.p; d.no_filter = h->opt_no_filter;
         double ub = (double)n_items * std::pow(4.0, (double)(L < 15 ? L : 15));
         size_t bound = ub > (double)h->fcap ? h->fcap : (size_t)ub;
-        hipLaunchKernelGGL(k_bp_dfs, dim3(grid_for(bound, 1, 256 * 12)), dim3(64), 0, st, d);
+        DfsArgs d;
+        d.items = h->items.p; d.cand = h->cand.p; d.ccount = ccount; d.ccap = (int)h->ccap; d.icnt = h->icnt.p;
+        d.status = h->status.p; d.reserve = 3 * levels + 3; d.stamps = h->stamps.p;
+        if (h->opt_no_filter) {
+            // Float64-only traversal (A/B checks)
+            d.seeds = h->frontier[L & 1].p; d.n_seed = fcount + L; d.seed_cap = (int)h->fcap; d.next_seed = next_seed;
+            d.no_filter = 1; d.resolver = 0;
+            hipLaunchKernelGGL(k_bp_dfs, dim3(grid_for(bound, 1, 256 * 8)), dim3(64), 0, st, d);
+        } else {
+            Dfs32Args f;
+            f.items = h->items.p; f.seeds = h->frontier[L & 1].p; f.n_seed = fcount + L; f.next_seed = next_seed;
+            f.seed_cap = (int)h->fcap; f.cand = h->cand.p; f.ccount = ccount; f.ccap = (int)h->ccap;
+            f.und = h->und.p; f.ucount = ucount; f.ucap = (int)h->ucap; f.icnt = h->icnt.p; f.status = h->status.p;
+            f.reserve = 3 * levels + 3;
+            hipLaunchKernelGGL(k_bp_dfs32, dim3(grid_for(bound, 1, 256 * 6)), dim3(kDfsBlock), 0, st, f);
+            // the undecided pairs and everything below them: exact Float64 traversal
+            d.seeds = h->und.p; d.n_seed = ucount; d.seed_cap = (int)h->ucap; d.next_seed = next_seed2;
+            d.no_filter = 1; d.resolver = 1;
+            hipLaunchKernelGGL(k_bp_dfs, dim3(grid_for(h->ucap, 1, 256 * 8)), dim3(64), 0, st, d);
+        }
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));
 
@@ -1607,7 +1853,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BR], st));
     hipLaunchKernelGGL(k_final, dim3(grid_for(n_items, 128, 1 << 20)), dim3(128), 0, st, br);
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_FIN], st));
-    hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, st, n_items, h->icnt.p, h->ctr.p, levels + 8, h->status.p, h->tail.p);
+    hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, st, n_items, h->icnt.p, h->ctr.p, levels + 12, h->status.p, h->tail.p);
     HIP_TRY(h, hipGetLastError());
     return PFC_OK;
 }
@@ -1663,7 +1909,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
 int check_eval(pfc_context *h) {
     if (!h->pending) return PFC_OK;
     const int levels = h->last_levels;
-    const size_t n_tail = (size_t)levels + 8 + 12;
+    const size_t n_tail = (size_t)levels + 12 + 12;
     HIP_TRY(h, hipMemcpyAsync(h->h_tail, h->tail.p, sizeof(int) * n_tail, hipMemcpyDeviceToHost, h->last_stream));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     h->pending = false;
@@ -1674,18 +1920,20 @@ int check_eval(pfc_context *h) {
     long long fpeak = 0;
     int used_levels = 0;
     for (int lv = 0; lv <= h->last_bfs_levels && lv <= levels; ++lv) {
-        if (ctr[4 + lv] > fpeak) fpeak = ctr[4 + lv];
-        if (ctr[4 + lv] > 0) used_levels = lv + 1;
+        if (ctr[6 + lv] > fpeak) fpeak = ctr[6 + lv];
+        if (ctr[6 + lv] > 0) used_levels = lv + 1;
     }
     h->stats[1] = ctr[0]; h->last_tslots = ctr[1]; h->stats[4] = used_levels; h->stats[5] = fpeak;
     h->stats[6] = status; h->stats[7] = h->last_n_items;
     if (status & kStBadIns) return fail(h, PFC_ERR_BAD_ARG, "instruction id out of range in ins_ids");
-    if (status & (kStFrontierOvf | kStCandOvf | kStTracOvf | kStRecOvf)) {
+    h->last_undecided = ctr[4];
+    if (status & (kStFrontierOvf | kStCandOvf | kStTracOvf | kStRecOvf | kStUndOvf)) {
         // VectorCache-style growth (src/obb/vector_cache.jl:13-17): at least double, at least the observed need
         if (status & kStFrontierOvf) { size_t f = h->fcap * 2; while (f < (size_t)fpeak) f *= 2; h->fcap = f; }
         if (status & kStCandOvf) { size_t c = h->ccap * 2; while (c < (size_t)ctr[0]) c *= 2; h->ccap = c; }
         if (status & kStTracOvf) { size_t t = h->tcap * 2; while (t < (size_t)ctr[1]) t *= 2; h->tcap = t; }
         if (status & kStRecOvf) { size_t r = h->rcap * 2; while (r < (size_t)ctr[3]) r *= 2; h->rcap = r; }
+        if (status & kStUndOvf) { size_t u = h->ucap * 2; while (u < (size_t)ctr[4]) u *= 2; h->ucap = u; }
         return fail(h, PFC_ERR_OVERFLOW, "work list overflow (status %u): capacities grown to frontier %zu, candidates %zu, tractions %zu, records %zu",
                     status, h->fcap, h->ccap, h->tcap, h->rcap);
     }
@@ -1724,6 +1972,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &m : h->meshes) {
         if (m.d_nodes) (void)hipFree(m.d_nodes);
+        if (m.d_nodesf) (void)hipFree(m.d_nodesf);
         if (m.d_tri) (void)hipFree(m.d_tri);
         if (m.d_tet) (void)hipFree(m.d_tet);
         if (m.d_tet_eps) (void)hipFree(m.d_tet_eps);
@@ -1732,7 +1981,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->d_ins) (void)hipFree(h->d_ins);
     h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
     h->clip_n.release(); h->icnt.release(); h->trac_item.release(); h->acc.release(); h->res.release();
-    h->trac_d.release(); h->rec.release(); h->ctr.release(); h->status.release(); h->stamps.release();
+    h->trac_d.release(); h->rec.release(); h->und.release(); h->ctr.release(); h->status.release(); h->stamps.release();
     h->h_pose.release(); h->h_twist.release(); h->h_s.release(); h->h_wrench.release(); h->h_sdot.release();
     h->h_ins.release(); h->h_counts.release();
     for (int k = 0; k < EV_COUNT; ++k)
@@ -1814,6 +2063,45 @@ int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int
             if (m.nodes[r.child0].leaf != kInternal) r.child0 = ~r.child0;
             if (m.nodes[r.child1].leaf != kInternal) r.child1 = ~r.child1;
         }
+    // single-precision mirror (k_bp_dfs32): Float64 centre, Float32 extents, rotation as a unit quaternion
+    m.nodesf.resize(n_node);
+    for (int k = 0; k < n_node; ++k) {
+        const NodeRec &r = m.nodes[k];
+        NodeF f;
+        std::memset(&f, 0, sizeof f);
+        for (int j = 0; j < 3; ++j) { f.c[j] = r.c[j]; f.e[j] = (float)r.e[j]; }
+        const double *R = r.R;   // column-major: R(i,j) = R[i + 3 j]
+        double q[4];
+        const double tr = R[0] + R[4] + R[8];
+        if (tr > 0.0) {
+            const double sq = std::sqrt(tr + 1.0) * 2.0;
+            q[0] = 0.25 * sq; q[1] = (R[5] - R[7]) / sq; q[2] = (R[6] - R[2]) / sq; q[3] = (R[1] - R[3]) / sq;
+        } else if (R[0] > R[4] && R[0] > R[8]) {
+            const double sq = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2.0;
+            q[0] = (R[5] - R[7]) / sq; q[1] = 0.25 * sq; q[2] = (R[3] + R[1]) / sq; q[3] = (R[6] + R[2]) / sq;
+        } else if (R[4] > R[8]) {
+            const double sq = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2.0;
+            q[0] = (R[6] - R[2]) / sq; q[1] = (R[3] + R[1]) / sq; q[2] = 0.25 * sq; q[3] = (R[7] + R[5]) / sq;
+        } else {
+            const double sq = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2.0;
+            q[0] = (R[1] - R[3]) / sq; q[1] = (R[6] + R[2]) / sq; q[2] = (R[7] + R[5]) / sq; q[3] = 0.25 * sq;
+        }
+        const double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        for (int j = 0; j < 4; ++j) f.q[j] = (float)(q[j] / qn);
+        // host check of the bound the device relies on: the Float32 quaternion must reproduce R to 8 u per entry
+        {
+            const double w = f.q[0], x = f.q[1], y = f.q[2], z = f.q[3];
+            const double Rq[9] = {1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w),
+                                  2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w),
+                                  2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)};
+            double worst = 0.0;
+            for (int j = 0; j < 9; ++j) worst = std::fmax(worst, std::fabs(Rq[j] - R[j]));
+            f.exact_only = (std::isfinite(qn) && worst <= 4.0 * 5.9604644775390625e-8) ? 0 : 1;
+        }
+        if (r.leaf == kInternal) { f.link0 = r.child0; f.link1 = r.child1; }
+        else { f.link0 = r.leaf; f.link1 = -1; }
+        m.nodesf[k] = f;
+    }
     h->meshes.push_back(std::move(m));
     return (int)h->meshes.size() - 1;
 }
@@ -1858,6 +2146,8 @@ int pfc_finalize(pfc_handle h) {
         int *d_idx = nullptr;
         HIP_TRY(h, hipMalloc((void **)&m.d_nodes, sizeof(NodeRec) * m.nodes.size()));
         HIP_TRY(h, hipMemcpy(m.d_nodes, m.nodes.data(), sizeof(NodeRec) * m.nodes.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMalloc((void **)&m.d_nodesf, sizeof(NodeF) * m.nodesf.size()));
+        HIP_TRY(h, hipMemcpy(m.d_nodesf, m.nodesf.data(), sizeof(NodeF) * m.nodesf.size(), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMalloc((void **)&d_xyz, sizeof(double) * m.xyz.size()));
         HIP_TRY(h, hipMemcpy(d_xyz, m.xyz.data(), sizeof(double) * m.xyz.size(), hipMemcpyHostToDevice));
         if (m.n_tri) {
@@ -1879,7 +2169,7 @@ int pfc_finalize(pfc_handle h) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         (void)hipFree(d_xyz); (void)hipFree(d_idx);
         if (d_eps) (void)hipFree(d_eps);
-        md[k].nodes = m.d_nodes; md[k].tri = m.d_tri; md[k].tet = m.d_tet; md[k].tet_eps = m.d_tet_eps; md[k].Ebar = m.Ebar;
+        md[k].nodes = m.d_nodes; md[k].nodesf = m.d_nodesf; md[k].tri = m.d_tri; md[k].tet = m.d_tet; md[k].tet_eps = m.d_tet_eps; md[k].Ebar = m.Ebar;
         md[k].n_tri = m.n_tri; md[k].n_tet = m.n_tet; md[k].n_node = m.n_node; md[k].depth = m.depth;
     }
     unsigned status = 0;
@@ -1898,7 +2188,7 @@ int pfc_finalize(pfc_handle h) {
         if (h->meshes[in.m1].n_tri == 0) h->any_tet_tet = true;
     }
     // the depth-first broadphase keeps 3 * levels + 3 stack slots in reserve (k_bp_dfs)
-    if (3 * h->max_levels + 3 > kDfsStack - 128)
+    if (3 * h->max_levels + 3 > kDfsStack - 128 || 3 * h->max_levels + 3 > kDfsStack32 - 1024)
         return fail(h, PFC_ERR_BAD_ARG, "OBB trees too deep (depth sum %d): rebuild them balanced", h->max_levels - 1);
     if (!h->ins.empty()) {
         HIP_TRY(h, hipMalloc((void **)&h->d_ins, sizeof(InsDev) * h->ins.size()));
@@ -2083,6 +2373,7 @@ int pfc_debug_stamps(pfc_handle h, long long *out16) {
     unsigned long long v[16] = {0};
     if (h->stamps.p) HIP_TRY(h, hipMemcpy(v, h->stamps.p, sizeof v, hipMemcpyDeviceToHost));
     for (int k = 0; k < 16; ++k) out16[k] = (long long)v[k];
+    out16[7] = h->last_undecided;
     return PFC_OK;
 }
 

@@ -21,6 +21,7 @@ enum : unsigned {
     kStBadIns = 16u,
     kStAbort = 32u,
     kStRecOvf = 64u,
+    kStUndOvf = 128u,
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -42,6 +43,18 @@ static_assert(sizeof(NodeRec) == 144, "NodeRec layout");
 // child links on the device: ~index (negative) marks a LEAF child (encoded at pfc_add_mesh)
 __host__ __device__ inline int node_index(int link) { return link < 0 ? ~link : link; }
 
+// One cache line per node for the single-precision broadphase: Float64 centre (the centre offset of two boxes is
+// formed in Float64), Float32 extents, the box rotation as a unit quaternion (identity for every merged box) and
+// the links.  For a leaf link0 is the element index.
+struct alignas(16) NodeF {
+    double c[3];
+    float e[3];
+    float q[4];        // w, x, y, z
+    int link0, link1;  // children (index, or ~index for a leaf child); leaf: link0 = element index
+    int exact_only;    // 1: the quaternion does not reproduce R to 8 u (improper / non-orthonormal R): always Float64
+};
+static_assert(sizeof(NodeF) == 64, "NodeF layout");
+
 struct alignas(16) TriRec {  // triangle_vertices (non_friction.jl:145) + triangleNormal (geometry_kernel.jl:10)
     double v[9];  // v1, v2, v3 in frame r1
     double n[3];  // unit normal in frame r1
@@ -57,6 +70,7 @@ static_assert(sizeof(TetRec) == 256, "TetRec layout");
 
 struct MeshDev {
     const NodeRec *nodes;
+    const NodeF *nodesf;
     const TriRec *tri;
     const TetRec *tet;
     const double *tet_eps;   // 4 per tet: raw ϵ of the tet's vertices (needed by the tet-tet equal-pressure plane)
@@ -76,6 +90,7 @@ struct alignas(16) ItemRec {  // per (instruction, pose) item: outputs of refres
     double s[6];              // bristle state
     double chi, Ebar, mu_s, mu_d, v_c, tau, k_bar, magic;
     const NodeRec *nodes1, *nodes2;
+    const NodeF *nf1, *nf2;
     const TriRec *tri;       // mesh_1 triangles, or null for a tet-tet instruction
     const TetRec *tet;       // mesh_2 tets
     const TetRec *tet1;      // mesh_1 tets (tet-tet) or null
@@ -305,6 +320,71 @@ __device__ __forceinline__ int sat15_f32(const double *ea64, const double *eb64,
 #undef R_
 #undef AR_
     return sep ? 0 : (hit ? 1 : 2);
+}
+
+// The 15 axes on Float32 inputs with a caller-supplied error radius E (see k_bp_dfs32).
+// returns 0 = separated, 1 = overlapping, 2 = undecided
+__device__ __forceinline__ int sat15_f32_core(const float *ea, const float *eb, const float *t, const float *R, float E) {
+    float aR[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aR[k] = __builtin_fabsf(R[k]);
+    bool sep = false, hit = true;
+#define R_(i, j) R[(i) + 3 * (j)]
+#define AR_(i, j) aR[(i) + 3 * (j)]
+#define AXIS_(tl, rsum)                      \
+    do {                                     \
+        const float d_ = (tl) - (rsum);      \
+        sep |= d_ > E;                       \
+        hit &= d_ < -E;                      \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float rb = __builtin_fmaf(AR_(i, 2), eb[2], __builtin_fmaf(AR_(i, 1), eb[1], AR_(i, 0) * eb[0]));
+        AXIS_(__builtin_fabsf(t[i]), ea[i] + rb);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float tl = __builtin_fabsf(__builtin_fmaf(R_(2, j), t[2], __builtin_fmaf(R_(1, j), t[1], R_(0, j) * t[0])));
+        const float ra = __builtin_fmaf(AR_(2, j), ea[2], __builtin_fmaf(AR_(1, j), ea[1], AR_(0, j) * ea[0]));
+        AXIS_(tl, ra + eb[j]);
+    }
+    constexpr int i100[3] = {1, 0, 0}, i221[3] = {2, 2, 1};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float tl = __builtin_fabsf(__builtin_fmaf(t[2], R_(1, j), -(t[1] * R_(2, j))));
+        const float ra = __builtin_fmaf(ea[1], AR_(2, j), ea[2] * AR_(1, j));
+        const float rb = __builtin_fmaf(eb[i100[j]], AR_(0, i221[j]), eb[i221[j]] * AR_(0, i100[j]));
+        AXIS_(tl, ra + rb);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float tl = __builtin_fabsf(__builtin_fmaf(t[0], R_(2, j), -(t[2] * R_(0, j))));
+        const float ra = __builtin_fmaf(ea[0], AR_(2, j), ea[2] * AR_(0, j));
+        const float rb = __builtin_fmaf(eb[i100[j]], AR_(1, i221[j]), eb[i221[j]] * AR_(1, i100[j]));
+        AXIS_(tl, ra + rb);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float tl = __builtin_fabsf(__builtin_fmaf(t[1], R_(0, j), -(t[0] * R_(1, j))));
+        const float ra = __builtin_fmaf(ea[0], AR_(1, j), ea[1] * AR_(0, j));
+        const float rb = __builtin_fmaf(eb[i100[j]], AR_(2, i221[j]), eb[i221[j]] * AR_(2, i100[j]));
+        AXIS_(tl, ra + rb);
+    }
+#undef AXIS_
+#undef R_
+#undef AR_
+    return sep ? 0 : (hit ? 1 : 2);
+}
+
+// rotation matrix (column-major 3x3) of a unit quaternion, Float32
+__device__ __forceinline__ void quat_to_R(const float *q, float *R) {
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float x2 = x + x, y2 = y + y, z2 = z + z;
+    const float xx = x * x2, yy = y * y2, zz = z * z2, xy = x * y2, xz = x * z2, yz = y * z2;
+    const float wx = w * x2, wy = w * y2, wz = w * z2;
+    R[0] = 1.0f - (yy + zz); R[3] = xy - wz; R[6] = xz + wy;
+    R[1] = xy + wz; R[4] = 1.0f - (xx + zz); R[7] = yz - wx;
+    R[2] = xz - wy; R[5] = yz + wx; R[8] = 1.0f - (xx + yy);
 }
 
 // BB_BB_intersect(tt, a, b) (:2-12): dh_final = inv(dh_a) * dh_a_b * dh_b, then the 15-axis test.
