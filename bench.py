@@ -171,25 +171,26 @@ def main():
         # SURVEY §8(d) accounting: algorithmic bytes / kernel time against the HBM peak.  Both kernels re-read their
         # 96..256-byte records from L2 / Infinity Cache across the poses of a batch, so "achieved" can exceed what HBM
         # could deliver while the PMC traffic stays tiny: the kernels are Float64-issue / latency bound (see "valu").
-        roof_np = {"kernel": "k_narrow<0>", "bound": "hbm", "achieved": BYTES_PER_OP * st["candidates"] / (np_ms * 1e-3) / 1e9,
+        roof_np = {"kernel": "k_narrow<0,false>", "bound": "hbm", "achieved": BYTES_PER_OP * st["candidates"] / (np_ms * 1e-3) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms_per_launch": np_ms,
                    "units_per_launch": st["candidates"], "bytes_per_unit": BYTES_PER_OP}
-        roof_bp = {"kernel": "k_bp_dfs (+ the few k_bp_expand seed levels)", "bound": "hbm",
+        roof_bp = {"kernel": "k_bp_dfs32 (+ k_bp_expand seed levels, + k_bp_dfs Float64 resolver)", "bound": "hbm",
                    "achieved": BYTES_PER_NODE_TEST * st["node_tests"] / (bp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "traffic": None, "ms_per_launch": bp_ms,
                    "units_per_launch": st["node_tests"], "bytes_per_unit": BYTES_PER_NODE_TEST}
         for r in (roof_np, roof_bp):
             r["frac"] = r["achieved"] / r["peak"]
-        # Float64 vector-ALU view of the broadphase: one 15-axis OBB test is ~170 flops on the axis-aligned path and
-        # ~330 on the general path (counted from the source); 250 is used as the mean
-        roof_bp["valu"] = {"flop_per_unit": 250, "achieved_tflops": 250.0 * st["node_tests"] / (bp_ms * 1e-3) / 1e12,
-                           "peak_tflops_fp64_vector": 78.6}
+        # vector-ALU view of the broadphase: one node test is ~440 single-precision vector instructions per wave of 64
+        # pairs (SQ_INSTS_VALU / iterations, profiles/), i.e. the kernel is instruction-issue bound
+        roof_bp["valu"] = {"valu_instructions_per_wave_iteration": 440,
+                           "issue_bound_ms": 440.0 * (st["node_tests"] / 64.0) * 2.0 / (1024 * 2.1e9) * 1e3,
+                           "note": "1024 SIMDs, 2 cycles per wave64 FP32 instruction at >= 2 waves per SIMD, 2.1 GHz"}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # measured offline with rocprofv3 --pmc
         if os.path.exists(pmc):
             try:
                 tj = json.load(open(pmc))
                 roof_np["traffic"] = tj.get("k_narrow0_bytes_per_launch")
-                roof_bp["traffic"] = tj.get("k_bp_dfs_bytes_per_launch")
+                roof_bp["traffic"] = tj.get("k_bp_dfs32_bytes_per_launch")
                 roof_np["traffic_note"] = roof_bp["traffic_note"] = tj.get("note")
             except Exception:
                 pass
