@@ -108,6 +108,23 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
                     const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, void *stream);
 int pfc_check(pfc_handle h);
 
+/*
+ * addGeneralizedForcesThirdLaw! for every item (src/contact_algorithms_non_friction.jl:267-286): the item's wrench is
+ * moved to the world frame with x_rw_r2 (RigidBodyDynamics transform(wrench, .)) and projected on the geometric
+ * Jacobians of the two bodies (torque!), f[scene] += J_2' w - J_1' w.
+ *   wrench  n_items x 6   [angular; linear], as returned by pfc_eval
+ *   x_w_r2  n_items x 12  x_rw_r2: R (9, column-major) then t (3)
+ *   body_1, body_2        body index of mesh_1 / mesh_2 per item, or -1 for a body without Jacobian (root: the
+ *                         addGeneralizedForcesExternal!(..., jac::Nothing, ...) method, :275-279)
+ *   scene   n_items       scene (mechanism) index per item, or NULL for a single mechanism
+ *   jac     n_body x nv x 6   per body the 6 x nv geometric Jacobian, column-major (rows 0..2 angular, 3..5 linear)
+ *   f_out   n_scene x nv  OUT f_generalized contribution of the contacts (overwritten)
+ * Host buffers, synchronous.
+ */
+int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, const double *x_w_r2, const int *body_1,
+                            const int *body_2, const int *scene, int n_scene, int n_body, int nv, const double *jac,
+                            double *f_out);
+
 /* Options: "debug" (1: keep per-pair clip counts and materialise traction points of every item so that the
  * pfc_debug_* calls work), "profile" (1: bracket each stage with HIP events), "max_levels" (0 = automatic). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);

@@ -69,6 +69,7 @@ def lib():
         L.pfo_eval_batch.argtypes = [C.c_int, C.POINTER(_Mesh), C.POINTER(_Ins), _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp,
                                      _ip, C.c_int]
         L.pfo_max_threads.restype = C.c_int
+        L.pfo_scatter_generalized.argtypes = [C.c_int, _dp, _dp, _ip, _ip, _ip, C.c_int, _dp, _dp]
         L.pfo_calc_clamped_piecewise.restype = C.c_double
         L.pfo_calc_clamped_piecewise.argtypes = [C.c_double] * 5
         L.pfo_traction_regularized.argtypes = [C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp]
@@ -201,3 +202,16 @@ def evaluate_batch(meshes, ins_list, ins_m1, ins_m2, ins_ids, pose, twist, s, n_
     st = L.pfo_eval_batch(n, marr, iarr, m1_p, m2_p, id_p, po_p, tw_p, s_p, wrench.ctypes.data_as(_dp),
                           sdot.ctypes.data_as(_dp), counts.ctypes.data_as(_ip), int(n_threads))
     return st, wrench, sdot, counts
+
+
+def scatter_generalized(wrench, x_w_r2, body_1, body_2, jac, scene=None, n_scene: int = 1):
+    """pfo_scatter_generalized: addGeneralizedForcesThirdLaw! over all items; jac (n_body, nv, 6)."""
+    L = lib()
+    w_a, w_p = _d(wrench); x_a, x_p = _d(x_w_r2); b1_a, b1_p = _i(body_1); b2_a, b2_p = _i(body_2); j_a, j_p = _d(jac)
+    nv = int(np.shape(jac)[1])
+    sc_p = None
+    if scene is not None:
+        sc_a, sc_p = _i(scene)
+    f = np.zeros((n_scene, nv))
+    L.pfo_scatter_generalized(w_a.size // 6, w_p, x_p, b1_p, b2_p, sc_p, nv, j_p, f.ctypes.data_as(_dp))
+    return f

@@ -959,3 +959,28 @@ int pfo_max_threads(void)
     return 1;
 #endif
 }
+
+/* addGeneralizedForcesThirdLaw!: src/contact_algorithms_non_friction.jl:267-286 (RigidBodyDynamics transform(wrench,.)
+ * and torque!(tau, jac, wrench) restated: lin = R lin, ang = R ang + t x lin, tau_j = J_ang[:,j].ang + J_lin[:,j].lin) */
+void pfo_scatter_generalized(int n_items, const double *wrench, const double *x_w_r2, const int *body_1, const int *body_2,
+                             const int *scene, int nv, const double *jac, double *f)
+{
+    for (int i = 0; i < n_items; ++i) {
+        const double *w = wrench + 6 * (size_t)i, *x = x_w_r2 + 12 * (size_t)i;
+        v3 ang = ld3(w), lin = ld3(w + 3);
+        v3 lw = V3((x[0] * lin.x + x[3] * lin.y) + x[6] * lin.z, (x[1] * lin.x + x[4] * lin.y) + x[7] * lin.z,
+                   (x[2] * lin.x + x[5] * lin.y) + x[8] * lin.z);
+        v3 aw = add3(V3((x[0] * ang.x + x[3] * ang.y) + x[6] * ang.z, (x[1] * ang.x + x[4] * ang.y) + x[7] * ang.z,
+                        (x[2] * ang.x + x[5] * ang.y) + x[8] * ang.z), cross3(ld3(x + 9), lw));
+        double *fs = f + (size_t)(scene ? scene[i] : 0) * nv;
+        for (int pass = 0; pass < 2; ++pass) {       /* +wrench on body 2, then -wrench on body 1 (:271-272) */
+            int b = pass == 0 ? body_2[i] : body_1[i];
+            double sgn = pass == 0 ? 1.0 : -1.0;
+            if (b < 0) continue;                     /* jac::Nothing (:275-279) */
+            for (int j = 0; j < nv; ++j) {
+                const double *J = jac + ((size_t)b * nv + j) * 6;
+                fs[j] += sgn * (dot3(ld3(J), aw) + dot3(ld3(J + 3), lw));
+            }
+        }
+    }
+}

@@ -83,6 +83,9 @@ int pfo_eval_batch(int n_items, const pfo_mesh *meshes, const pfo_ins *ins, cons
                    double *sdot, int *counts, int n_threads);
 int pfo_max_threads(void);
 
+void pfo_scatter_generalized(int n_items, const double *wrench, const double *x_w_r2, const int *body_1, const int *body_2,
+                             const int *scene, int nv, const double *jac, double *f);
+
 /* Unit entry points used by the restated reference tests */
 double pfo_calc_clamped_piecewise(double x, double x1, double x2, double y1, double y2);
 void pfo_traction_regularized(double mu_s, double mu_d, double v_c, const double vel_t[3], double p_dA, double out[3]);

@@ -42,6 +42,7 @@ SIGNATURES = {
     "pfc_debug_pairs": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.c_int]),
     "pfc_debug_tractions": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int]),
     "pfc_debug_stiffness": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]),
+    "pfc_scatter_generalized": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _ip, _ip, _ip, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "pfc_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     "pfc_selftest_math": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
 }

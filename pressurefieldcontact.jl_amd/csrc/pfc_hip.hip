@@ -1554,6 +1554,43 @@ __global__ void __launch_bounds__(256) k_pack(int n_items, const int *icnt, cons
     for (int k = threadIdx.x; k < n_ctr; k += blockDim.x) tail[12 + k] = ctr[k];
 }
 
+// addGeneralizedForcesThirdLaw! (non_friction.jl:267-286): per item, the wrench on body 2 (frame r2) goes to the
+// world frame (RigidBodyDynamics transform(wrench, x_rw_r2): lin = R lin, ang = R ang + t x lin) and is projected
+// on the geometric Jacobians: f += J_2' w - J_1' w (torque!: tau_j = J_ang[:,j].ang + J_lin[:,j].lin).
+// One thread per (item, velocity coordinate); bodies without a Jacobian (root / no mesh path) have id < 0.
+struct ScatterArgs {
+    int n_items, nv;
+    const double *wrench;   // n_items x 6 (device, as written by the evaluation)
+    const double *x_w_r2;   // n_items x 12: R (9, column-major), t (3)
+    const int *body_1, *body_2, *scene;
+    const double *jac;      // n_body x 6 x nv: rows 0..2 angular, 3..5 linear, column-major (6 x nv)
+    double *f;              // n_scene x nv
+};
+__global__ void k_scatter(ScatterArgs g) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long long)g.n_items * g.nv) return;
+    const int i = (int)(tid / g.nv), j = (int)(tid % g.nv);
+    const double *w = g.wrench + 6 * (size_t)i;
+    const double *x = g.x_w_r2 + 12 * (size_t)i;
+    const V3 ang = ld3(w), lin = ld3(w + 3);
+    const V3 lw = mk3((x[0] * lin.x + x[3] * lin.y) + x[6] * lin.z, (x[1] * lin.x + x[4] * lin.y) + x[7] * lin.z,
+                      (x[2] * lin.x + x[5] * lin.y) + x[8] * lin.z);
+    const V3 aw = mk3((x[0] * ang.x + x[3] * ang.y) + x[6] * ang.z, (x[1] * ang.x + x[4] * ang.y) + x[7] * ang.z,
+                      (x[2] * ang.x + x[5] * ang.y) + x[8] * ang.z) + cross(ld3(x + 9), lw);
+    double tau = 0.0;
+    const int b2 = g.body_2[i], b1 = g.body_1[i];
+    if (b2 >= 0) {
+        const double *J = g.jac + ((size_t)b2 * g.nv + j) * 6;
+        tau += dot(ld3(J), aw) + dot(ld3(J + 3), lw);
+    }
+    if (b1 >= 0) {
+        const double *J = g.jac + ((size_t)b1 * g.nv + j) * 6;
+        tau -= dot(ld3(J), aw) + dot(ld3(J + 3), lw);
+    }
+    const int sc = g.scene ? g.scene[i] : 0;
+    if (tau != 0.0) unsafeAtomicAdd(&g.f[(size_t)sc * g.nv + j], tau);
+}
+
 __global__ void k_selftest(int n, const double *x, const double *y, double *out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -2365,6 +2402,51 @@ int pfc_debug_stiffness(pfc_handle h, int item, double *K36, double *Kis36, doub
     if (Sinv6) std::memcpy(Sinv6, r.data() + kResSinv, sizeof(double) * 6);
     if (cop3) std::memcpy(cop3, r.data() + kResCop, sizeof(double) * 3);
     return 1;
+}
+
+int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, const double *x_w_r2, const int *body_1,
+                            const int *body_2, const int *scene, int n_scene, int n_body, int nv, const double *jac,
+                            double *f_out) {
+    if (!h || n_items < 0 || nv <= 0 || n_scene <= 0 || n_body < 0 || !f_out)
+        return fail(h, PFC_ERR_BAD_ARG, "pfc_scatter_generalized: bad argument");
+    if (n_items > 0 && (!wrench || !x_w_r2 || !body_1 || !body_2 || (n_body > 0 && !jac)))
+        return fail(h, PFC_ERR_BAD_ARG, "pfc_scatter_generalized: null buffer");
+    for (int i = 0; i < n_items; ++i) {
+        if (body_1[i] >= n_body || body_2[i] >= n_body || (scene && (scene[i] < 0 || scene[i] >= n_scene)))
+            return fail(h, PFC_ERR_BAD_ARG, "pfc_scatter_generalized: body / scene id out of range (item %d)", i);
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = (size_t)n_items, nf = (size_t)n_scene * nv, nj = (size_t)n_body * 6 * nv;
+    double *dw = nullptr, *dx = nullptr, *dj = nullptr, *df = nullptr;
+    int *db = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&df, sizeof(double) * nf));
+    HIP_TRY(h, hipMemsetAsync(df, 0, sizeof(double) * nf, h->stream));
+    if (n) {
+        HIP_TRY(h, hipMalloc((void **)&dw, sizeof(double) * n * 6));
+        HIP_TRY(h, hipMalloc((void **)&dx, sizeof(double) * n * 12));
+        HIP_TRY(h, hipMalloc((void **)&dj, sizeof(double) * (nj ? nj : 1)));
+        HIP_TRY(h, hipMalloc((void **)&db, sizeof(int) * n * 3));
+        HIP_TRY(h, hipMemcpyAsync(dw, wrench, sizeof(double) * n * 6, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(dx, x_w_r2, sizeof(double) * n * 12, hipMemcpyHostToDevice, h->stream));
+        if (nj) HIP_TRY(h, hipMemcpyAsync(dj, jac, sizeof(double) * nj, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(db, body_1, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(db + n, body_2, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
+        if (scene) HIP_TRY(h, hipMemcpyAsync(db + 2 * n, scene, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
+        ScatterArgs a;
+        a.n_items = n_items; a.nv = nv; a.wrench = dw; a.x_w_r2 = dx; a.body_1 = db; a.body_2 = db + n;
+        a.scene = scene ? db + 2 * n : nullptr; a.jac = dj; a.f = df;
+        const long long tot = (long long)n_items * nv;
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, a);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipMemcpyAsync(f_out, df, sizeof(double) * nf, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(df);
+    if (dw) (void)hipFree(dw);
+    if (dx) (void)hipFree(dx);
+    if (dj) (void)hipFree(dj);
+    if (db) (void)hipFree(db);
+    return PFC_OK;
 }
 
 int pfc_debug_stamps(pfc_handle h, long long *out16) {

@@ -288,6 +288,23 @@ class MechanismScenario:
                                         sdot.ctypes.data_as(_dp), counts.ctypes.data_as(_ip)))
         return wrench, sdot, counts
 
+    def scatter_generalized(self, wrench, x_w_r2, body_1, body_2, jac, scene=None, n_scene: int = 1):
+        """addGeneralizedForcesThirdLaw! for all items (non_friction.jl:267-286) on the device.
+        wrench (n,6); x_w_r2 (n,12) = R col-major + t; body_1/body_2 (n,) body ids (-1: no Jacobian);
+        jac (n_body, nv, 6): per body and velocity coordinate [angular 3; linear 3]; returns f (n_scene, nv)."""
+        w_a, w_p = _d(wrench); x_a, x_p = _d(x_w_r2)
+        b1_a, b1_p = _i(body_1); b2_a, b2_p = _i(body_2)
+        j_a, j_p = _d(jac)
+        n = w_a.size // 6
+        n_body, nv = (int(np.shape(jac)[0]), int(np.shape(jac)[1])) if np.ndim(jac) == 3 else (0, 0)
+        sc_p = None
+        if scene is not None:
+            sc_a, sc_p = _i(scene)
+        f = np.zeros((n_scene, nv))
+        self._check(_lib.lib().pfc_scatter_generalized(self._h, n, w_p, x_p, b1_p, b2_p, sc_p, n_scene, n_body, nv, j_p,
+                                                       f.ctypes.data_as(_dp)))
+        return f
+
     def eval_device(self, n_items: int, d_ins_ids: int, d_pose: int, d_twist: int, d_s: int, d_wrench: int,
                     d_sdot: int, d_counts: int, stream: int = 0):
         """pfc_eval_device: raw device addresses (e.g. torch.Tensor.data_ptr()); asynchronous."""

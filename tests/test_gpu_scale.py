@@ -162,3 +162,31 @@ def test_error_paths(pfc):
     with pytest.raises(L.PFCError) as ei:
         m2.finalize()
     assert ei.value.status == L.ERR_INVERTED_TET
+
+
+def test_scatter_generalized_third_law(pfc):
+    """addGeneralizedForcesThirdLaw! (non_friction.jl:267-286) on the device, 256 scenes x (1 free box
+    against the rooted ground): wrench -> world frame -> J' w, against the oracle's restatement."""
+    from oracle import oracle as O
+    w = pfc.configs.c2_box_on_plane(64, montecarlo=True)
+    m = pfc.configs.build_scenario(w)
+    wrench, _, _ = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    rng = np.random.default_rng(12)
+    n, nv, n_body = w.n_items, 6, 2
+    x_w_r2 = np.zeros((n, 12))
+    for k in range(n):
+        R = pfc.configs.random_rotation(rng)
+        x_w_r2[k, :9] = R.reshape(-1, order="F"); x_w_r2[k, 9:] = rng.standard_normal(3)
+    jac = rng.standard_normal((n_body, nv, 6))
+    body_1 = np.full(n, -1, dtype=np.int32)                      # ground: root body, no Jacobian
+    body_2 = np.where(np.arange(n) % 3 == 0, 1, 0).astype(np.int32)
+    scene = (np.arange(n) // 4).astype(np.int32)
+    f = m.scatter_generalized(wrench, x_w_r2, body_1, body_2, jac, scene, n_scene=16)
+    ref = O.scatter_generalized(wrench, x_w_r2, body_1, body_2, jac, scene, n_scene=16)
+    np.testing.assert_allclose(f, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    # both bodies movable: third law (+w on body 2, -w on body 1)
+    body_1b = np.ones(n, dtype=np.int32)
+    f2 = m.scatter_generalized(wrench, x_w_r2, body_1b, np.zeros(n, dtype=np.int32), jac, None, 1)
+    ref2 = O.scatter_generalized(wrench, x_w_r2, body_1b, np.zeros(n, dtype=np.int32), jac, None, 1)
+    np.testing.assert_allclose(f2, ref2, rtol=1e-11, atol=1e-11 * np.abs(ref2).max())
+    m.close()
