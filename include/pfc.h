@@ -109,6 +109,24 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
 int pfc_check(pfc_handle h);
 
 /*
+ * eMesh_to_tree (src/geometry/blob_types.jl:136-173) on the host: builds the flattened binary OBB tree that
+ * pfc_add_mesh takes.  method PFC_TREE_BLOB follows the reference (bottom-up merging of face/edge-adjacent blobs by
+ * marginal cost :74-134, median-split top-down over the remaining blobs src/geometry/top_down.jl:10-32, tight leaf
+ * boxes src/obb/obb_construction.jl:13-41); PFC_TREE_MEDIAN skips the bottom-up phase (pure top_down.jl).  Equal-cost
+ * merges are ordered by (cost, blob key); Julia's PriorityQueue order among ties is not specified, so trees are
+ * quality-equivalent rather than node-identical to Julia-built ones.
+ *   elem   n_elem x arity (3: triangles, 4: tets), 0-based; eps per point (tets only, may be NULL for triangles)
+ *   node_* OUT arrays sized for 2*n_elem-1 nodes: c (x3), e (x3), R (x9 column-major), child (x2), leaf (x1)
+ * Returns the node count (2*n_elem-1) or a negative pfc_status; message via pfc_tree_last_error().  Reference
+ * errors kept: "three triangles share the same edge", "three tetrahedrons share the same face", open triangle
+ * surfaces ("not implemented error: disconnected mesh", :156), "inverted tet".
+ */
+enum { PFC_TREE_BLOB = 0, PFC_TREE_MEDIAN = 1 };
+int pfc_build_tree(int n_pt, const double *pt, int n_elem, int arity, const int *elem, const double *eps, int method,
+                   double *node_c, double *node_e, double *node_R, int *node_child, int *node_leaf);
+const char *pfc_tree_last_error(void);
+
+/*
  * addGeneralizedForcesThirdLaw! for every item (src/contact_algorithms_non_friction.jl:267-286): the item's wrench is
  * moved to the world frame with x_rw_r2 (RigidBodyDynamics transform(wrench, .)) and projected on the geometric
  * Jacobians of the two bodies (torque!), f[scene] += J_2' w - J_1' w.

@@ -81,8 +81,8 @@ def _rng(seed: int, stream: int):
     return np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed, spawn_key=(stream,))))
 
 
-def _mesh(name, mesh, Ebar=None) -> MeshSpec:
-    return MeshSpec(name, mesh, G.build_tree(mesh), Ebar)
+def _mesh(name, mesh, Ebar=None, method: str = "blob") -> MeshSpec:
+    return MeshSpec(name, mesh, G.build_tree(mesh, method), Ebar)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -124,7 +124,8 @@ def c2_box_on_plane(n_scenes: int = 1, seed: int = 20260101, n_div: int = 9, mon
     r = 0.05
     ground = G.emesh_ground(1.0)
     box = G.as_tet_emesh(G.emesh_box_div(r, n_div))
-    meshes = [_mesh("ground", ground), _mesh("box", box, 1.0e6)]
+    meshes = [_mesh("ground", ground, method="median"),      # open patch: the blob builder refuses it, as upstream
+              _mesh("box", box, 1.0e6)]
     ins = [InsSpec(0, 1, "regularized", chi=0.5, mu_d=0.3, v_tol=1.0e-2)]
     pose, twist = [], []
     for k in range(n_scenes):

@@ -267,7 +267,7 @@ def emesh_box_div(r=1.0, n_div: int = 1, c=(0.0, 0.0, 0.0)) -> EMesh:
 def emesh_ground(half_w: float = 1.0, z: float = 0.0) -> EMesh:
     """Open rigid ground patch: 2 triangles forming a (2*half_w)^2 square at height z, normal +z
     (BASELINE.md C2).  The reference's blob builder cannot build a tree for an open mesh
-    (src/geometry/blob_types.jl:62-69,156); the top-down builder below can."""
+    (src/geometry/blob_types.jl:62-69,156); build_tree(..., "median") can."""
     p = np.array([[-half_w, -half_w, z], [half_w, -half_w, z], [half_w, half_w, z], [-half_w, half_w, z]])
     return EMesh(p, np.array([[0, 1, 2], [0, 2, 3]]), None, None)
 
@@ -350,10 +350,40 @@ class OBBTree:
         return best
 
 
-def build_tree(m: EMesh) -> OBBTree:
-    """Median-split top-down tree over leaf AABBs (src/geometry/top_down.jl:10-32), internal boxes = AABB of
-    the two children's AABBs (src/obb/box_types.jl:11-15), leaves then re-fitted tight
-    (src/geometry/blob_types.jl:170,175-190) unless the mesh has a single element (:139-146)."""
+def build_tree(m: EMesh, method: str = "blob") -> OBBTree:
+    """eMesh_to_tree (src/geometry/blob_types.jl:136-173) through the library's native builder (pfc_build_tree,
+    csrc/pfc_tree.cpp).  method "blob": bottom-up blob merging + top-down over the remaining blobs (the reference's
+    builder); "median": the pure median-split top-down tree (src/geometry/top_down.jl:10-32)."""
+    import ctypes as C
+    from . import _lib
+    if m.tri is not None and m.tet is not None:
+        raise ValueError("Cannot create tree for eMesh{Tri,Tet}; use as_tri_emesh or as_tet_emesh first")
+    elem = m.tri if m.tri is not None else m.tet
+    if elem is None or elem.shape[0] == 0:
+        raise ValueError("empty mesh")
+    code = {"blob": 0, "median": 1}[method]
+    pt = np.ascontiguousarray(m.point, dtype=np.float64)
+    el = np.ascontiguousarray(elem, dtype=np.int32)
+    eps = None if m.eps is None else np.ascontiguousarray(m.eps, dtype=np.float64)
+    n = 2 * el.shape[0] - 1
+    c, e, R = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 9))
+    child, leaf = np.zeros((n, 2), dtype=np.int32), np.zeros(n, dtype=np.int32)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L = _lib.lib()
+    rc = L.pfc_build_tree(pt.shape[0], pt.ctypes.data_as(dp), el.shape[0], el.shape[1], el.ctypes.data_as(ip),
+                          None if eps is None else eps.ctypes.data_as(dp), code, c.ctypes.data_as(dp),
+                          e.ctypes.data_as(dp), R.ctypes.data_as(dp), child.ctypes.data_as(ip), leaf.ctypes.data_as(ip))
+    if rc < 0:
+        raise ValueError(L.pfc_tree_last_error().decode())
+    assert rc == n
+    return OBBTree(c, e, R, child, leaf)
+
+
+def build_tree_py(m: EMesh) -> OBBTree:
+    """Pure-Python statement of the "median" tree (test comparator for pfc_build_tree): recursive_top_down
+    (src/geometry/top_down.jl:10-32) over leaf AABBs, every internal box = OBB(child_1.box, child_2.box)
+    (src/obb/box_types.jl:11-15), leaves then re-fitted tight (src/geometry/blob_types.jl:170,175-190) unless the
+    mesh has a single element (:139-146)."""
     if m.tri is not None and m.tet is not None:
         raise ValueError("Cannot create tree for eMesh{Tri,Tet}; use as_tri_emesh or as_tet_emesh first")
     elem = m.tri if m.tri is not None else m.tet
@@ -364,45 +394,48 @@ def build_tree(m: EMesh) -> OBBTree:
     lo, hi = P.min(axis=1), P.max(axis=1)
     lc, le = (hi + lo) * 0.5, (hi - lo) * 0.5           # calc_obb: centre/extent of the leaf AABB
 
-    C, E, R, CH, LF = [], [], [], [], []
-    eye = np.eye(3).reshape(9)
-
-    def new_node():
-        C.append(None); E.append(None); R.append(eye); CH.append([-1, -1]); LF.append(INTERNAL)
-        return len(C) - 1
-
-    def merged(ids):
-        mn = (lc[ids] - le[ids]).min(axis=0)
-        mx = (lc[ids] + le[ids]).max(axis=0)
+    def union(a, b):                                    # OBB(a, b) for axis-aligned boxes
+        mn = np.minimum(np.minimum(a[0] - a[1], a[0] + a[1]), np.minimum(b[0] - b[1], b[0] + b[1]))
+        mx = np.maximum(np.maximum(a[0] - a[1], a[0] + a[1]), np.maximum(b[0] - b[1], b[0] + b[1]))
         return (mx + mn) * 0.5, (mx - mn) * 0.5
 
-    def rec(ids: np.ndarray) -> int:
-        k = new_node()
-        n = ids.shape[0]
+    def rec(ts):                                        # ts: list of subtrees (box, leaf, children)
+        n = len(ts)
         if n == 1:
-            i = int(ids[0])
-            C[k], E[k], LF[k] = lc[i], le[i], i
-            return k
-        C[k], E[k] = merged(ids)
+            return ts[0]
         if n == 2:
-            a, b = ids[:1], ids[1:]
-        else:
-            ax = int(np.argmax(E[k]))
-            perm = np.argsort(lc[ids, ax], kind="stable")
-            n_mid = -(-n // 2)
-            a, b = ids[perm[:n_mid - 1]], ids[perm[n_mid - 1:]]
-        CH[k] = [rec(a), rec(b)]
-        return k
+            return (union(ts[0][0], ts[1][0]), INTERNAL, (ts[0], ts[1]))
+        box = ts[0][0]
+        for t in ts:
+            box = union(box, t[0])
+        ax = int(np.argmax(box[1]))
+        perm = np.argsort(np.array([t[0][0][ax] for t in ts]), kind="stable")
+        n_mid = -(-n // 2)
+        a = rec([ts[i] for i in perm[:n_mid - 1]])
+        b = rec([ts[i] for i in perm[n_mid - 1:]])
+        return (union(a[0], b[0]), INTERNAL, (a, b))
 
     import sys
     old = sys.getrecursionlimit()
     sys.setrecursionlimit(max(old, 10000))
     try:
-        rec(np.arange(n_leaf))
+        root = rec([((lc[i], le[i]), i, None) for i in range(n_leaf)])
     finally:
         sys.setrecursionlimit(old)
 
-    C, E, R = np.asarray(C), np.asarray(E), np.asarray(R).copy()
+    C, E, CH, LF = [], [], [], []
+    stack = [(root, -1, 0)]
+    while stack:                                        # preorder flattening, node 0 = root
+        t, parent, side = stack.pop()
+        k = len(C)
+        C.append(t[0][0]); E.append(t[0][1]); CH.append([-1, -1]); LF.append(t[1])
+        if parent >= 0:
+            CH[parent][side] = k
+        if t[1] == INTERNAL:
+            stack.append((t[2][1], k, 1))
+            stack.append((t[2][0], k, 0))
+    C, E = np.asarray(C), np.asarray(E)
+    R = np.tile(np.eye(3).reshape(9), (len(C), 1))
     CH, LF = np.asarray(CH, dtype=np.int32), np.asarray(LF, dtype=np.int32)
     if n_leaf > 1:                                      # tight_fit_leaves!
         for k in np.nonzero(LF != INTERNAL)[0]:

@@ -107,7 +107,7 @@ def test_single_element_tree_keeps_aabb(pfc):
     t = G.build_tree(hp)
     assert t.n_node == 1 and t.leaf[0] == 0
     assert np.array_equal(t.R[0], np.eye(3).reshape(9))
-    two = G.build_tree(G.emesh_ground())
+    two = G.build_tree(G.emesh_ground(), "median")       # open patch: no adjacency for the blob builder
     assert two.n_node == 3 and two.leaf.tolist() == [G.INTERNAL, 0, 1]
 
 
