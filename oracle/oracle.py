@@ -43,7 +43,7 @@ class _Debug(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(HERE, f) for f in ("pfc_oracle.c", "pfc_oracle.h", "Makefile")]
+    src = [os.path.join(HERE, f) for f in ("pfc_oracle.c", "pfc_oracle_dual.cpp", "pfc_oracle.h", "Makefile")]
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
     if force or stale:
         subprocess.run(["make", "-C", HERE, "-B" if force else "-s", "libpfc_oracle.so"], check=True,
@@ -69,6 +69,9 @@ def lib():
         L.pfo_eval_batch.argtypes = [C.c_int, C.POINTER(_Mesh), C.POINTER(_Ins), _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp,
                                      _ip, C.c_int]
         L.pfo_max_threads.restype = C.c_int
+        L.pfo_eval_dual.restype = C.c_int
+        L.pfo_eval_dual.argtypes = [C.POINTER(_Mesh), C.POINTER(_Mesh), C.POINTER(_Ins), _dp, _dp, _dp, C.c_int, _dp, _dp, _dp,
+                                    _dp, _dp, _dp, _dp]
         L.pfo_scatter_generalized.argtypes = [C.c_int, _dp, _dp, _ip, _ip, _ip, C.c_int, _dp, _dp]
         L.pfo_calc_clamped_piecewise.restype = C.c_double
         L.pfo_calc_clamped_piecewise.argtypes = [C.c_double] * 5
@@ -215,3 +218,18 @@ def scatter_generalized(wrench, x_w_r2, body_1, body_2, jac, scene=None, n_scene
     f = np.zeros((n_scene, nv))
     L.pfo_scatter_generalized(w_a.size // 6, w_p, x_p, b1_p, b2_p, sc_p, nv, j_p, f.ctypes.data_as(_dp))
     return f
+
+
+def evaluate_dual(m1: OracleMesh, m2: OracleMesh, ins: _Ins, pose, twist, s, d_pose, d_twist, d_s):
+    """pfo_eval_dual: one force_single_elastic_intersection! on Duals.  d_pose (n_dir, 24), d_twist (n_dir, 6),
+    d_s (n_dir, 6).  Returns (status, wrench, sdot, d_wrench (n_dir, 6), d_sdot (n_dir, 6))."""
+    L = lib()
+    pose_a, pose_p = _d(pose); tw_a, tw_p = _d(twist); s_a, s_p = _d(np.zeros(6) if s is None else s)
+    dp_a, dp_p = _d(d_pose); dt_a, dt_p = _d(d_twist)
+    n_dir = dp_a.size // 24
+    ds_a, ds_p = _d(np.zeros((n_dir, 6)) if d_s is None else d_s)
+    wrench = np.zeros(6); sdot = np.zeros(6); dw = np.zeros((n_dir, 6)); dsd = np.zeros((n_dir, 6))
+    st = L.pfo_eval_dual(C.byref(m1.c), C.byref(m2.c), C.byref(ins), pose_p, tw_p, s_p, n_dir, dp_p, dt_p, ds_p,
+                         wrench.ctypes.data_as(_dp), sdot.ctypes.data_as(_dp), dw.ctypes.data_as(_dp),
+                         dsd.ctypes.data_as(_dp))
+    return st, wrench, sdot, dw, dsd
