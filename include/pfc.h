@@ -109,6 +109,24 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
 int pfc_check(pfc_handle h);
 
 /*
+ * The same evaluation on ForwardDiff.Dual numbers: what forceAllElasticIntersections! does when calcXd! runs on
+ * MechanismScenario.dual (Dual{Nothing,Float64,N_chunk}, src/mechanism_scenario.jl:187) for Radau's Jacobian
+ * (src/radau/radau_functions.jl:2-40).  Values as pfc_eval; in addition, for each of n_dir (1..16) seed directions,
+ * the partials of every input and of every output:
+ *   d_pose   n_items x n_dir x 24   partials of pose (same packing as pose)
+ *   d_twist  n_items x n_dir x 6    d_s  n_items x n_dir x 6 (or NULL = zeros)
+ *   d_wrench n_items x n_dir x 6    OUT partials of wrench     d_sdot  n_items x n_dir x 6   OUT partials of sdot
+ * The candidate pairs come from the value pass (the intersection does not depend on partials,
+ * src/contact_algorithms_non_friction.jl:95); every branch compares values, as ForwardDiff's comparisons do.  The one
+ * step that is not the reference's operation sequence is eigen!(Hermitian{Dual}) (src/contact_algorithms_friction.jl:88,
+ * GenericLinearAlgebra): the partials of K̄^{-1/2} are its analytic Frechet derivative ("Dual path").
+ * Host buffers, synchronous.
+ */
+int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, const double *pose, const double *twist,
+                  const double *s, const double *d_pose, const double *d_twist, const double *d_s, double *wrench,
+                  double *sdot, double *d_wrench, double *d_sdot, int *counts);
+
+/*
  * eMesh_to_tree (src/geometry/blob_types.jl:136-173) on the host: builds the flattened binary OBB tree that
  * pfc_add_mesh takes.  method PFC_TREE_BLOB follows the reference (bottom-up merging of face/edge-adjacent blobs by
  * marginal cost :74-134, median-split top-down over the remaining blobs src/geometry/top_down.jl:10-32, tight leaf

@@ -42,6 +42,7 @@ SIGNATURES = {
     "pfc_debug_pairs": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.c_int]),
     "pfc_debug_tractions": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int]),
     "pfc_debug_stiffness": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]),
+    "pfc_eval_dual": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "pfc_build_tree": (C.c_int, [C.c_int, _dp, C.c_int, C.c_int, _ip, _dp, C.c_int, _dp, _dp, _dp, _ip, _ip]),
     "pfc_tree_last_error": (C.c_char_p, []),
     "pfc_scatter_generalized": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _ip, _ip, _ip, C.c_int, C.c_int, C.c_int, _dp, _dp]),
@@ -58,7 +59,7 @@ class PFCError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile csrc/pfc_hip.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("pfc_hip.hip", "pfc_tree.cpp", "pfc_kernels.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("pfc_hip.hip", "pfc_tree.cpp", "pfc_kernels.h", "pfc_dual.h")]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "pfc.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:

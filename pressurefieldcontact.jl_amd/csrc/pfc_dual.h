@@ -1,0 +1,681 @@
+// pfc_dual.h — the hot path on ForwardDiff.Dual numbers (value + partials): what calcXd! runs when Radau builds its
+// Jacobian (src/mechanism_scenario.jl:187, src/radau/radau_functions.jl:2-40).  Included by pfc_hip.hip.
+//
+// Layout of the work.  The broadphase does not depend on partials (src/contact_algorithms_non_friction.jl:95), so
+// the candidate list of the value evaluation is reused.  A Dual with N partials is carried as N independent
+// (value, one partial) pairs: the work item is (candidate, seed direction) and one lane evaluates one direction.
+// A wave takes 64 / n_dir consecutive candidates; its lanes are direction-major (lane = dir * cpw + c), so the lanes
+// of one (item, direction) are contiguous for the segmented reductions while the n_dir lanes of one candidate gather
+// the same mesh records (one fetch per wave instruction).  Per-lane state is 2x the value kernel's, so the polygon
+// ring stays in LDS (32 KiB per wave) and the occupancy does not collapse as it would with 7-wide Duals in one lane.
+//
+// All branches compare values (ForwardDiff's comparison operators do), and the value part of every operation is the
+// same instruction sequence as the value kernel's, so both take the same branches.
+//
+// Bristle model: three passes over the candidates, as in the reference (normal_wrench_cop; then
+// calc_patch_spatial_stiffness! about the cop; then calc_spatial_bristle_force), src/contact_algorithms_friction.jl
+// :119-201.  The partials of K̄^{-1/2} are the Frechet derivative of the matrix function on the eigen-basis
+// (Daleckii-Krein); the reference differentiates through GenericLinearAlgebra's eigen-solver instead (not vendored),
+// which agrees wherever the unclamped eigenvalues are distinct ("Dual path").
+#pragma once
+
+struct Du { double v, d; };
+__device__ __forceinline__ Du du(double v) { return Du{v, 0.0}; }
+__device__ __forceinline__ Du du(double v, double d) { return Du{v, d}; }
+__device__ __forceinline__ Du operator+(Du a, Du b) { return Du{a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Du operator-(Du a, Du b) { return Du{a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Du operator-(Du a) { return Du{-a.v, -a.d}; }
+__device__ __forceinline__ Du operator*(Du a, Du b) { return Du{a.v * b.v, a.v * b.d + a.d * b.v}; }
+__device__ __forceinline__ Du operator*(double a, Du b) { return Du{a * b.v, a * b.d}; }
+__device__ __forceinline__ Du operator*(Du a, double b) { return Du{a.v * b, a.d * b}; }
+__device__ __forceinline__ Du operator/(Du a, Du b) {
+    const double q = a.v / b.v;
+    return Du{q, (a.d - q * b.d) / b.v};
+}
+__device__ __forceinline__ Du operator/(Du a, double b) { return Du{a.v / b, a.d / b}; }
+__device__ __forceinline__ Du dsqrt(Du a) {
+    const double s = __builtin_sqrt(a.v);
+    return Du{s, a.d / (2.0 * s)};
+}
+// muladd(a, x, c) with a constant a
+__device__ __forceinline__ Du dfma(double a, Du x, Du c) { return Du{__builtin_fma(a, x.v, c.v), a * x.d + c.d}; }
+__device__ __forceinline__ Du dfma(Du a, Du x, Du c) { return Du{__builtin_fma(a.v, x.v, c.v), a.v * x.d + a.d * x.v + c.d}; }
+__device__ __forceinline__ void operator+=(Du &a, Du b) { a.v += b.v; a.d += b.d; }
+
+struct Du3 { Du x, y, z; };
+__device__ __forceinline__ Du3 dmk(Du x, Du y, Du z) { return Du3{x, y, z}; }
+__device__ __forceinline__ Du3 operator+(Du3 a, Du3 b) { return Du3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ Du3 operator-(Du3 a, Du3 b) { return Du3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ Du3 operator*(Du3 a, Du s) { return Du3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ Du3 operator*(Du3 a, double s) { return Du3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ Du3 operator/(Du3 a, Du s) { return Du3{a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ Du3 operator/(Du3 a, double s) { return Du3{a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ Du ddot(Du3 a, Du3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ Du3 dcross(Du3 a, Du3 b) {
+    return Du3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ Du3 dnormalize(Du3 a) {
+    const Du s = du(1.0) / dsqrt(ddot(a, a));
+    return Du3{s * a.x, s * a.y, s * a.z};
+}
+__device__ __forceinline__ Du dtriangle_area(Du3 a, Du3 b, Du3 c, Du3 n) { return ddot(n, dcross(b - a, c - b) * 0.5); }
+__device__ __forceinline__ Du3 dvec_sub_vec_proj(Du3 v, Du3 n) {
+    const Du t = -ddot(v, n);
+    return Du3{dfma(t, n.x, v.x), dfma(t, n.y, v.y), dfma(t, n.z, v.z)};
+}
+__device__ __forceinline__ Du dclamped_piecewise(Du x, double x1, double x2, double y1, double y2) {
+    const double k = (y2 - y1) / (x2 - x1);
+    const Du y = du(y1) + (x - du(x1)) * k;
+    return (y.v > y1) ? du(y1) : ((y.v < y2) ? du(y2) : y);
+}
+
+// accumulator slots per (item, direction): values then partials of each group
+constexpr int kDaA = 0;     // pass A: 10 Duals = wrench 6 (regularized total / bristle normal), sum w, sum w r (3)
+constexpr int kDaB = 20;    // pass B: 21 Duals = K11 (xx xy xz yy yz zz), K12 (9, column-major), K22 (6) about the cop
+constexpr int kDaC = 62;    // pass C: 6 Duals = friction wrench about the cop
+constexpr int kDaStride = 76;
+// derived per (item, direction): cop 3, Delta 6, Sinv 6, Kis 36 (values then partials each)
+constexpr int kDrCop = 0, kDrDelta = 6, kDrSinv = 18, kDrKis = 30, kDrStride = 102;
+
+struct DualArgs {
+    const ItemRec *items;
+    const WorkRec *cand;
+    const int *ccount;
+    int ccap;
+    int n_items, n_dir;
+    const double *d_pose;    // (item, dir) x 24: dR21 9, dt21 3, dR12 9, dt12 3
+    const double *d_twist;   // (item, dir) x 6
+    const double *d_s;       // (item, dir) x 6
+    const int *icnt;
+    double *dacc;
+    double *dres;
+    double *d_wrench;        // OUT (item, dir) x 6
+    double *d_sdot;          // OUT (item, dir) x 6
+    unsigned *status;
+};
+
+#define PV(k, c) pv[((((rbase) + (k)) & 7) * 4 + (c)) * 64 + lane]
+#define PD(k, c) pd[((((rbase) + (k)) & 7) * 4 + (c)) * 64 + lane]
+
+// MODE 0: pass A (normal wrench, regularized friction fused, cop sums); 1: pass B (patch stiffness about the cop);
+// 2: pass C (bristle friction force).  TT as in k_narrow.
+template <int MODE, bool TT>
+__global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
+    __shared__ double pv[8 * 4 * 64];
+    __shared__ double pd[8 * 4 * 64];
+    const int lane = threadIdx.x;
+    int n_c = *g.ccount;
+    if (n_c > g.ccap) n_c = g.ccap;
+    const int n_dir = g.n_dir;
+    const int cpw = 64 / n_dir;
+    const int n_group = (n_c + cpw - 1) / cpw;
+    const int dir = lane / cpw, cl = lane - dir * cpw;
+    for (int grp = blockIdx.x; grp < n_group; grp += gridDim.x) {
+        const int idx = grp * cpw + cl;
+        const bool active = dir < n_dir && idx < n_c;
+        WorkRec cw;
+        cw.item = 0; cw.a = 0; cw.b = 0; cw.pad = 0;
+        if (active) cw = g.cand[idx];
+        const ItemRec *it = g.items + cw.item;
+        const TetRec *tp = it->tet + cw.b;
+        const int nq = it->nq;
+        const bool reg = it->model == PFC_REGULARIZED;
+        const int key = active ? cw.item * n_dir + dir : -1;
+        const bool work = active && g.icnt[4 * (size_t)cw.item + 3] > 0 && (MODE == 0 || !reg);
+        int n_poly = 0, rbase = 0;
+        Du3 nh = dmk(du(0.0), du(0.0), du(0.0));
+        if (work) {
+            const double *dp = g.d_pose + (size_t)key * 24;
+            Du R21[9], t21[3];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R21[k] = du(it->R21[k], dp[k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t21[k] = du(it->t21[k], dp[9 + k]);
+            Du z[4][4];
+            int n_in = 0;
+            Du3 nh_in = nh;
+            double Z[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
+            if (!TT || it->tet1 == nullptr) {
+                // tri-tet op (non_friction.jl:196-215)
+                const TriRec tr = it->tri[cw.a];
+                Du X[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
+                    X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + du(Z[i + 12]);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        z[k][i] = ((X[i] * tr.v[3 * k] + X[i + 4] * tr.v[3 * k + 1]) + X[i + 8] * tr.v[3 * k + 2]) + X[i + 12];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[3][i] = du(0.0);
+                n_in = 3;
+                nh_in = dmk((R21[0] * tr.n[0] + R21[3] * tr.n[1]) + R21[6] * tr.n[2],
+                            (R21[1] * tr.n[0] + R21[4] * tr.n[1]) + R21[7] * tr.n[2],
+                            (R21[2] * tr.n[0] + R21[5] * tr.n[1]) + R21[8] * tr.n[2]);
+            } else {
+                // tet-tet op (non_friction.jl:166-194)
+                const TetRec *t1 = it->tet1 + cw.a;
+                Du plane[4];
+                {
+                    Du R12[9], t12[3], X1[16];
+                    double Z1[16];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) R12[k] = du(it->R12[k], dp[12 + k]);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t12[k] = du(it->t12[k], dp[21 + k]);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) Z1[k] = t1->xzr[k];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            X1[i + 4 * j] = (Z1[i] * R12[3 * j] + Z1[i + 4] * R12[3 * j + 1]) + Z1[i + 8] * R12[3 * j + 2];
+                        X1[i + 12] = ((Z1[i] * t12[0] + Z1[i + 4] * t12[1]) + Z1[i + 8] * t12[2]) + du(Z1[i + 12]);
+                    }
+                    double Ee1[4], Ee2[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        Ee1[j] = it->Ebar1 * it->eps1[4 * (size_t)cw.a + j];
+                        Ee2[j] = it->Ebar * it->eps2[4 * (size_t)cw.b + j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const Du p1 = ((Ee1[0] * X1[4 * j] + Ee1[1] * X1[4 * j + 1]) + Ee1[2] * X1[4 * j + 2]) + Ee1[3] * X1[4 * j + 3];
+                        const double p2 = ((Ee2[0] * Z[4 * j] + Ee2[1] * Z[4 * j + 1]) + Ee2[2] * Z[4 * j + 2]) + Ee2[3] * Z[4 * j + 3];
+                        plane[j] = du(p2) - p1;
+                    }
+                }
+                Du3 P[4];
+                Du proj[4];
+                int n_neg = 0, n_pos = 0;
+                unsigned posm = 0, negm = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double vx = t1->xrz[3 * j], vy = t1->xrz[3 * j + 1], vz = t1->xrz[3 * j + 2];
+                    P[j] = dmk(((R21[0] * vx + R21[3] * vy) + R21[6] * vz) + t21[0],
+                               ((R21[1] * vx + R21[4] * vy) + R21[7] * vz) + t21[1],
+                               ((R21[2] * vx + R21[5] * vy) + R21[8] * vz) + t21[2]);
+                    proj[j] = ((plane[0] * P[j].x + plane[1] * P[j].y) + plane[2] * P[j].z) + plane[3];
+                    if (proj[j].v < 0.0) { ++n_neg; negm |= 1u << j; }
+                    if (0.0 < proj[j].v) { ++n_pos; posm |= 1u << j; }
+                }
+                Du3 q[4];
+                q[0] = q[1] = q[2] = q[3] = dmk(du(0.0), du(0.0), du(0.0));
+                int n_q = 0;
+#define PW_(i1, i2) (P[i2] * (proj[i1] / (proj[i1] - proj[i2])) - P[i1] * (proj[i2] / (proj[i1] - proj[i2])))
+                if (n_pos != 0 && n_neg != 0) {
+                    int lone = -1;
+                    if (n_pos == 1) lone = __builtin_ctz(posm);
+                    else if (n_neg == 1) lone = __builtin_ctz(negm);
+                    if (lone >= 0) {
+                        Du3 a, b, c;
+                        if (lone == 0) { a = PW_(1, 0); b = PW_(3, 0); c = PW_(2, 0); }
+                        else if (lone == 1) { a = PW_(0, 1); b = PW_(2, 1); c = PW_(3, 1); }
+                        else if (lone == 2) { a = PW_(0, 2); b = PW_(3, 2); c = PW_(1, 2); }
+                        else { a = PW_(0, 3); b = PW_(1, 3); c = PW_(2, 3); }
+                        const double pl = (lone == 0) ? proj[0].v : (lone == 1) ? proj[1].v : (lone == 2) ? proj[2].v : proj[3].v;
+                        n_q = 3;
+                        if (0.0 < pl) { q[0] = a; q[1] = b; q[2] = c; } else { q[0] = c; q[1] = b; q[2] = a; }
+                    } else {
+                        Du3 a, b, c, d;
+                        const bool p0 = (posm & 1u) != 0, p1 = (posm & 2u) != 0, p2 = (posm & 4u) != 0;
+                        if (p0 == p1) { a = PW_(1, 2); b = PW_(1, 3); c = PW_(0, 3); d = PW_(0, 2); }
+                        else if (p0 == p2) { a = PW_(0, 1); b = PW_(0, 3); c = PW_(2, 3); d = PW_(2, 1); }
+                        else { a = PW_(0, 2); b = PW_(0, 1); c = PW_(3, 1); d = PW_(3, 2); }
+                        n_q = 4;
+                        if (0.0 < proj[0].v) { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+                        else { q[0] = d; q[1] = c; q[2] = b; q[3] = a; }
+                    }
+                }
+#undef PW_
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const Du v = ((Z[i] * q[k].x + Z[i + 4] * q[k].y) + Z[i + 8] * q[k].z) + du(Z[i + 12]);
+                        z[k][i] = v * ((1.0e-14 < __builtin_fabs(v.v)) ? 1.0 : 0.0);   // zero_small_coordinates
+                    }
+                n_in = n_q;
+                nh_in = dnormalize(dmk(plane[0], plane[1], plane[2]));
+            }
+            bool finite = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) finite &= (k >= n_in) || (__builtin_fabs(z[k][i].v) <= 1.79769313486231570815e308);
+            bool reject = !finite || n_in < 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                reject |= (z[0][i].v <= 0.0) && (z[1][i].v <= 0.0) && (z[2][i].v <= 0.0) && (n_in < 4 || z[3][i].v <= 0.0);
+            if (!reject) {
+                // clip_in_tet_coordinates (static_clip.jl:7-23,34-201), polygon ring in LDS, clipped in place
+                int n = n_in;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < n_in) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { PV(k, i) = z[k][i].v; PD(k, i) = z[k][i].d; }
+                    }
+                for (int i = 0; i < 4 && n > 0; ++i) {
+                    unsigned nonpos = 0, nonneg = 0;
+                    for (int k = 0; k < n; ++k) {
+                        const double sv = PV(k, i);
+                        nonpos |= (unsigned)(sv <= 0.0) << k;
+                        nonneg |= (unsigned)(0.0 <= sv) << k;
+                    }
+                    const unsigned full = (1u << n) - 1u;
+                    if (nonpos == full) { n = 0; break; }
+                    if (nonneg == full) continue;
+                    const unsigned nxt = ((nonpos >> 1) | ((nonpos & 1u) << (n - 1))) & full;
+                    const unsigned cand_start = nonpos & ~nxt & full;
+                    if (cand_start == 0) { n = 0; break; }   // the value pass has reported it
+                    const int st = __builtin_ctz(cand_start);
+                    int m = n;
+                    while (m > 3) {
+                        int k2 = st + m - 2; if (k2 >= n) k2 -= n;
+                        if ((nonpos >> k2) & 1u) --m; else break;
+                    }
+                    int k1 = st + 1; if (k1 >= n) k1 -= n;
+                    int kl = st + m - 1; if (kl >= n) kl -= n;
+                    int kp = st + m - 2; if (kp >= n) kp -= n;
+                    const bool inside = (m <= 5) ? (((nonpos >> kl) & 1u) == 0) : (((nonneg >> kl) & 1u) != 0);
+                    Du zs[4], ze[4];
+                    {
+                        const Du w1 = du(PV(st, i), PD(st, i)), w2 = du(PV(k1, i), PD(k1, i));
+                        const Du sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) zs[c] = c1 * du(PV(k1, c), PD(k1, c)) - c2 * du(PV(st, c), PD(st, c));
+                    }
+                    {
+                        const int kn = inside ? st : kl, kq = inside ? kl : kp;
+                        const Du w1 = du(PV(kn, i), PD(kn, i)), w2 = du(PV(kq, i), PD(kq, i));
+                        const Du sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ze[c] = c1 * du(PV(kq, c), PD(kq, c)) - c2 * du(PV(kn, c), PD(kn, c));
+                    }
+                    const int ncopy = inside ? (m - 1) : (m - 2);
+                    for (int q = n - st - 1; q < ncopy; ++q) {
+                        const int src = st + 1 + q - n, dst = st + 1 + q;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const double tv = PV(src, c), td = PD(src, c);
+                            PV(dst, c) = tv; PD(dst, c) = td;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        PV(st, c) = zs[c].v; PD(st, c) = zs[c].d;
+                        PV(st + ncopy + 1, c) = ze[c].v; PD(st + ncopy + 1, c) = ze[c].d;
+                    }
+                    rbase = (rbase + st) & 7;
+                    n = ncopy + 2;
+                    if (m == 7) break;
+                }
+                n_poly = n;
+                if (n >= 3) nh = nh_in;
+            }
+        }
+        // ---- integrate_over_polygon_patch! (non_friction.jl:217-234) ------------------------------------------------
+        constexpr int NS = MODE == 0 ? 10 : (MODE == 1 ? 21 : 6);
+        Du sum[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) sum[k] = du(0.0);
+        int n_trac_lane = 0;
+        if (n_poly >= 3) {
+            const int n = n_poly;
+            {
+                double V[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
+                for (int k = 0; k < n; ++k) {
+                    const Du z0 = du(PV(k, 0), PD(k, 0)), z1 = du(PV(k, 1), PD(k, 1)), z2 = du(PV(k, 2), PD(k, 2)),
+                             z3 = du(PV(k, 3), PD(k, 3));
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const Du r = ((V[c] * z0 + V[c + 3] * z1) + V[c + 6] * z2) + V[c + 9] * z3;
+                        PV(k, c) = r.v; PD(k, c) = r.d;
+                    }
+                }
+            }
+#define PVT(k) dmk(du(PV(k, 0), PD(k, 0)), du(PV(k, 1), PD(k, 1)), du(PV(k, 2), PD(k, 2)))
+            Du3 cen;
+            {
+                const Du3 a = PVT(0);
+                Du3 cc = PVT(1);
+                Du cum_sum = du(0.0);
+                Du3 cum_prod = dmk(du(0.0), du(0.0), du(0.0));
+                for (int k = 2; k < n; ++k) {
+                    const Du3 b = cc;
+                    cc = PVT(k);
+                    const Du ar = dtriangle_area(a, b, cc, nh);
+                    cum_prod = cum_prod + (((a + b) + cc) * (1.0 / 3.0)) * ar;
+                    cum_sum += ar;
+                }
+                cen = (cum_sum.v == 0.0) ? a : cum_prod / cum_sum;
+            }
+            const double er0 = tp->epsr[0], er1 = tp->epsr[1], er2 = tp->epsr[2], er3 = tp->epsr[3];
+            const double *dt = g.d_twist + (size_t)key * 6;
+            const Du3 w = dmk(du(it->w[0], dt[0]), du(it->w[1], dt[1]), du(it->w[2], dt[2]));
+            const Du3 vl = dmk(du(it->v[0], dt[3]), du(it->v[1], dt[4]), du(it->v[2], dt[5]));
+            const double chi = it->chi, Ebar = it->Ebar;
+            const double v_c = it->v_c, mu_s = it->mu_s, mu_d = it->mu_d;
+            Du3 cop = dmk(du(0.0), du(0.0), du(0.0)), Da = cop, Dl = cop;
+            double tau = 0.0, k_bar = 0.0;
+            if (MODE == 1) {
+                const double *a = g.dacc + (size_t)key * kDaStride + kDaA;
+                const Du ip = du(a[6], a[16]);
+                cop = dmk(du(a[7], a[17]), du(a[8], a[18]), du(a[9], a[19])) / ip;
+            }
+            if (MODE == 2) {
+                const double *r = g.dres + (size_t)key * kDrStride;
+                cop = dmk(du(r[kDrCop], r[kDrCop + 3]), du(r[kDrCop + 1], r[kDrCop + 4]), du(r[kDrCop + 2], r[kDrCop + 5]));
+                Da = dmk(du(r[kDrDelta], r[kDrDelta + 6]), du(r[kDrDelta + 1], r[kDrDelta + 7]), du(r[kDrDelta + 2], r[kDrDelta + 8]));
+                Dl = dmk(du(r[kDrDelta + 3], r[kDrDelta + 9]), du(r[kDrDelta + 4], r[kDrDelta + 10]), du(r[kDrDelta + 5], r[kDrDelta + 11]));
+                tau = it->tau; k_bar = it->k_bar;
+            }
+            Du3 v2 = PVT(n - 1);
+            for (int k = 0; k < n; ++k) {
+                const Du3 v1 = v2;
+                v2 = PVT(k);
+                const Du area = dtriangle_area(v1, v2, cen, nh);
+                if (!(0.0 < area.v)) continue;
+                for (int q = 0; q < nq; ++q) {
+                    double q0, q1, q2, qw;
+                    if (nq == 1) {
+                        q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
+                    } else {
+                        const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
+                        q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
+                        qw = 0.33333333333333331483;
+                    }
+                    const Du3 r = dmk((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
+                                      (v1.z * q0 + v2.z * q1) + cen.z * q2);
+                    Du eq = dfma(er0, r.x, du(er3));
+                    eq = dfma(er1, r.y, eq);
+                    eq = dfma(er2, r.z, eq);
+                    const Du3 rdot = vl + dcross(w, r);
+                    const Du ee = -((er0 * rdot.x + er1 * rdot.y) + er2 * rdot.z);
+                    const Du darg = du(1.0) + chi * ee;
+                    const Du damp = (darg.v > 0.0) ? darg : du(0.0);   // max(0.0, .)
+                    const Du p = (eq * Ebar) * damp;
+                    const Du dA = qw * area;
+                    if (!(0.0 < p.v)) continue;
+                    ++n_trac_lane;
+                    const Du p_dA = p * dA;
+                    if (MODE == 2) {
+                        // calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48)
+                        const Du3 x = r - cop;
+                        const Du3 del = Dl + dcross(Da, x);
+                        Du3 Ts = (del + rdot * tau) * (-k_bar);
+                        Ts = dvec_sub_vec_proj(Ts, nh);
+                        const Du m2 = ddot(Ts, Ts);
+                        Du3 T;
+                        if (m2.v < mu_s * mu_s) {
+                            T = Ts;
+                        } else {
+                            const Du mg = dsqrt(m2);
+                            const Du mu = dclamped_piecewise(mg, 2 * mu_s, 3 * mu_s, mu_s, mu_d);
+                            T = (Ts * mu) / mg;
+                        }
+                        const Du3 Tc = T * p_dA;
+                        const Du3 ta = dcross(x, Tc);
+                        sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+                        sum[3] += Tc.x; sum[4] += Tc.y; sum[5] += Tc.z;
+                        continue;
+                    }
+                    if (MODE == 1) {
+                        // calc_patch_spatial_stiffness! (friction.jl:147-169), r - cop
+                        const Du3 x = r - cop;
+                        const Du3 xn = dcross(x, nh);
+                        const Du q1s = x.x * x.x, q2s = x.y * x.y, q3s = x.z * x.z;
+                        const Du xy = x.x * x.y, xz = x.x * x.z, yz = x.y * x.z;
+                        // K11 -= w ([x]x^2 + (x x n)(x x n)')
+                        sum[0] += -(p_dA * ((-q2s - q3s) + xn.x * xn.x));
+                        sum[1] += -(p_dA * (xy + xn.x * xn.y));
+                        sum[2] += -(p_dA * (xz + xn.x * xn.z));
+                        sum[3] += -(p_dA * ((-q1s - q3s) + xn.y * xn.y));
+                        sum[4] += -(p_dA * (yz + xn.y * xn.z));
+                        sum[5] += -(p_dA * ((-q1s - q2s) + xn.z * xn.z));
+                        // K12 += w ([x]x - (x x n) n'), column-major
+                        sum[6] += p_dA * (du(0.0) - xn.x * nh.x);
+                        sum[7] += p_dA * (x.z - xn.y * nh.x);
+                        sum[8] += p_dA * (-x.y - xn.z * nh.x);
+                        sum[9] += p_dA * (-x.z - xn.x * nh.y);
+                        sum[10] += p_dA * (du(0.0) - xn.y * nh.y);
+                        sum[11] += p_dA * (x.x - xn.z * nh.y);
+                        sum[12] += p_dA * (x.y - xn.x * nh.z);
+                        sum[13] += p_dA * (-x.x - xn.y * nh.z);
+                        sum[14] += p_dA * (du(0.0) - xn.z * nh.z);
+                        // K22 += w (I - n n')
+                        sum[15] += p_dA * (du(1.0) - nh.x * nh.x);
+                        sum[16] += p_dA * (du(0.0) - nh.x * nh.y);
+                        sum[17] += p_dA * (du(0.0) - nh.x * nh.z);
+                        sum[18] += p_dA * (du(1.0) - nh.y * nh.y);
+                        sum[19] += p_dA * (du(0.0) - nh.y * nh.z);
+                        sum[20] += p_dA * (du(1.0) - nh.z * nh.z);
+                        continue;
+                    }
+                    Du3 tk;
+                    if (reg) {
+                        // yes_contact!(::Regularized) (friction.jl:50-72)
+                        const Du3 vt = dvec_sub_vec_proj(rdot, nh);
+                        const Du m2 = ddot(vt, vt);
+                        Du3 T;
+                        if (m2.v < v_c * v_c) {
+                            T = (vt * (-mu_s)) / v_c;
+                        } else {
+                            const Du mg = dsqrt(m2);
+                            const Du mu = dclamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
+                            T = (vt * (-mu)) / mg;
+                        }
+                        tk = nh * p_dA + T * p_dA;
+                    } else {
+                        // normal_wrench_cop (normal.jl:17-34)
+                        tk = nh * p_dA;
+                        sum[6] += p_dA;
+                        sum[7] += p_dA * r.x; sum[8] += p_dA * r.y; sum[9] += p_dA * r.z;
+                    }
+                    const Du3 ta = dcross(r, tk);
+                    sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+                    sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
+                }
+            }
+#undef PVT
+        }
+        // ---- per (item, direction) reductions ---------------------------------------------------------------------
+        double flat[2 * NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { flat[k] = sum[k].v; flat[NS + k] = sum[k].d; }
+        constexpr int base = MODE == 0 ? kDaA : (MODE == 1 ? kDaB : kDaC);
+        accumulate_items<2 * NS>(g.dacc, key, active, work && n_trac_lane > 0, flat, base, kDaStride);
+    }
+}
+#undef PV
+#undef PD
+
+// symmetric 6x6 eigen-decomposition (cyclic Jacobi), column-major; one thread
+__device__ inline void dual_jacobi6(double *A, double *V, double *w) {
+    for (int i = 0; i < 36; ++i) V[i] = 0.0;
+    for (int i = 0; i < 6; ++i) V[7 * i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j)
+                if (i != j) off += A[i + 6 * j] * A[i + 6 * j]; else dia += A[7 * i] * A[7 * i];
+        if (off <= 1e-300 || off <= 1e-34 * dia) break;
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                const double apq = A[p + 6 * q];
+                if (apq == 0.0) continue;
+                const double theta = (A[7 * q] - A[7 * p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / __builtin_sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 6; ++k) {
+                    const double akp = A[k + 6 * p], akq = A[k + 6 * q];
+                    A[k + 6 * p] = cs * akp - sn * akq; A[k + 6 * q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double apk = A[p + 6 * k], aqk = A[q + 6 * k];
+                    A[p + 6 * k] = cs * apk - sn * aqk; A[q + 6 * k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double vkp = V[k + 6 * p], vkq = V[k + 6 * q];
+                    V[k + 6 * p] = cs * vkp - sn * vkq; V[k + 6 * q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 6; ++i) w[i] = A[7 * i];
+}
+
+// per (item, direction): cop, decompose_K! (friction.jl:96-117) with the Frechet derivative of K̄^{-1/2}, Delta (:130-131)
+__global__ void __launch_bounds__(64) k_dual_eig(DualArgs g) {
+    const int key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= g.n_items * g.n_dir) return;
+    const int item = key / g.n_dir;
+    const ItemRec *it = g.items + item;
+    if (it->model == PFC_REGULARIZED || g.icnt[4 * (size_t)item + 3] <= 0) return;
+    const double *a = g.dacc + (size_t)key * kDaStride;
+    double *res = g.dres + (size_t)key * kDrStride;
+    {
+        const Du ip = du(a[kDaA + 6], a[kDaA + 16]);
+        for (int k = 0; k < 3; ++k) {
+            const Du c = du(a[kDaA + 7 + k], a[kDaA + 17 + k]) / ip;
+            res[kDrCop + k] = c.v; res[kDrCop + 3 + k] = c.d;
+        }
+    }
+    const double k_bar = it->k_bar;
+    Du K[36];
+    {
+        const double *b = a + kDaB;
+        auto S = [&](int k) { return du(b[k], b[21 + k]) * k_bar; };
+        const int u11[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) {
+                K[i + 6 * j] = S(u11[i][j]);
+                K[i + 6 * (j + 3)] = S(6 + i + 3 * j);
+                K[(i + 3) + 6 * j] = S(6 + j + 3 * i);
+                K[(i + 3) + 6 * (j + 3)] = S(15 + u11[i][j]);
+            }
+    }
+    const Du t1 = (K[0] + K[7]) + K[14], t2 = (K[21] + K[28]) + K[35];
+    const Du s1 = du(1.0) / dsqrt(t1), s2 = du(1.0) / dsqrt(t2);
+    Du Sinv[6];
+    for (int k = 0; k < 3; ++k) { Sinv[k] = s1 * it->magic; Sinv[k + 3] = s2; }
+    double A[36], V[36], lam[6], dK[36];
+    for (int j = 0; j < 6; ++j)
+        for (int i = 0; i < 6; ++i) {
+            const Du kij = (i <= j) ? K[i + 6 * j] : K[j + 6 * i];
+            const Du kb = (Sinv[i] * kij) * Sinv[j];
+            A[i + 6 * j] = kb.v; dK[i + 6 * j] = kb.d;
+        }
+    dual_jacobi6(A, V, lam);
+    double mx = lam[0];
+    int imx = 0;
+    for (int k = 1; k < 6; ++k) if (lam[k] > mx) { mx = lam[k]; imx = k; }
+    double T[36], M[36];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 6; ++k) s += dK[i + 6 * k] * V[k + 6 * j];
+            T[i + 6 * j] = s;
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 6; ++k) s += V[k + 6 * i] * T[k + 6 * j];
+            M[i + 6 * j] = s;
+        }
+    const double floor_v = mx * 1.0e-16, dfloor = M[imx + 6 * imx] * 1.0e-16;
+    double f[6], fp[6], fx[6];
+    bool clamped[6];
+    for (int k = 0; k < 6; ++k) {
+        clamped[k] = !(lam[k] > floor_v);
+        const double x = clamped[k] ? floor_v : lam[k];
+        f[k] = 1.0 / __builtin_sqrt(x);
+        const double dfdx = -0.5 * f[k] / x;
+        fp[k] = clamped[k] ? 0.0 : dfdx;
+        fx[k] = clamped[k] ? dfdx * dfloor : 0.0;
+    }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double gij;
+            if (i == j) gij = fp[i];
+            else if (clamped[i] && clamped[j]) gij = 0.0;
+            else if (lam[i] != lam[j]) gij = (f[i] - f[j]) / (lam[i] - lam[j]);
+            else gij = fp[i];
+            M[i + 6 * j] *= gij;
+        }
+    for (int k = 0; k < 6; ++k) M[7 * k] += fx[k];
+    Du Kis[36];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 6; ++k) s += (V[i + 6 * k] * f[k]) * V[j + 6 * k];
+            Kis[i + 6 * j].v = s;
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 6; ++k) s += M[i + 6 * k] * V[j + 6 * k];
+            T[i + 6 * j] = s;
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 6; ++k) s += V[i + 6 * k] * T[k + 6 * j];
+            Kis[i + 6 * j].d = s;
+        }
+    const double *ds = g.d_s + (size_t)key * 6;
+    for (int i = 0; i < 6; ++i) {
+        Du acc = du(0.0);
+        for (int k = 0; k < 6; ++k) acc += Kis[i + 6 * k] * du(it->s[k], ds[k]);
+        const Du dl = Sinv[i] * acc;
+        res[kDrDelta + i] = dl.v; res[kDrDelta + 6 + i] = dl.d;
+        res[kDrSinv + i] = Sinv[i].v; res[kDrSinv + 6 + i] = Sinv[i].d;
+    }
+    for (int k = 0; k < 36; ++k) { res[kDrKis + k] = Kis[k].v; res[kDrKis + 36 + k] = Kis[k].d; }
+}
+
+// per (item, direction): total wrench and sdot partials (friction.jl:134-143, :77-81)
+__global__ void __launch_bounds__(64) k_dual_final(DualArgs g) {
+    const int key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= g.n_items * g.n_dir) return;
+    const int item = key / g.n_dir;
+    const ItemRec *it = g.items + item;
+    const double *a = g.dacc + (size_t)key * kDaStride;
+    double *ow = g.d_wrench + (size_t)key * 6, *os = g.d_sdot + (size_t)key * 6;
+    const bool contact = g.icnt[4 * (size_t)item + 3] > 0;
+    if (it->model == PFC_REGULARIZED) {
+        for (int k = 0; k < 6; ++k) { ow[k] = contact ? a[kDaA + 10 + k] : 0.0; os[k] = 0.0; }
+        return;
+    }
+    const double *ds = g.d_s + (size_t)key * 6;
+    const double tau_inv = 1.0 / it->tau;
+    if (!contact) {
+        for (int k = 0; k < 6; ++k) { ow[k] = 0.0; os[k] = -tau_inv * ds[k]; }
+        return;
+    }
+    const double *res = g.dres + (size_t)key * kDrStride;
+    Du wc[6];
+    for (int k = 0; k < 6; ++k) wc[k] = du(a[kDaC + k], a[kDaC + 6 + k]);
+    const Du3 cop = dmk(du(res[kDrCop], res[kDrCop + 3]), du(res[kDrCop + 1], res[kDrCop + 4]), du(res[kDrCop + 2], res[kDrCop + 5]));
+    const Du3 fang = dmk(wc[0], wc[1], wc[2]), flin = dmk(wc[3], wc[4], wc[5]);
+    const Du3 fang2 = fang + dcross(cop, flin);
+    Du sw[6];
+    for (int k = 0; k < 6; ++k) sw[k] = du(res[kDrSinv + k], res[kDrSinv + 6 + k]) * wc[k];
+    for (int i = 0; i < 6; ++i) {
+        Du acc = du(0.0);
+        for (int k = 0; k < 6; ++k) acc += du(res[kDrKis + i + 6 * k], res[kDrKis + 36 + i + 6 * k]) * sw[k];
+        const Du sd = (acc + du(it->s[i], ds[i])) * (-tau_inv);
+        os[i] = sd.d;
+    }
+    ow[0] = a[kDaA + 10] + fang2.x.d; ow[1] = a[kDaA + 11] + fang2.y.d; ow[2] = a[kDaA + 12] + fang2.z.d;
+    ow[3] = a[kDaA + 13] + flin.x.d; ow[4] = a[kDaA + 14] + flin.y.d; ow[5] = a[kDaA + 15] + flin.z.d;
+}

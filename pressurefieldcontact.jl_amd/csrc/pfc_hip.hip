@@ -724,7 +724,8 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // on N consecutive accumulator slots: single-lane atomics are issue-bound (one wave instruction per ~50 ns per CU,
 // MI355X guide 'Global float atomics'), a 37-lane one costs the same as a 1-lane one.
 template <int N>
-__device__ __forceinline__ void accumulate_items(double *acc, int item, bool listed, bool any, const double *v, int n0) {
+__device__ __forceinline__ void accumulate_items(double *acc, int item, bool listed, bool any, const double *v, int n0,
+                                                 int stride = kAccStride) {
     // listed: the lane holds a work-list entry (its item keys the run even if it contributes nothing, so empty
     // polygons do not chop an item's run into pieces); any: the lane has a contribution
     static_assert(N <= 64, "one value per lane");
@@ -745,7 +746,7 @@ __device__ __forceinline__ void accumulate_items(double *acc, int item, bool lis
             const double x = readlane_f64(tot[k], t);
             if (lane == k) mine = x;
         }
-        if (lane < N && mine != 0.0) unsafeAtomicAdd(&acc[(size_t)item_t * kAccStride + n0 + lane], mine);
+        if (lane < N && mine != 0.0) unsafeAtomicAdd(&acc[(size_t)item_t * stride + n0 + lane], mine);
     }
 }
 
@@ -1253,6 +1254,8 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
 }
 #undef PR
 
+#include "pfc_dual.h"
+
 // =================================================================================================================
 // bristle model: cop, patch stiffness, 6x6 eigen, friction pass, finalisation
 // =================================================================================================================
@@ -1687,6 +1690,7 @@ struct pfc_context {
     bool pending = false;
     hipStream_t last_stream = nullptr;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    DevBuf<double> dual_in, dual_acc, dual_res, dual_out;   // pfc_eval_dual
     long long last_undecided = 0;      // node pairs the Float32 broadphase left to the Float64 resolver
     long long last_tslots = 0;         // traction slots used by the last evaluation (>= traction points)
     hipEvent_t ev[EV_COUNT] = {};
@@ -2028,6 +2032,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     h->tail.release();
+    h->dual_in.release(); h->dual_acc.release(); h->dual_res.release(); h->dual_out.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -2306,6 +2311,56 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     std::memcpy(wrench, po, sizeof(double) * n * 6);
     std::memcpy(sdot, po + n * 6, sizeof(double) * n * 6);
     if (counts) std::memcpy(counts, po + out_d, sizeof(int) * n * 4);
+    return PFC_OK;
+}
+
+int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, const double *pose, const double *twist,
+                  const double *s, const double *d_pose, const double *d_twist, const double *d_s, double *wrench,
+                  double *sdot, double *d_wrench, double *d_sdot, int *counts) {
+    if (!h) return PFC_ERR_BAD_ARG;
+    if (n_dir < 1 || n_dir > 16) return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: n_dir must be in 1..16");
+    if (n_items > 0 && (!d_pose || !d_twist || !d_wrench || !d_sdot))
+        return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: null buffer");
+    // values, candidate list and per-item counters: the ordinary evaluation (the broadphase ignores partials,
+    // src/contact_algorithms_non_friction.jl:95)
+    int rc = pfc_eval(h, n_items, ins_ids, pose, twist, s, wrench, sdot, counts);
+    if (rc != PFC_OK || n_items == 0) return rc;
+    const size_t nk = (size_t)n_items * n_dir;
+    hipStream_t st = h->stream;
+    HIP_TRY(h, h->dual_in.ensure(nk * 36));
+    HIP_TRY(h, h->dual_acc.ensure(nk * kDaStride));
+    HIP_TRY(h, h->dual_res.ensure(nk * kDrStride));
+    HIP_TRY(h, h->dual_out.ensure(nk * 12));
+    double *dp = h->dual_in.p, *dt = dp + nk * 24, *dsd = dt + nk * 6;
+    HIP_TRY(h, hipMemcpyAsync(dp, d_pose, sizeof(double) * nk * 24, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dt, d_twist, sizeof(double) * nk * 6, hipMemcpyHostToDevice, st));
+    if (d_s) HIP_TRY(h, hipMemcpyAsync(dsd, d_s, sizeof(double) * nk * 6, hipMemcpyHostToDevice, st));
+    else HIP_TRY(h, hipMemsetAsync(dsd, 0, sizeof(double) * nk * 6, st));
+    HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
+    DualArgs a;
+    a.items = h->items.p; a.cand = h->cand.p; a.ccount = h->ctr.p; a.ccap = (int)h->ccap;
+    a.n_items = n_items; a.n_dir = n_dir; a.d_pose = dp; a.d_twist = dt; a.d_s = dsd; a.icnt = h->icnt.p;
+    a.dacc = h->dual_acc.p; a.dres = h->dual_res.p; a.d_wrench = h->dual_out.p; a.d_sdot = h->dual_out.p + nk * 6;
+    a.status = h->status.p;
+    const int cpw = 64 / n_dir;
+    const size_t n_cand = (size_t)h->stats[1];
+    const int grid = grid_for((n_cand + cpw - 1) / cpw, 1, 256 * 16);
+    const int kgrid = grid_for(nk, 64, 1 << 20);
+    const bool tt = h->any_tet_tet;
+    if (tt) hipLaunchKernelGGL((k_narrow_dual<0, true>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_narrow_dual<0, false>), dim3(grid), dim3(64), 0, st, a);
+    if (h->any_bristle) {
+        if (tt) hipLaunchKernelGGL((k_narrow_dual<1, true>), dim3(grid), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_narrow_dual<1, false>), dim3(grid), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_dual_eig, dim3(kgrid), dim3(64), 0, st, a);
+        if (tt) hipLaunchKernelGGL((k_narrow_dual<2, true>), dim3(grid), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_narrow_dual<2, false>), dim3(grid), dim3(64), 0, st, a);
+    }
+    hipLaunchKernelGGL(k_dual_final, dim3(kgrid), dim3(64), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(d_wrench, a.d_wrench, sizeof(double) * nk * 6, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(d_sdot, a.d_sdot, sizeof(double) * nk * 6, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
     return PFC_OK;
 }
 

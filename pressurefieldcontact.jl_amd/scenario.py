@@ -288,6 +288,40 @@ class MechanismScenario:
                                         sdot.ctypes.data_as(_dp), counts.ctypes.data_as(_ip)))
         return wrench, sdot, counts
 
+    def force_all_elastic_intersections_dual(self, pose, twist, s, d_pose, d_twist, d_s=None,
+                                             ins_ids: Optional[Sequence[int]] = None):
+        """The evaluation on Dual numbers (MechanismScenario.dual, src/mechanism_scenario.jl:187): values plus, for
+        each of n_dir seed directions, the partials.  d_pose (n, n_dir, 24), d_twist (n, n_dir, 6), d_s (n, n_dir, 6)
+        or None.  Returns (wrench, sdot, d_wrench (n, n_dir, 6), d_sdot (n, n_dir, 6), counts)."""
+        if not self._finalized:
+            raise RuntimeError("finalize the scenario first")
+        pose_a, pose_p = _d(pose)
+        n = pose_a.size // 24
+        tw_a, tw_p = _d(twist)
+        dp_a, dp_p = _d(d_pose)
+        if n == 0 or dp_a.size % (24 * n) != 0:
+            raise ValueError("d_pose must be (n, n_dir, 24)")
+        n_dir = dp_a.size // (24 * n)
+        dt_a, dt_p = _d(d_twist)
+        if tw_a.size != 6 * n or dt_a.size != 6 * n * n_dir:
+            raise ValueError("twist must be (n, 6) and d_twist (n, n_dir, 6)")
+        s_p = ds_p = id_p = None
+        if s is not None:
+            s_a, s_p = _d(s)
+        if d_s is not None:
+            ds_a, ds_p = _d(d_s)
+            if ds_a.size != 6 * n * n_dir:
+                raise ValueError("d_s must be (n, n_dir, 6)")
+        if ins_ids is not None:
+            id_a, id_p = _i(ins_ids)
+        wrench = np.zeros((n, 6)); sdot = np.zeros((n, 6)); counts = np.zeros((n, 4), dtype=np.int32)
+        dw = np.zeros((n, n_dir, 6)); dsd = np.zeros((n, n_dir, 6))
+        self._check(_lib.lib().pfc_eval_dual(self._h, n, n_dir, id_p, pose_p, tw_p, s_p, dp_p, dt_p, ds_p,
+                                             wrench.ctypes.data_as(_dp), sdot.ctypes.data_as(_dp),
+                                             dw.ctypes.data_as(_dp), dsd.ctypes.data_as(_dp),
+                                             counts.ctypes.data_as(_ip)))
+        return wrench, sdot, dw, dsd, counts
+
     def scatter_generalized(self, wrench, x_w_r2, body_1, body_2, jac, scene=None, n_scene: int = 1):
         """addGeneralizedForcesThirdLaw! for all items (non_friction.jl:267-286) on the device.
         wrench (n,6); x_w_r2 (n,12) = R col-major + t; body_1/body_2 (n,) body ids (-1: no Jacobian);

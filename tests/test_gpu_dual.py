@@ -1,0 +1,106 @@
+"""pfc_eval_dual: the HIP Dual-number path against the Dual oracle (oracle/pfc_oracle_dual.cpp, itself
+pinned by central differences in tests/test_oracle_dual.py).  Tolerances: 1e-6 relative on the wrench partials
+(north_star's Float64 tolerance); the partials of sdot go through K̄^{-1/2} and inherit its conditioning, so they are
+compared at 1e-5 of the largest partial of the item (values of sdot themselves are only reproducible to ~1e-4 on
+sliver patches, tests/test_gpu_scale.py)."""
+import numpy as np
+import pytest
+
+from helpers import oracle_ins, oracle_meshes
+from test_oracle_dual import tangents
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(pfc, O, w, n_dir, seed, wr_tol=1e-6, sd_tol=1e-5, zero_s=False):
+    rng = np.random.default_rng(seed)
+    n = w.n_items
+    if not zero_s:
+        w.s[:] = rng.standard_normal((n, 6)) * 1e-3
+    dq = rng.standard_normal((n, n_dir, 6)) * np.array([1, 1, 1, 0.05, 0.05, 0.05])
+    d_twist = rng.standard_normal((n, n_dir, 6)) * np.array([1, 1, 1, 0.1, 0.1, 0.1])
+    d_s = rng.standard_normal((n, n_dir, 6)) * 1e-3
+    d_pose = np.zeros((n, n_dir, 24))
+    for k in range(n):
+        R0 = w.pose[k][:9].reshape(3, 3, order="F"); t0 = w.pose[k][9:12]
+        d_pose[k] = tangents(R0, t0, dq[k])
+    m = pfc.configs.build_scenario(w)
+    wr, sd, dw, dsd, counts = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, d_pose, d_twist, d_s, w.ins_ids)
+    wr0, sd0, counts0 = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    # same value path (atomic summation order differs between two launches: rounding-level differences only)
+    np.testing.assert_allclose(wr, wr0, rtol=1e-11, atol=1e-11 * np.abs(wr0).max())
+    np.testing.assert_allclose(sd, sd0, rtol=1e-7, atol=1e-7 * max(np.abs(sd0).max(), 1e-300))
+    assert np.array_equal(counts, counts0)
+    m.close()
+    om = oracle_meshes(w)
+    n_contact = 0
+    for k in range(n):
+        c = w.instructions[int(w.ins_ids[k])]
+        st, rw, rs, rdw, rdsd = O.evaluate_dual(om[c.id_1], om[c.id_2], oracle_ins(pfc, c), w.pose[k], w.twist[k],
+                                                w.s[k], d_pose[k], d_twist[k], d_s[k])
+        assert st == 0
+        n_contact += counts[k, 3] > 0
+        sw = max(np.abs(rdw).max(), 1e-300)
+        assert np.abs(dw[k] - rdw).max() <= wr_tol * sw, (k, np.abs(dw[k] - rdw).max() / sw)
+        ss = max(np.abs(rdsd).max(), 1e-300)
+        assert np.abs(dsd[k] - rdsd).max() <= sd_tol * ss, (k, np.abs(dsd[k] - rdsd).max() / ss)
+    assert n_contact > 0
+    return n_contact
+
+
+def test_dual_regularized_c4(pfc, O):
+    w = pfc.configs.c2_box_on_plane(24, montecarlo=True)
+    assert run_case(pfc, O, w, 6, 1) == 24
+
+
+def test_dual_bristle_blob_tool(pfc, O):
+    w = pfc.configs.c3_blob_tool(12, seed=3, n_div_blob=6, n_div_tool=4)
+    run_case(pfc, O, w, 6, 2)
+
+
+@pytest.mark.parametrize("n_dir", [1, 3, 7, 12, 16])
+def test_dual_direction_counts(pfc, O, n_dir):
+    w = pfc.configs.c3_blob_tool(5, seed=4, n_div_blob=5, n_div_tool=3)
+    run_case(pfc, O, w, n_dir, 10 + n_dir)
+
+
+def test_dual_tet_tet_and_mixed(pfc, O):
+    for model in ("regularized", "bristle"):
+        w = pfc.configs.vol_vol(6, n_div=3, model=model)
+        run_case(pfc, O, w, 6, 5)
+
+
+def test_dual_c1_boxes(pfc, O):
+    w = pfc.configs.c1_boxes()
+    run_case(pfc, O, w, 6, 6)
+
+
+def test_dual_linear_in_seed(pfc):
+    """Partials are linear in the seed: a Dual evaluation with seeds (a, b, a + 2b) returns d3 = d1 + 2 d2."""
+    w = pfc.configs.c3_blob_tool(4, seed=8, n_div_blob=6, n_div_tool=4)
+    rng = np.random.default_rng(9)
+    n = w.n_items
+    w.s[:] = rng.standard_normal((n, 6)) * 1e-3
+    dq = rng.standard_normal((n, 2, 6)) * 0.1
+    d_pose = np.zeros((n, 3, 24)); d_twist = np.zeros((n, 3, 6)); d_s = np.zeros((n, 3, 6))
+    for k in range(n):
+        R0 = w.pose[k][:9].reshape(3, 3, order="F"); t0 = w.pose[k][9:12]
+        d_pose[k, :2] = tangents(R0, t0, dq[k])
+    d_twist[:, :2] = rng.standard_normal((n, 2, 6)); d_s[:, :2] = rng.standard_normal((n, 2, 6)) * 1e-3
+    for a in (d_pose, d_twist, d_s):
+        a[:, 2] = a[:, 0] + 2 * a[:, 1]
+    m = pfc.configs.build_scenario(w)
+    _, _, dw, dsd, _ = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, d_pose, d_twist, d_s, w.ins_ids)
+    m.close()
+    np.testing.assert_allclose(dw[:, 2], dw[:, 0] + 2 * dw[:, 1], rtol=1e-9, atol=1e-9 * np.abs(dw).max())
+    np.testing.assert_allclose(dsd[:, 2], dsd[:, 0] + 2 * dsd[:, 1], rtol=1e-7, atol=1e-7 * np.abs(dsd).max())
+
+
+def test_dual_bad_arguments(pfc):
+    w = pfc.configs.c1_boxes()
+    m = pfc.configs.build_scenario(w)
+    n = w.n_items
+    with pytest.raises(pfc._lib.PFCError):
+        m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, np.zeros((n, 17, 24)), np.zeros((n, 17, 6)), None,
+                                               w.ins_ids)
+    m.close()
