@@ -162,7 +162,11 @@ int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, con
                             double *f_out);
 
 /* Options: "debug" (1: keep per-pair clip counts and materialise traction points of every item so that the
- * pfc_debug_* calls work), "profile" (1: bracket each stage with HIP events), "max_levels" (0 = automatic). */
+ * pfc_debug_* calls work), "profile" (1: bracket each stage with HIP events), "max_levels" (0 = automatic),
+ * "bfs_levels" (-1 = automatic: level-synchronous seed expansion only until there are >= 2048 seed pairs),
+ * "graph" (1 = capture the launch sequence into a hipGraph per evaluation shape and replay it; default 1),
+ * "no_filter" (1 = run the whole broadphase in the exact Float64 kernel instead of the Float32 filter + Float64
+ * resolver; same candidate set, for A/B checks). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);
 
 /* Totals of the last checked evaluation: out[0..7] = {node tests, candidate pairs, non-empty pairs, traction
