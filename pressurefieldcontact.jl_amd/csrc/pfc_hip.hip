@@ -693,12 +693,16 @@ struct NpArgs {
     const int *ccount;
     int ccap;
     double *acc;
-    const double *res; // per-item derived results (PASS 1)
-    double *rec;       // moment records (PASS 0, bristle)
+    double *rec;       // moment records (bristle)
     int *rcount;
     int rcap;
     int *icnt;
     int *clip_n;     // per candidate, or null
+    // clipped polygons of bristle items, kept for the friction pass (k_fric): SoA [field][slot], slot < pcap
+    int *poly_item;  // item | n_poly << 28
+    double *poly;    // 34 fields: n̂ 3, centroid 3, ϵ_r² 4, vertices 8 x 3 (frame r²)
+    int *pcount;
+    int pcap;
     TracSoA trac;
     int *tcount;
     int tcap;
@@ -750,15 +754,16 @@ __device__ __forceinline__ void accumulate_items(double *acc, int item, bool lis
     }
 }
 
-// PASS 0: everything up to the per-item sums (regularized friction fused; bristle: normal wrench + patch moments).
-// PASS 1: bristle items only, after k_eig: the same gather / clip / quadrature is recomputed (bit-identical traction
-//         points) and calc_spatial_bristle_force (friction.jl:171-201) is integrated.  Recomputing is cheaper than
-//         materialising the TractionCache: 9 scattered 8-byte stores per traction point cost 2.7x the whole
-//         clip + quadrature (measured), and the list is only kept in debug mode (pfc_debug_tractions).
+// Everything up to the per-item sums (regularized friction fused; bristle: normal wrench + patch moments).  For bristle
+// items the clipped polygon of every contributing pair is kept (34 doubles, SoA by compacted slot: every store
+// instruction of a wave writes consecutive doubles) so that the friction pass after k_eig (k_fric) re-integrates the
+// bit-identical traction points without gathering and clipping again.  Materialising the TractionCache itself was
+// measured at 2.7x the whole clip + quadrature (9 scattered 8-byte stores per point, ~12 points per polygon); it is only
+// kept in debug mode (pfc_debug_tractions).
 //
 // TT: the scenario contains tet-tet instructions (non_friction.jl:166-194); compiled out otherwise so that the common
 // tri-tet-only scenario does not pay the registers of the plane / tet intersection.
-template <int PASS, bool TT>
+template <bool TT>
 __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
     __shared__ double poly[8 * 4 * kNpBlock];
     const int lane = threadIdx.x;
@@ -779,9 +784,8 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         const TetRec *tp = it->tet + cw.b;
         const int nq = it->nq;
         const bool reg = it->model == PFC_REGULARIZED;
-        const bool materialise = PASS == 0 && active && g.debug;
-        // PASS 1 skips regularized items and items without contact
-        const bool work = active && (PASS == 0 || (!reg && g.icnt[4 * (size_t)cw.item + 3] > 0));
+        const bool materialise = active && g.debug;
+        const bool work = active;
         int n_poly = 0, rbase = 0;
         V3 nh = mk3(0.0, 0.0, 0.0);
         // ==== phase 1 (divergent): gather, transform to tet coordinates, clip ========================================
@@ -998,7 +1002,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 if (n >= 3) nh = nh_in;
             }
         }
-        if (PASS == 0 && g.clip_n && active) g.clip_n[idx] = n_poly;
+        if (g.clip_n && active) g.clip_n[idx] = n_poly;
         STAMP(t2);
         // ==== phase 2 (wave-uniform): reserve a contiguous run of traction slots for the whole wave ================
         // A lane with an n-gon owns n * nq consecutive slots, so the traction points of a wave (and, because the
@@ -1006,7 +1010,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         // wave-uniformly with one atomic per wave instead of one per lane.
         const int slots = (materialise && n_poly >= 3) ? n_poly * nq : 0;
         int tbase = 0;
-        if (PASS == 0 && g.debug) {
+        if (g.debug) {
             int incl = seg_incl_scan(slots);
             const int tot = __shfl(incl, 63, 64);
             int base = 0;
@@ -1059,13 +1063,6 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             const V3 w = ld3(it->w), vl = ld3(it->v);
             const double chi = it->chi, Ebar = it->Ebar;
             const double v_c = it->v_c, mu_s = it->mu_s, mu_d = it->mu_d;
-            V3 cop = mk3(0.0, 0.0, 0.0), Da = cop, Dl = cop;
-            double tau = 0.0, k_bar = 0.0;
-            if (PASS == 1) {
-                const double *res = g.res + (size_t)cw.item * kResStride;
-                cop = ld3(res + kResCop); Da = ld3(res + kResDelta); Dl = ld3(res + kResDelta + 3);
-                tau = it->tau; k_bar = it->k_bar;
-            }
             const bool store = materialise && (tbase + slots <= g.tcap);
             if (materialise && !store) atomicOr(g.status, kStTracOvf);
             int tpos = tbase;
@@ -1106,27 +1103,6 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         g.trac.dA[tpos] = dA; g.trac.p[tpos] = p;
                         ++tpos;
                     }
-                    if (PASS == 1) {
-                        // calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48)
-                        V3 x = r - cop;
-                        V3 del = Dl + cross(Da, x);
-                        V3 Ts = (del + rdot * tau) * (-k_bar);
-                        Ts = vec_sub_vec_proj(Ts, nh);
-                        double m2 = dot(Ts, Ts);
-                        V3 T;
-                        if (m2 < mu_s * mu_s) {
-                            T = Ts;
-                        } else {
-                            double mg = __builtin_sqrt(m2);
-                            double mu = clamped_piecewise(mg, 2 * mu_s, 3 * mu_s, mu_s, mu_d);
-                            T = (Ts * mu) / mg;
-                        }
-                        V3 Tc = T * p_dA;
-                        V3 ta = cross(x, Tc);
-                        sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
-                        sum[3] += Tc.x; sum[4] += Tc.y; sum[5] += Tc.z;
-                        continue;
-                    }
                     V3 tk;
                     if (reg) {
                         // yes_contact!(::Regularized) (friction.jl:50-72) fused
@@ -1163,10 +1139,28 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         STAMP(t4);
         // ==== phase 4 (wave-uniform): per-item reductions =============================================================
         const bool contributed = work && n_trac_lane > 0;
-        if (PASS == 1) {
-            accumulate_items<6>(g.acc, cw.item, active, contributed, sum, kAccFric);
-        } else {
+        {
             accumulate_items<10>(g.acc, cw.item, active, contributed, sum, 0);
+            // ---- keep the polygon of contributing bristle pairs for k_fric -------------------------------------------
+            if (__any(contributed && !reg)) {
+                const bool keep = contributed && !reg;
+                const unsigned long long km = __ballot(keep);
+                int base = 0;
+                if (lane == 0) base = atomicAdd(g.pcount, __popcll(km));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int slot = base + __popcll(km & ((1ull << lane) - 1ull));
+                if (keep && slot < g.pcap) {      // pcap >= ccap: cannot overflow
+                    const size_t P = (size_t)g.pcap;
+                    double *o = g.poly + slot;
+                    g.poly_item[slot] = (int)((unsigned)cw.item | ((unsigned)n_poly << 28));
+                    o[0] = nh.x; o[P] = nh.y; o[2 * P] = nh.z;
+                    o[3 * P] = cen.x; o[4 * P] = cen.y; o[5 * P] = cen.z;
+                    o[6 * P] = tp->epsr[0]; o[7 * P] = tp->epsr[1]; o[8 * P] = tp->epsr[2]; o[9 * P] = tp->epsr[3];
+                    for (int k = 0; k < n_poly; ++k) {
+                        o[(10 + 3 * k) * P] = PR(k, 0); o[(11 + 3 * k) * P] = PR(k, 1); o[(12 + 3 * k) * P] = PR(k, 2);
+                    }
+                }
+            }
             if (__any(contributed && !reg)) {
                 // ---- patch-stiffness moments of the bristle model, one record per run of an item in this wave ----
                 const bool cb = contributed && !reg;
@@ -1253,6 +1247,100 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
     }
 }
 #undef PR
+
+// Bristle friction pass (after k_eig): calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48)
+// over the polygons k_narrow kept.  One lane per kept polygon, every load is a coalesced read of consecutive slots;
+// the fan / quadrature arithmetic is the one of k_narrow, so the traction points are bit-identical.
+struct FricArgs {
+    const ItemRec *items;
+    const int *poly_item;
+    const double *poly;
+    const int *pcount;
+    int pcap;
+    const double *res;
+    double *acc;
+};
+__global__ void __launch_bounds__(64) k_fric(FricArgs g) {
+    const int lane = threadIdx.x;
+    int n_p = *g.pcount;
+    if (n_p > g.pcap) n_p = g.pcap;
+    const size_t P = (size_t)g.pcap;
+    const int stride = gridDim.x * 64;
+    const int n_round = (n_p + stride - 1) / stride;
+    for (int rd = 0; rd < n_round; ++rd) {
+        const int idx = rd * stride + blockIdx.x * 64 + lane;
+        const bool active = idx < n_p;
+        double sum[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sum[k] = 0.0;
+        int item = 0;
+        bool contributed = false;
+        if (active) {
+            const unsigned pk = (unsigned)g.poly_item[idx];
+            item = (int)(pk & 0x0FFFFFFFu);
+            const int n = (int)(pk >> 28);
+            const ItemRec *it = g.items + item;
+            const double *o = g.poly + idx;
+            const V3 nh = mk3(o[0], o[P], o[2 * P]);
+            const V3 cen = mk3(o[3 * P], o[4 * P], o[5 * P]);
+            const double er0 = o[6 * P], er1 = o[7 * P], er2 = o[8 * P], er3 = o[9 * P];
+            const int nq = it->nq;
+            const V3 w = ld3(it->w), vl = ld3(it->v);
+            const double chi = it->chi, Ebar = it->Ebar, mu_s = it->mu_s, mu_d = it->mu_d;
+            const double tau = it->tau, k_bar = it->k_bar;
+            const double *res = g.res + (size_t)item * kResStride;
+            const V3 cop = ld3(res + kResCop), Da = ld3(res + kResDelta), Dl = ld3(res + kResDelta + 3);
+            V3 v2 = mk3(o[(10 + 3 * (n - 1)) * P], o[(11 + 3 * (n - 1)) * P], o[(12 + 3 * (n - 1)) * P]);
+            for (int k = 0; k < n; ++k) {
+                const V3 v1 = v2;
+                v2 = mk3(o[(10 + 3 * k) * P], o[(11 + 3 * k) * P], o[(12 + 3 * k) * P]);
+                const double area = triangle_area(v1, v2, cen, nh);
+                if (!(0.0 < area)) continue;
+                for (int q = 0; q < nq; ++q) {
+                    double q0, q1, q2, qw;
+                    if (nq == 1) {
+                        q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
+                    } else {
+                        const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
+                        q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
+                        qw = 0.33333333333333331483;
+                    }
+                    const V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
+                                     (v1.z * q0 + v2.z * q1) + cen.z * q2);
+                    double eq = __builtin_fma(er0, r.x, er3);
+                    eq = __builtin_fma(er1, r.y, eq);
+                    eq = __builtin_fma(er2, r.z, eq);
+                    const V3 rdot = vl + cross(w, r);
+                    const double ee = -dot(mk3(er0, er1, er2), rdot);
+                    const double damp = fmax(0.0, 1.0 + chi * ee);
+                    const double p = eq * Ebar * damp;
+                    const double dA = qw * area;
+                    if (!(0.0 < p)) continue;
+                    contributed = true;
+                    const double p_dA = p * dA;
+                    const V3 x = r - cop;
+                    const V3 del = Dl + cross(Da, x);
+                    V3 Ts = (del + rdot * tau) * (-k_bar);
+                    Ts = vec_sub_vec_proj(Ts, nh);
+                    const double m2 = dot(Ts, Ts);
+                    V3 T;
+                    if (m2 < mu_s * mu_s) {
+                        T = Ts;
+                    } else {
+                        const double mg = __builtin_sqrt(m2);
+                        const double mu = clamped_piecewise(mg, 2 * mu_s, 3 * mu_s, mu_s, mu_d);
+                        T = (Ts * mu) / mg;
+                    }
+                    const V3 Tc = T * p_dA;
+                    const V3 ta = cross(x, Tc);
+                    sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+                    sum[3] += Tc.x; sum[4] += Tc.y; sum[5] += Tc.z;
+                }
+            }
+        }
+        accumulate_items<6>(g.acc, item, active, contributed, sum, kAccFric);
+    }
+}
 
 #include "pfc_dual.h"
 
@@ -1691,6 +1779,8 @@ struct pfc_context {
     hipStream_t last_stream = nullptr;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     DevBuf<double> dual_in, dual_acc, dual_res, dual_out;   // pfc_eval_dual
+    DevBuf<int> poly_item;                                  // kept polygons of bristle pairs (k_narrow -> k_fric)
+    DevBuf<double> poly;
     long long last_undecided = 0;      // node pairs the Float32 broadphase left to the Float64 resolver
     long long last_tslots = 0;         // traction slots used by the last evaluation (>= traction points)
     hipEvent_t ev[EV_COUNT] = {};
@@ -1769,6 +1859,10 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     if ((e = h->frontier[1].ensure(f)) != hipSuccess) return e;
     if ((e = h->cand.ensure(c)) != hipSuccess) return e;
     if ((e = h->clip_n.ensure(c)) != hipSuccess) return e;
+    if (h->any_bristle) {
+        if ((e = h->poly_item.ensure(c)) != hipSuccess) return e;
+        if ((e = h->poly.ensure(c * 34)) != hipSuccess) return e;
+    }
     if ((e = h->trac_item.ensure(t)) != hipSuccess) return e;
     if ((e = h->trac_d.ensure(t * 8)) != hipSuccess) return e;
     if ((e = h->tail.ensure((size_t)h->max_levels + 40)) != hipSuccess) return e;
@@ -1814,6 +1908,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
     int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2, *rcount = h->ctr.p + 3;
     int *ucount = h->ctr.p + 4, *next_seed2 = h->ctr.p + 5, *fcount = h->ctr.p + 6;
+    int *pcount = h->ctr.p + levels + 8;   // after the per-level frontier counts
     HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(int) * ((size_t)levels + 12), st));
     HIP_TRY(h, hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * 4, st));
 #ifdef PFC_STAMPS
@@ -1873,10 +1968,11 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     np.icnt = h->icnt.p; np.clip_n = h->opt_debug ? h->clip_n.p : nullptr; np.trac = trac_view(h);
     np.tcount = tcount; np.tcap = (int)h->tcap; np.status = h->status.p; np.debug = h->opt_debug;
     np.stamps = h->stamps.p;
-    np.res = h->res.p; np.rec = h->rec.p; np.rcount = rcount; np.rcap = (int)h->rcap;
+    np.rec = h->rec.p; np.rcount = rcount; np.rcap = (int)h->rcap;
+    np.poly_item = h->poly_item.p; np.poly = h->poly.p; np.pcount = pcount; np.pcap = (int)h->ccap;
     const int np_grid = grid_for(h->ccap, kNpBlock, 256 * 16);
-    if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<0, true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
-    else hipLaunchKernelGGL((k_narrow<0, false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+    if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+    else hipLaunchKernelGGL((k_narrow<false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_NP], st));
 
     BrArgs br;
@@ -1888,8 +1984,10 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         sh.rec = h->rec.p; sh.rcount = rcount; sh.rcap = (int)h->rcap; sh.acc = h->acc.p;
         hipLaunchKernelGGL(k_shift, dim3(grid_for(h->rcap, 64, 2048)), dim3(64), 0, st, sh);
         hipLaunchKernelGGL(k_eig, dim3(grid_for(n_items, 64, 1 << 20)), dim3(64), 0, st, br);
-        if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<1, true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
-        else hipLaunchKernelGGL((k_narrow<1, false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        FricArgs fr;
+        fr.items = h->items.p; fr.poly_item = h->poly_item.p; fr.poly = h->poly.p; fr.pcount = pcount;
+        fr.pcap = (int)h->ccap; fr.res = h->res.p; fr.acc = h->acc.p;
+        hipLaunchKernelGGL(k_fric, dim3(grid_for(h->ccap, 64, 256 * 16)), dim3(64), 0, st, fr);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BR], st));
     hipLaunchKernelGGL(k_final, dim3(grid_for(n_items, 128, 1 << 20)), dim3(128), 0, st, br);
@@ -2032,6 +2130,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     h->tail.release();
+    h->poly_item.release(); h->poly.release();
     h->dual_in.release(); h->dual_acc.release(); h->dual_res.release(); h->dual_out.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
