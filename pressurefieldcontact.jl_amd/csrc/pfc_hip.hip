@@ -346,13 +346,85 @@ __device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, boo
     return verdict;
 }
 
-// One WORKGROUP (4 waves) per seed, one shared LDS stack: a seed of the 2 048-pose C3 batch is ~45 k node tests, i.e.
-// ~700 dependent iterations for a single wave -- that serial chain, not ALU or memory, bounded the one-wave-per-seed
-// version (every variant of its inner loop ran 2.0 ms).  Four waves pop 256 pairs per iteration from the same stack.
 constexpr int kDfsBlock = 256;
 constexpr int kDfsWaves = kDfsBlock / 64;
 constexpr int kDfsStack32 = 4096;   // node pairs per workgroup (32 KiB)
 constexpr int kDfsOut32 = 1280;     // staged candidates per workgroup (10 KiB)
+
+// The exact Float64 BB_BB_intersect (general composition, src/obb/bb_intersection.jl:2-74) of the node pairs the
+// Float32 test leaves undecided (~2e-5 of all node tests), evaluated COOPERATIVELY: 16 lanes per pair.  Lanes 0..8
+// form one entry each of R_a' R_a_b, then of R_tot = (R_a' R_a_b) R_b (lanes 9..11 the translation), through LDS, and
+// lanes 0..14 test one of the 15 axes each.  Every entry / axis is the same expression, in the same order, as in
+// bb_compose() / sat15(), so the boolean is the reference's bit for bit, and the per-lane register need is a few
+// dozen instead of the ~220 of the one-lane-per-pair Float64 test (which cost the kernel a third of its occupancy
+// when inlined, and as a no-inline call needed scratch).  xs: 33 doubles per 16-lane group.
+__device__ __forceinline__ void exact_pairs_coop(const ItemRec *it, const double *pose, const int2 *und_l, int n_def,
+                                                 double *xs, int *und_v, int tid) {
+    const int grp = tid >> 4, sub = tid & 15;
+    double *T = xs + grp * 33, *tt = T + 9, *R = T + 12, *aR = T + 21, *t = T + 30;
+    for (int c0 = 0; c0 < n_def; c0 += kDfsBlock / 16) {
+        const int j = c0 + grp;
+        const bool valid = j < n_def;
+        int2 e = make_int2(0, 0);
+        if (valid) e = und_l[j];
+        const NodeRec *na = it->nodes1 + node_index(e.x), *nb = it->nodes2 + node_index(e.y);
+        if (valid && sub < 9) {
+            const int i = sub % 3, jj = sub / 3;
+            const double r0 = na->R[3 * i], r1 = na->R[3 * i + 1], r2 = na->R[3 * i + 2];
+            T[i + 3 * jj] = (r0 * pose[3 * jj] + r1 * pose[3 * jj + 1]) + r2 * pose[3 * jj + 2];
+        } else if (valid && sub < 12) {
+            const int i = sub - 9;
+            const double r0 = na->R[3 * i], r1 = na->R[3 * i + 1], r2 = na->R[3 * i + 2];
+            const double nt = ((-r0) * na->c[0] + (-r1) * na->c[1]) + (-r2) * na->c[2];
+            tt[i] = ((r0 * pose[9] + r1 * pose[10]) + r2 * pose[11]) + nt;
+        }
+        __syncthreads();
+        if (valid && sub < 9) {
+            const int i = sub % 3, jj = sub / 3;
+            const double r = (T[i] * nb->R[3 * jj] + T[i + 3] * nb->R[3 * jj + 1]) + T[i + 6] * nb->R[3 * jj + 2];
+            R[i + 3 * jj] = r;
+            aR[i + 3 * jj] = __builtin_fabs(r) + 1.0e-14;
+        } else if (valid && sub < 12) {
+            const int i = sub - 9;
+            t[i] = ((T[i] * nb->c[0] + T[i + 3] * nb->c[1]) + T[i + 6] * nb->c[2]) + tt[i];
+        }
+        __syncthreads();
+        bool sep = false;
+        if (valid && sub < 15) {
+            const double ea[3] = {na->e[0], na->e[1], na->e[2]}, eb[3] = {nb->e[0], nb->e[1], nb->e[2]};
+#define R_(i, j) R[(i) + 3 * (j)]
+#define AR_(i, j) aR[(i) + 3 * (j)]
+            if (sub < 3) {          // face test 1/2 (:29-32)
+                const int i = sub;
+                const double rb = (AR_(i, 0) * eb[0] + AR_(i, 1) * eb[1]) + AR_(i, 2) * eb[2];
+                sep = (ea[i] + rb) < __builtin_fabs(t[i]);
+            } else if (sub < 6) {   // face test 2/2 (:35-38)
+                const int jj = sub - 3;
+                const double tl = __builtin_fabs((R_(0, jj) * t[0] + R_(1, jj) * t[1]) + R_(2, jj) * t[2]);
+                const double ra = (AR_(0, jj) * ea[0] + AR_(1, jj) * ea[1]) + AR_(2, jj) * ea[2];
+                sep = (ra + eb[jj]) < tl;
+            } else {                // cross tests (:56-72): row m of the cross block, column jj
+                const int m = (sub - 6) / 3, jj = (sub - 6) % 3;
+                const int u = (m + 1) % 3, v = (m + 2) % 3;
+                const int p100 = jj == 0 ? 1 : 0, p221 = jj == 2 ? 1 : 2;
+                const double tl = __builtin_fabs(t[v] * R_(u, jj) - t[u] * R_(v, jj));
+                // sat15 writes the two products of ra with the lower axis index first; a + b == b + a exactly
+                const double ra = ea[u] * AR_(v, jj) + ea[v] * AR_(u, jj);
+                const double rb = eb[p100] * AR_(m, p221) + eb[p221] * AR_(m, p100);
+                sep = (ra + rb) < tl;
+            }
+#undef R_
+#undef AR_
+        }
+        const unsigned long long ms = __ballot(sep);
+        if (valid && sub == 0) und_v[j] = ((ms >> ((tid & 63) & ~15)) & 0xFFFFull) ? 0 : 1;
+        __syncthreads();
+    }
+}
+
+// One WORKGROUP (4 waves) per seed, one shared LDS stack: a seed of the 2 048-pose C3 batch is ~45 k node tests, i.e.
+// ~700 dependent iterations for a single wave -- that serial chain, not ALU or memory, bounded the one-wave-per-seed
+// version (every variant of its inner loop ran 2.0 ms).  Four waves pop 256 pairs per iteration from the same stack.
 
 // one ticket per workgroup: thread 0 takes it, LDS broadcast between two barriers
 __device__ __forceinline__ int next_ticket_block(int *ctr, int *slot) {
@@ -385,71 +457,72 @@ __global__ void __launch_bounds__(kDfsBlock) k_bp_dfs32(Dfs32Args g) {
     __shared__ int2 stk[kDfsStack32];
     __shared__ int2 ob[kDfsOut32];
     __shared__ int s_cnt[kDfsWaves][2];   // per wave: candidates, pushed pairs of the current iteration
-    __shared__ int s_seed, s_base;
+    __shared__ int2 und_l[kDfsBlock];     // node pairs the Float32 test left undecided in the last iteration
+    __shared__ int und_v[kDfsBlock];      // their exact verdicts
+    __shared__ double xs[(kDfsBlock / 16) * 33];
+    __shared__ int s_seed, s_base, s_def;
+    __shared__ double s_pose[12];         // R_a_b (9, column-major), t_a_b (3) of the current seed's item
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n_seed = *g.n_seed;
     if (n_seed > g.seed_cap) n_seed = g.seed_cap;
     // one ticket per workgroup (same loop shape as k_bp_dfs: condition in the for header, no break)
     for (int sd = next_ticket_block(g.next_seed, &s_seed); sd < n_seed; sd = next_ticket_block(g.next_seed, &s_seed)) {
-        const WorkRec s = g.seeds[sd];
-        const int item = s.item;
+        const WorkRec s = g.seeds[__builtin_amdgcn_readfirstlane(sd)];
+        const int item = __builtin_amdgcn_readfirstlane(s.item);   // uniform: scalar loads of the pose below
         const ItemRec *it = g.items + item;
-        double R12[9], t12[3];
-        float R12f[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { R12[k] = it->R12[k]; R12f[k] = (float)R12[k]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) t12[k] = it->t12[k];
+        // the item's pose lives in LDS (broadcast reads inside the iteration) rather than in 33 registers that would
+        // stay live across the call of the exact test
+        if (tid < 9) s_pose[tid] = it->R12[tid];
+        else if (tid < 12) s_pose[tid] = it->t12[tid - 9];
         const NodeF *n1 = it->nf1, *n2 = it->nf2;
-        int sp = 1, n_out = 0, n_test = 0, n_cand = 0;
+        int sp = 1, n_out = 0, n_test = 0, n_cand = 0, n_def = 0, n_und = 0;
         if (tid == 0) {
             // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
             const int sa = (it->nodes1[s.a].leaf != kInternal) ? ~s.a : s.a;
             const int sb = (it->nodes2[s.b].leaf != kInternal) ? ~s.b : s.b;
             stk[0] = make_int2(sa, sb);
+            s_def = 0;
         }
         __syncthreads();
         // every workgroup must reach its exit: the iteration guard stops a corrupt (cyclic) tree from spinning forever
-        for (int guard = 0; sp > 0 && guard < (1 << 22); ++guard) {
-            // pop up to 256 pairs, but never more than the stack can take back as children (4 per pair)
+        for (int guard = 0; (sp > 0 || n_def > 0) && guard < (1 << 22); ++guard) {
+            // Either settle the pairs the previous iteration left undecided (exact Float64 test; their children still
+            // have the room that iteration reserved for them), or pop up to 256 pairs, but never more than the stack can
+            // take back as children (4 per pair).  n_def is uniform over the workgroup.
+            const bool settle = n_def > 0;
             int pw = (kDfsStack32 - g.reserve - sp) / 3;
             int p = sp < kDfsBlock ? sp : kDfsBlock;
             if (pw < 1) pw = 1;
             if (p > pw) p = pw;
+            if (settle) {
+                p = n_def;
+                exact_pairs_coop(it, s_pose, und_l, n_def, xs, und_v, tid);   // ends with a barrier
+            }
             const bool act = tid < p;
             int2 e = make_int2(0, 0);
-            if (act) e = stk[sp - 1 - tid];
+            if (act) e = settle ? und_l[tid] : stk[sp - 1 - tid];
             __syncthreads();
-            sp -= p;
-            n_test += p;
-            const bool la = act && e.x < 0, lb = act && e.y < 0;
+            if (!settle) { sp -= p; n_test += p; } else { n_und += p; }
             int verdict = 0, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            if (settle && act) verdict = und_v[tid];
+            const bool la = act && e.x < 0, lb = act && e.y < 0;
             if (act) {
                 const NodeF a = load_nodef(n1 + node_index(e.x));
                 const NodeF b = load_nodef(n2 + node_index(e.y));
                 a0 = a.link0; a1 = a.link1; b0 = b.link0; b1 = b.link1;
-                verdict = test_pair_f32(a, b, la || lb, R12, R12f, t12);
-            }
-            const bool hit = verdict == 1;
-            // undecided pairs: to the Float64 resolver (rare: one atomic per wave that has any)
-            {
-                const unsigned long long mu = __ballot(verdict == 2);
-                if (mu) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(g.ucount, __builtin_popcountll(mu));
-                    base = __shfl(base, 0, 64);
-                    if (verdict == 2) {
-                        const int pos = base + prefix_count(mu);
-                        if (pos < g.ucap) {
-                            WorkRec c;
-                            c.item = item; c.a = e.x; c.b = e.y; c.pad = 0;
-                            g.und[pos] = c;
-                        } else {
-                            atomicOr(g.status, kStUndOvf);
-                        }
-                    }
+                if (!settle) {
+                    double R12[9], t12[3];
+                    float R12f[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) { R12[k] = s_pose[k]; R12f[k] = (float)R12[k]; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
+                    verdict = test_pair_f32(a, b, la || lb, R12, R12f, t12);
                 }
             }
+            // an undecided pair is parked for the next iteration (verdict 2 only comes from the Float32 test)
+            if (verdict == 2) und_l[atomicAdd(&s_def, 1)] = e;
+            const bool hit = verdict == 1;
             const bool is_cand = hit && la && lb;
             const bool two = hit && (la != lb);
             const bool four = hit && !la && !lb;
@@ -459,6 +532,7 @@ __global__ void __launch_bounds__(kDfsBlock) k_bp_dfs32(Dfs32Args g) {
                 s_cnt[wave][1] = 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
             }
             __syncthreads();
+            n_def = s_def;   // read by everyone between this barrier and the next; reset after the next
             int c_off = 0, p_off = 0, c_tot = 0, p_tot = 0;
 #pragma unroll
             for (int w = 0; w < kDfsWaves; ++w) {
@@ -483,16 +557,18 @@ __global__ void __launch_bounds__(kDfsBlock) k_bp_dfs32(Dfs32Args g) {
             n_out += c_tot;
             sp += p_tot;
             __syncthreads();
-            if (n_out > kDfsOut32 - kDfsBlock || (sp == 0 && n_out > 0)) {
+            if (tid == 0) s_def = 0;   // ordered before the next iteration's parking by its first barrier
+            if (n_out > kDfsOut32 - kDfsBlock || (sp == 0 && n_def == 0 && n_out > 0)) {
                 flush_candidates(g, ob, n_out, item, tid, &s_base);
                 n_cand += n_out;
                 n_out = 0;
             }
         }
         if (tid == 0) {
-            if (sp > 0) atomicOr(g.status, kStAbort);
+            if (sp > 0 || n_def > 0) atomicOr(g.status, kStAbort);
             atomicAdd(&g.icnt[4 * (size_t)item], n_test);
             if (n_cand) atomicAdd(&g.icnt[4 * (size_t)item + 1], n_cand);
+            if (n_und) atomicAdd(g.ucount, n_und);   // statistics
         }
     }
 }
@@ -1955,10 +2031,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
             f.und = h->und.p; f.ucount = ucount; f.ucap = (int)h->ucap; f.icnt = h->icnt.p; f.status = h->status.p;
             f.reserve = 3 * levels + 3;
             hipLaunchKernelGGL(k_bp_dfs32, dim3(grid_for(bound, 1, 256 * 6)), dim3(kDfsBlock), 0, st, f);
-            // the undecided pairs and everything below them: exact Float64 traversal
-            d.seeds = h->und.p; d.n_seed = ucount; d.seed_cap = (int)h->ucap; d.next_seed = next_seed2;
-            d.no_filter = 1; d.resolver = 1;
-            hipLaunchKernelGGL(k_bp_dfs, dim3(grid_for(h->ucap, 1, 256 * 8)), dim3(64), 0, st, d);
+            (void)next_seed2;
         }
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));
