@@ -82,6 +82,8 @@ struct DualArgs {
     const WorkRec *cand;
     const int *ccount;
     int ccap;
+    const int *surv;         // candidate indices of contributing pairs (from the value pass)
+    const int *scount;
     int n_items, n_dir;
     const double *d_pose;    // (item, dir) x 24: dR21 9, dt21 3, dR12 9, dt12 3
     const double *d_twist;   // (item, dir) x 6
@@ -92,19 +94,146 @@ struct DualArgs {
     double *d_wrench;        // OUT (item, dir) x 6
     double *d_sdot;          // OUT (item, dir) x 6
     unsigned *status;
+    // Dual polygons of contributing bristle (pair, direction) lanes, kept by pass A for passes B and C:
+    // SoA [field][slot], 64 fields: n̂ (3 values, 3 partials), centroid (3, 3), ϵ_r² (4), 8 vertices x (3, 3)
+    double *dpoly;
+    int2 *dpoly_key;         // (item * n_dir + dir, n_poly)
+    int *dpcount;
+    long long dpcap;
 };
+constexpr int kDpFields = 64;
+
+// fan quadrature of one Dual polygon (integrate_over_polygon_patch!, non_friction.jl:217-265) with the pass-specific
+// integrand: MODE 0 normal wrench + regularized friction + cop sums, 1 patch stiffness about the cop, 2 bristle force
+template <int MODE, class VF>
+__device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, const double *er, const ItemRec *it,
+                                       const double *dt, bool reg, Du3 cop, Du3 Da, Du3 Dl, Du *sum, int &n_trac) {
+    const double er0 = er[0], er1 = er[1], er2 = er[2], er3 = er[3];
+    const Du3 w = dmk(du(it->w[0], dt[0]), du(it->w[1], dt[1]), du(it->w[2], dt[2]));
+    const Du3 vl = dmk(du(it->v[0], dt[3]), du(it->v[1], dt[4]), du(it->v[2], dt[5]));
+    const double chi = it->chi, Ebar = it->Ebar;
+    const double v_c = it->v_c, mu_s = it->mu_s, mu_d = it->mu_d;
+    const double tau = it->tau, k_bar = it->k_bar;
+    const int nq = it->nq;
+    Du3 v2 = vert(n - 1);
+    for (int k = 0; k < n; ++k) {
+        const Du3 v1 = v2;
+        v2 = vert(k);
+        const Du area = dtriangle_area(v1, v2, cen, nh);
+        if (!(0.0 < area.v)) continue;
+        for (int q = 0; q < nq; ++q) {
+            double q0, q1, q2, qw;
+            if (nq == 1) {
+                q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
+            } else {
+                const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
+                q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
+                qw = 0.33333333333333331483;
+            }
+            const Du3 r = dmk((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
+                              (v1.z * q0 + v2.z * q1) + cen.z * q2);
+            Du eq = dfma(er0, r.x, du(er3));
+            eq = dfma(er1, r.y, eq);
+            eq = dfma(er2, r.z, eq);
+            const Du3 rdot = vl + dcross(w, r);
+            const Du ee = -((er0 * rdot.x + er1 * rdot.y) + er2 * rdot.z);
+            const Du darg = du(1.0) + chi * ee;
+            const Du damp = (darg.v > 0.0) ? darg : du(0.0);   // max(0.0, .)
+            const Du p = (eq * Ebar) * damp;
+            const Du dA = qw * area;
+            if (!(0.0 < p.v)) continue;
+            ++n_trac;
+            const Du p_dA = p * dA;
+            if constexpr (MODE == 2) {
+                // calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48)
+                const Du3 x = r - cop;
+                const Du3 del = Dl + dcross(Da, x);
+                Du3 Ts = (del + rdot * tau) * (-k_bar);
+                Ts = dvec_sub_vec_proj(Ts, nh);
+                const Du m2 = ddot(Ts, Ts);
+                Du3 T;
+                if (m2.v < mu_s * mu_s) {
+                    T = Ts;
+                } else {
+                    const Du mg = dsqrt(m2);
+                    const Du mu = dclamped_piecewise(mg, 2 * mu_s, 3 * mu_s, mu_s, mu_d);
+                    T = (Ts * mu) / mg;
+                }
+                const Du3 Tc = T * p_dA;
+                const Du3 ta = dcross(x, Tc);
+                sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+                sum[3] += Tc.x; sum[4] += Tc.y; sum[5] += Tc.z;
+            } else if constexpr (MODE == 1) {
+                // calc_patch_spatial_stiffness! (friction.jl:147-169), r - cop
+                const Du3 x = r - cop;
+                const Du3 xn = dcross(x, nh);
+                const Du q1s = x.x * x.x, q2s = x.y * x.y, q3s = x.z * x.z;
+                const Du xy = x.x * x.y, xz = x.x * x.z, yz = x.y * x.z;
+                // K11 -= w ([x]x^2 + (x x n)(x x n)')
+                sum[0] += -(p_dA * ((-q2s - q3s) + xn.x * xn.x));
+                sum[1] += -(p_dA * (xy + xn.x * xn.y));
+                sum[2] += -(p_dA * (xz + xn.x * xn.z));
+                sum[3] += -(p_dA * ((-q1s - q3s) + xn.y * xn.y));
+                sum[4] += -(p_dA * (yz + xn.y * xn.z));
+                sum[5] += -(p_dA * ((-q1s - q2s) + xn.z * xn.z));
+                // K12 += w ([x]x - (x x n) n'), column-major
+                sum[6] += p_dA * (du(0.0) - xn.x * nh.x);
+                sum[7] += p_dA * (x.z - xn.y * nh.x);
+                sum[8] += p_dA * (-x.y - xn.z * nh.x);
+                sum[9] += p_dA * (-x.z - xn.x * nh.y);
+                sum[10] += p_dA * (du(0.0) - xn.y * nh.y);
+                sum[11] += p_dA * (x.x - xn.z * nh.y);
+                sum[12] += p_dA * (x.y - xn.x * nh.z);
+                sum[13] += p_dA * (-x.x - xn.y * nh.z);
+                sum[14] += p_dA * (du(0.0) - xn.z * nh.z);
+                // K22 += w (I - n n')
+                sum[15] += p_dA * (du(1.0) - nh.x * nh.x);
+                sum[16] += p_dA * (du(0.0) - nh.x * nh.y);
+                sum[17] += p_dA * (du(0.0) - nh.x * nh.z);
+                sum[18] += p_dA * (du(1.0) - nh.y * nh.y);
+                sum[19] += p_dA * (du(0.0) - nh.y * nh.z);
+                sum[20] += p_dA * (du(1.0) - nh.z * nh.z);
+            } else {
+            Du3 tk;
+            if (reg) {
+                // yes_contact!(::Regularized) (friction.jl:50-72)
+                const Du3 vt = dvec_sub_vec_proj(rdot, nh);
+                const Du m2 = ddot(vt, vt);
+                Du3 T;
+                if (m2.v < v_c * v_c) {
+                    T = (vt * (-mu_s)) / v_c;
+                } else {
+                    const Du mg = dsqrt(m2);
+                    const Du mu = dclamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
+                    T = (vt * (-mu)) / mg;
+                }
+                tk = nh * p_dA + T * p_dA;
+            } else {
+                // normal_wrench_cop (normal.jl:17-34)
+                tk = nh * p_dA;
+                sum[6] += p_dA;
+                sum[7] += p_dA * r.x; sum[8] += p_dA * r.y; sum[9] += p_dA * r.z;
+            }
+            const Du3 ta = dcross(r, tk);
+            sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+            sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
+            }
+        }
+    }
+}
 
 #define PV(k, c) pv[((((rbase) + (k)) & 7) * 4 + (c)) * 64 + lane]
 #define PD(k, c) pd[((((rbase) + (k)) & 7) * 4 + (c)) * 64 + lane]
 
-// MODE 0: pass A (normal wrench, regularized friction fused, cop sums); 1: pass B (patch stiffness about the cop);
-// 2: pass C (bristle friction force).  TT as in k_narrow.
-template <int MODE, bool TT>
+// Pass A: gather, clip and integrate in Dual arithmetic (normal wrench, regularized friction fused, cop sums); the
+// Dual polygon of every contributing bristle lane is kept for passes B and C (k_dual_poly).  TT as in k_narrow.
+template <bool TT>
 __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
+    constexpr int MODE = 0;
     __shared__ double pv[8 * 4 * 64];
     __shared__ double pd[8 * 4 * 64];
     const int lane = threadIdx.x;
-    int n_c = *g.ccount;
+    int n_c = *g.scount;     // contributing pairs only: no lane gathers for a pair that will be rejected
     if (n_c > g.ccap) n_c = g.ccap;
     const int n_dir = g.n_dir;
     const int cpw = 64 / n_dir;
@@ -115,13 +244,12 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
         const bool active = dir < n_dir && idx < n_c;
         WorkRec cw;
         cw.item = 0; cw.a = 0; cw.b = 0; cw.pad = 0;
-        if (active) cw = g.cand[idx];
+        if (active) cw = g.cand[g.surv[idx]];
         const ItemRec *it = g.items + cw.item;
         const TetRec *tp = it->tet + cw.b;
-        const int nq = it->nq;
         const bool reg = it->model == PFC_REGULARIZED;
         const int key = active ? cw.item * n_dir + dir : -1;
-        const bool work = active && g.icnt[4 * (size_t)cw.item + 3] > 0 && (MODE == 0 || !reg);
+        const bool work = active && g.icnt[4 * (size_t)cw.item + 3] > 0;
         int n_poly = 0, rbase = 0;
         Du3 nh = dmk(du(0.0), du(0.0), du(0.0));
         if (work) {
@@ -323,11 +451,12 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
             }
         }
         // ---- integrate_over_polygon_patch! (non_friction.jl:217-234) ------------------------------------------------
-        constexpr int NS = MODE == 0 ? 10 : (MODE == 1 ? 21 : 6);
+        constexpr int NS = 10;
         Du sum[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) sum[k] = du(0.0);
         int n_trac_lane = 0;
+        Du3 cen_keep = dmk(du(0.0), du(0.0), du(0.0));
         if (n_poly >= 3) {
             const int n = n_poly;
             {
@@ -360,145 +489,98 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
                 }
                 cen = (cum_sum.v == 0.0) ? a : cum_prod / cum_sum;
             }
-            const double er0 = tp->epsr[0], er1 = tp->epsr[1], er2 = tp->epsr[2], er3 = tp->epsr[3];
-            const double *dt = g.d_twist + (size_t)key * 6;
-            const Du3 w = dmk(du(it->w[0], dt[0]), du(it->w[1], dt[1]), du(it->w[2], dt[2]));
-            const Du3 vl = dmk(du(it->v[0], dt[3]), du(it->v[1], dt[4]), du(it->v[2], dt[5]));
-            const double chi = it->chi, Ebar = it->Ebar;
-            const double v_c = it->v_c, mu_s = it->mu_s, mu_d = it->mu_d;
+            const double er[4] = {tp->epsr[0], tp->epsr[1], tp->epsr[2], tp->epsr[3]};
             Du3 cop = dmk(du(0.0), du(0.0), du(0.0)), Da = cop, Dl = cop;
-            double tau = 0.0, k_bar = 0.0;
-            if (MODE == 1) {
-                const double *a = g.dacc + (size_t)key * kDaStride + kDaA;
-                const Du ip = du(a[6], a[16]);
-                cop = dmk(du(a[7], a[17]), du(a[8], a[18]), du(a[9], a[19])) / ip;
-            }
-            if (MODE == 2) {
-                const double *r = g.dres + (size_t)key * kDrStride;
-                cop = dmk(du(r[kDrCop], r[kDrCop + 3]), du(r[kDrCop + 1], r[kDrCop + 4]), du(r[kDrCop + 2], r[kDrCop + 5]));
-                Da = dmk(du(r[kDrDelta], r[kDrDelta + 6]), du(r[kDrDelta + 1], r[kDrDelta + 7]), du(r[kDrDelta + 2], r[kDrDelta + 8]));
-                Dl = dmk(du(r[kDrDelta + 3], r[kDrDelta + 9]), du(r[kDrDelta + 4], r[kDrDelta + 10]), du(r[kDrDelta + 5], r[kDrDelta + 11]));
-                tau = it->tau; k_bar = it->k_bar;
-            }
-            Du3 v2 = PVT(n - 1);
-            for (int k = 0; k < n; ++k) {
-                const Du3 v1 = v2;
-                v2 = PVT(k);
-                const Du area = dtriangle_area(v1, v2, cen, nh);
-                if (!(0.0 < area.v)) continue;
-                for (int q = 0; q < nq; ++q) {
-                    double q0, q1, q2, qw;
-                    if (nq == 1) {
-                        q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
-                    } else {
-                        const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
-                        q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
-                        qw = 0.33333333333333331483;
+            dual_integrate<0>([&](int k) { return PVT(k); }, n, nh, cen, er, it, g.d_twist + (size_t)key * 6, reg, cop, Da,
+                              Dl, sum, n_trac_lane);
+            cen_keep = cen;
+#undef PVT
+        }
+        // ---- keep the Dual polygon of contributing bristle lanes (compacted slots, coalesced SoA stores) -------------
+        {
+            const bool keep = work && n_trac_lane > 0 && !reg;
+            const unsigned long long km = __ballot(keep);
+            if (km) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(g.dpcount, __popcll(km));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const long long slot = (long long)base + __popcll(km & ((1ull << lane) - 1ull));
+                if (keep && slot < g.dpcap) {     // dpcap >= non-empty pairs x n_dir: cannot overflow
+                    const size_t P = (size_t)g.dpcap;
+                    double *o = g.dpoly + slot;
+                    g.dpoly_key[slot] = make_int2(key, n_poly);
+                    o[0] = nh.x.v; o[P] = nh.y.v; o[2 * P] = nh.z.v; o[3 * P] = nh.x.d; o[4 * P] = nh.y.d; o[5 * P] = nh.z.d;
+                    o[6 * P] = cen_keep.x.v; o[7 * P] = cen_keep.y.v; o[8 * P] = cen_keep.z.v;
+                    o[9 * P] = cen_keep.x.d; o[10 * P] = cen_keep.y.d; o[11 * P] = cen_keep.z.d;
+                    o[12 * P] = tp->epsr[0]; o[13 * P] = tp->epsr[1]; o[14 * P] = tp->epsr[2]; o[15 * P] = tp->epsr[3];
+                    for (int k = 0; k < n_poly; ++k) {
+                        double *q = o + (size_t)(16 + 6 * k) * P;
+                        q[0] = PV(k, 0); q[P] = PV(k, 1); q[2 * P] = PV(k, 2);
+                        q[3 * P] = PD(k, 0); q[4 * P] = PD(k, 1); q[5 * P] = PD(k, 2);
                     }
-                    const Du3 r = dmk((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
-                                      (v1.z * q0 + v2.z * q1) + cen.z * q2);
-                    Du eq = dfma(er0, r.x, du(er3));
-                    eq = dfma(er1, r.y, eq);
-                    eq = dfma(er2, r.z, eq);
-                    const Du3 rdot = vl + dcross(w, r);
-                    const Du ee = -((er0 * rdot.x + er1 * rdot.y) + er2 * rdot.z);
-                    const Du darg = du(1.0) + chi * ee;
-                    const Du damp = (darg.v > 0.0) ? darg : du(0.0);   // max(0.0, .)
-                    const Du p = (eq * Ebar) * damp;
-                    const Du dA = qw * area;
-                    if (!(0.0 < p.v)) continue;
-                    ++n_trac_lane;
-                    const Du p_dA = p * dA;
-                    if (MODE == 2) {
-                        // calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48)
-                        const Du3 x = r - cop;
-                        const Du3 del = Dl + dcross(Da, x);
-                        Du3 Ts = (del + rdot * tau) * (-k_bar);
-                        Ts = dvec_sub_vec_proj(Ts, nh);
-                        const Du m2 = ddot(Ts, Ts);
-                        Du3 T;
-                        if (m2.v < mu_s * mu_s) {
-                            T = Ts;
-                        } else {
-                            const Du mg = dsqrt(m2);
-                            const Du mu = dclamped_piecewise(mg, 2 * mu_s, 3 * mu_s, mu_s, mu_d);
-                            T = (Ts * mu) / mg;
-                        }
-                        const Du3 Tc = T * p_dA;
-                        const Du3 ta = dcross(x, Tc);
-                        sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
-                        sum[3] += Tc.x; sum[4] += Tc.y; sum[5] += Tc.z;
-                        continue;
-                    }
-                    if (MODE == 1) {
-                        // calc_patch_spatial_stiffness! (friction.jl:147-169), r - cop
-                        const Du3 x = r - cop;
-                        const Du3 xn = dcross(x, nh);
-                        const Du q1s = x.x * x.x, q2s = x.y * x.y, q3s = x.z * x.z;
-                        const Du xy = x.x * x.y, xz = x.x * x.z, yz = x.y * x.z;
-                        // K11 -= w ([x]x^2 + (x x n)(x x n)')
-                        sum[0] += -(p_dA * ((-q2s - q3s) + xn.x * xn.x));
-                        sum[1] += -(p_dA * (xy + xn.x * xn.y));
-                        sum[2] += -(p_dA * (xz + xn.x * xn.z));
-                        sum[3] += -(p_dA * ((-q1s - q3s) + xn.y * xn.y));
-                        sum[4] += -(p_dA * (yz + xn.y * xn.z));
-                        sum[5] += -(p_dA * ((-q1s - q2s) + xn.z * xn.z));
-                        // K12 += w ([x]x - (x x n) n'), column-major
-                        sum[6] += p_dA * (du(0.0) - xn.x * nh.x);
-                        sum[7] += p_dA * (x.z - xn.y * nh.x);
-                        sum[8] += p_dA * (-x.y - xn.z * nh.x);
-                        sum[9] += p_dA * (-x.z - xn.x * nh.y);
-                        sum[10] += p_dA * (du(0.0) - xn.y * nh.y);
-                        sum[11] += p_dA * (x.x - xn.z * nh.y);
-                        sum[12] += p_dA * (x.y - xn.x * nh.z);
-                        sum[13] += p_dA * (-x.x - xn.y * nh.z);
-                        sum[14] += p_dA * (du(0.0) - xn.z * nh.z);
-                        // K22 += w (I - n n')
-                        sum[15] += p_dA * (du(1.0) - nh.x * nh.x);
-                        sum[16] += p_dA * (du(0.0) - nh.x * nh.y);
-                        sum[17] += p_dA * (du(0.0) - nh.x * nh.z);
-                        sum[18] += p_dA * (du(1.0) - nh.y * nh.y);
-                        sum[19] += p_dA * (du(0.0) - nh.y * nh.z);
-                        sum[20] += p_dA * (du(1.0) - nh.z * nh.z);
-                        continue;
-                    }
-                    Du3 tk;
-                    if (reg) {
-                        // yes_contact!(::Regularized) (friction.jl:50-72)
-                        const Du3 vt = dvec_sub_vec_proj(rdot, nh);
-                        const Du m2 = ddot(vt, vt);
-                        Du3 T;
-                        if (m2.v < v_c * v_c) {
-                            T = (vt * (-mu_s)) / v_c;
-                        } else {
-                            const Du mg = dsqrt(m2);
-                            const Du mu = dclamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
-                            T = (vt * (-mu)) / mg;
-                        }
-                        tk = nh * p_dA + T * p_dA;
-                    } else {
-                        // normal_wrench_cop (normal.jl:17-34)
-                        tk = nh * p_dA;
-                        sum[6] += p_dA;
-                        sum[7] += p_dA * r.x; sum[8] += p_dA * r.y; sum[9] += p_dA * r.z;
-                    }
-                    const Du3 ta = dcross(r, tk);
-                    sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
-                    sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
                 }
             }
-#undef PVT
         }
         // ---- per (item, direction) reductions ---------------------------------------------------------------------
         double flat[2 * NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) { flat[k] = sum[k].v; flat[NS + k] = sum[k].d; }
-        constexpr int base = MODE == 0 ? kDaA : (MODE == 1 ? kDaB : kDaC);
-        accumulate_items<2 * NS>(g.dacc, key, active, work && n_trac_lane > 0, flat, base, kDaStride);
+        accumulate_items<2 * NS>(g.dacc, key, active, work && n_trac_lane > 0, flat, kDaA, kDaStride);
     }
 }
 #undef PV
 #undef PD
+
+// Passes B (MODE 1: calc_patch_spatial_stiffness! about the Dual cop) and C (MODE 2: calc_spatial_bristle_force) over
+// the kept Dual polygons: one lane per slot, coalesced loads, same fan / quadrature arithmetic as pass A.
+template <int MODE>
+__global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
+    const int lane = threadIdx.x;
+    long long n_p = *g.dpcount;
+    if (n_p > g.dpcap) n_p = g.dpcap;
+    const size_t P = (size_t)g.dpcap;
+    const long long stride = (long long)gridDim.x * 64;
+    constexpr int NS = MODE == 1 ? 21 : 6;
+    for (long long idx0 = (long long)blockIdx.x * 64; idx0 < n_p; idx0 += stride) {
+        const long long idx = idx0 + lane;
+        const bool active = idx < n_p;
+        Du sum[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) sum[k] = du(0.0);
+        int key = -1, n_trac = 0;
+        if (active) {
+            const int2 kn = g.dpoly_key[idx];
+            key = kn.x;
+            const int n = kn.y;
+            const ItemRec *it = g.items + key / g.n_dir;
+            const double *o = g.dpoly + idx;
+            const Du3 nh = dmk(du(o[0], o[3 * P]), du(o[P], o[4 * P]), du(o[2 * P], o[5 * P]));
+            const Du3 cen = dmk(du(o[6 * P], o[9 * P]), du(o[7 * P], o[10 * P]), du(o[8 * P], o[11 * P]));
+            const double er[4] = {o[12 * P], o[13 * P], o[14 * P], o[15 * P]};
+            Du3 cop, Da = dmk(du(0.0), du(0.0), du(0.0)), Dl = Da;
+            if (MODE == 1) {
+                const double *a = g.dacc + (size_t)key * kDaStride + kDaA;
+                const Du ip = du(a[6], a[16]);
+                cop = dmk(du(a[7], a[17]), du(a[8], a[18]), du(a[9], a[19])) / ip;
+            } else {
+                const double *r = g.dres + (size_t)key * kDrStride;
+                cop = dmk(du(r[kDrCop], r[kDrCop + 3]), du(r[kDrCop + 1], r[kDrCop + 4]), du(r[kDrCop + 2], r[kDrCop + 5]));
+                Da = dmk(du(r[kDrDelta], r[kDrDelta + 6]), du(r[kDrDelta + 1], r[kDrDelta + 7]), du(r[kDrDelta + 2], r[kDrDelta + 8]));
+                Dl = dmk(du(r[kDrDelta + 3], r[kDrDelta + 9]), du(r[kDrDelta + 4], r[kDrDelta + 10]), du(r[kDrDelta + 5], r[kDrDelta + 11]));
+            }
+            dual_integrate<MODE>(
+                [&](int k) {
+                    const double *q = o + (size_t)(16 + 6 * k) * P;
+                    return dmk(du(q[0], q[3 * P]), du(q[P], q[4 * P]), du(q[2 * P], q[5 * P]));
+                },
+                n, nh, cen, er, it, g.d_twist + (size_t)key * 6, false, cop, Da, Dl, sum, n_trac);
+        }
+        double flat[2 * NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { flat[k] = sum[k].v; flat[NS + k] = sum[k].d; }
+        accumulate_items<2 * NS>(g.dacc, key, active, n_trac > 0, flat, MODE == 1 ? kDaB : kDaC, kDaStride);
+    }
+}
 
 // symmetric 6x6 eigen-decomposition (cyclic Jacobi), column-major; one thread
 __device__ inline void dual_jacobi6(double *A, double *V, double *w) {

@@ -779,6 +779,8 @@ struct NpArgs {
     double *poly;    // 34 fields: n̂ 3, centroid 3, ϵ_r² 4, vertices 8 x 3 (frame r²)
     int *pcount;
     int pcap;
+    int *surv;       // candidate indices of the pairs that contributed traction points (work list of the Dual passes)
+    int *scount;
     TracSoA trac;
     int *tcount;
     int tcap;
@@ -1217,14 +1219,27 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         const bool contributed = work && n_trac_lane > 0;
         {
             accumulate_items<10>(g.acc, cw.item, active, contributed, sum, 0);
-            // ---- keep the polygon of contributing bristle pairs for k_fric -------------------------------------------
-            if (__any(contributed && !reg)) {
-                const bool keep = contributed && !reg;
-                const unsigned long long km = __ballot(keep);
-                int base = 0;
-                if (lane == 0) base = atomicAdd(g.pcount, __popcll(km));
-                base = __builtin_amdgcn_readfirstlane(base);
-                const int slot = base + __popcll(km & ((1ull << lane) - 1ull));
+            // ---- compacted slots for (a) the polygons of contributing bristle pairs, kept for k_fric, and (b) when
+            // pfc_eval_dual asked for it, the candidate indices of all contributing pairs.  ONE 64-bit atomic per wave
+            // reserves both (pcount in the low word, scount in the high word): a second single-address atomic per wave
+            // cost 0.6 ms on the C3 batch.
+            const bool keep = contributed && !reg;
+            const bool list = contributed && g.surv != nullptr;
+            if (__any(keep || list)) {
+                const unsigned long long km = __ballot(keep), sm = __ballot(list);
+                unsigned long long base2 = 0;
+                if (lane == 0) {
+                    if (g.surv == nullptr)
+                        base2 = (unsigned)atomicAdd(g.pcount, __popcll(km));
+                    else
+                        base2 = atomicAdd(reinterpret_cast<unsigned long long *>(g.pcount),
+                                          ((unsigned long long)__popcll(sm) << 32) | (unsigned long long)__popcll(km));
+                }
+                const int base = __builtin_amdgcn_readfirstlane((int)(base2 & 0xFFFFFFFFull));
+                const int sbase = __builtin_amdgcn_readfirstlane((int)(base2 >> 32));
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (list) g.surv[sbase + __popcll(sm & below)] = idx;   // <= ccap entries
+                const int slot = base + __popcll(km & below);
                 if (keep && slot < g.pcap) {      // pcap >= ccap: cannot overflow
                     const size_t P = (size_t)g.pcap;
                     double *o = g.poly + slot;
@@ -1838,12 +1853,13 @@ struct pfc_context {
     // captured launch sequence (hipGraph) of the last evaluation shape
     hipGraphExec_t gexec = nullptr;
     struct GraphKey {
-        int n_items, levels, L, debug, bristle;
+        int n_items, levels, L, debug, bristle, surv;
         const void *p[7];
         void *stream;
         unsigned long long epoch;
     } gkey = {};
     bool ghave = false;
+    bool want_surv = false;   // the narrowphase also lists the contributing candidates (pfc_eval_dual)
     int opt_graph = 1;
     size_t fcap = 0, ccap = 0, tcap = 0, rcap = 0, ucap = 0;
     // host-pointer path staging
@@ -1854,7 +1870,10 @@ struct pfc_context {
     bool pending = false;
     hipStream_t last_stream = nullptr;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    DevBuf<double> dual_in, dual_acc, dual_res, dual_out;   // pfc_eval_dual
+    DevBuf<double> dual_in, dual_acc, dual_res, dual_out, dual_poly;   // pfc_eval_dual
+    DevBuf<int2> dual_pkey;
+    DevBuf<int> dual_cnt;
+    DevBuf<int> surv;                                       // candidate indices of contributing pairs
     DevBuf<int> poly_item;                                  // kept polygons of bristle pairs (k_narrow -> k_fric)
     DevBuf<double> poly;
     long long last_undecided = 0;      // node pairs the Float32 broadphase left to the Float64 resolver
@@ -1935,6 +1954,7 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     if ((e = h->frontier[1].ensure(f)) != hipSuccess) return e;
     if ((e = h->cand.ensure(c)) != hipSuccess) return e;
     if ((e = h->clip_n.ensure(c)) != hipSuccess) return e;
+    if ((e = h->surv.ensure(c)) != hipSuccess) return e;
     if (h->any_bristle) {
         if ((e = h->poly_item.ensure(c)) != hipSuccess) return e;
         if ((e = h->poly.ensure(c * 34)) != hipSuccess) return e;
@@ -1984,7 +2004,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
     int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2, *rcount = h->ctr.p + 3;
     int *ucount = h->ctr.p + 4, *next_seed2 = h->ctr.p + 5, *fcount = h->ctr.p + 6;
-    int *pcount = h->ctr.p + levels + 8;   // after the per-level frontier counts
+    int *pcount = h->ctr.p + ((levels + 9) & ~1);   // after the per-level frontier counts; 8-byte aligned pair
     HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(int) * ((size_t)levels + 12), st));
     HIP_TRY(h, hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * 4, st));
 #ifdef PFC_STAMPS
@@ -2043,6 +2063,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     np.stamps = h->stamps.p;
     np.rec = h->rec.p; np.rcount = rcount; np.rcap = (int)h->rcap;
     np.poly_item = h->poly_item.p; np.poly = h->poly.p; np.pcount = pcount; np.pcap = (int)h->ccap;
+    np.surv = h->want_surv ? h->surv.p : nullptr; np.scount = pcount + 1;
     const int np_grid = grid_for(h->ccap, kNpBlock, 256 * 16);
     if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
     else hipLaunchKernelGGL((k_narrow<false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
@@ -2090,6 +2111,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
         pfc_context::GraphKey key = {};
         key.n_items = n_items; key.levels = levels; key.L = L; key.debug = h->opt_debug;
         key.bristle = (h->any_bristle ? 1 : 0) | (h->any_tet_tet ? 2 : 0);
+        key.surv = h->want_surv ? 1 : 0;
         key.p[0] = d_ins_ids; key.p[1] = d_pose; key.p[2] = d_twist; key.p[3] = d_s; key.p[4] = d_wrench;
         key.p[5] = d_sdot; key.p[6] = d_counts; key.stream = (void *)st; key.epoch = h->epoch;
         if (!h->ghave || std::memcmp(&key, &h->gkey, sizeof key) != 0) {
@@ -2203,7 +2225,8 @@ void pfc_destroy(pfc_handle h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     h->tail.release();
-    h->poly_item.release(); h->poly.release();
+    h->poly_item.release(); h->poly.release(); h->surv.release();
+    h->dual_poly.release(); h->dual_pkey.release(); h->dual_cnt.release();
     h->dual_in.release(); h->dual_acc.release(); h->dual_res.release(); h->dual_out.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -2495,7 +2518,9 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
         return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: null buffer");
     // values, candidate list and per-item counters: the ordinary evaluation (the broadphase ignores partials,
     // src/contact_algorithms_non_friction.jl:95)
+    h->want_surv = true;
     int rc = pfc_eval(h, n_items, ins_ids, pose, twist, s, wrench, sdot, counts);
+    h->want_surv = false;
     if (rc != PFC_OK || n_items == 0) return rc;
     const size_t nk = (size_t)n_items * n_dir;
     hipStream_t st = h->stream;
@@ -2511,22 +2536,29 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
     DualArgs a;
     a.items = h->items.p; a.cand = h->cand.p; a.ccount = h->ctr.p; a.ccap = (int)h->ccap;
+    a.surv = h->surv.p; a.scount = h->ctr.p + (((h->last_levels + 9) & ~1) + 1);
     a.n_items = n_items; a.n_dir = n_dir; a.d_pose = dp; a.d_twist = dt; a.d_s = dsd; a.icnt = h->icnt.p;
     a.dacc = h->dual_acc.p; a.dres = h->dual_res.p; a.d_wrench = h->dual_out.p; a.d_sdot = h->dual_out.p + nk * 6;
     a.status = h->status.p;
     const int cpw = 64 / n_dir;
-    const size_t n_cand = (size_t)h->stats[1];
+    const size_t n_cand = (size_t)h->stats[2];   // contributing pairs <= pairs with a non-empty polygon
     const int grid = grid_for((n_cand + cpw - 1) / cpw, 1, 256 * 16);
     const int kgrid = grid_for(nk, 64, 1 << 20);
     const bool tt = h->any_tet_tet;
-    if (tt) hipLaunchKernelGGL((k_narrow_dual<0, true>), dim3(grid), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_narrow_dual<0, false>), dim3(grid), dim3(64), 0, st, a);
+    // Dual polygons kept between the passes: at most (pairs with a non-empty polygon) x n_dir slots
+    const size_t dpcap = h->any_bristle ? (size_t)h->stats[2] * n_dir + 64 : 64;
+    HIP_TRY(h, h->dual_poly.ensure(dpcap * kDpFields));
+    HIP_TRY(h, h->dual_pkey.ensure(dpcap));
+    HIP_TRY(h, h->dual_cnt.ensure(4));
+    HIP_TRY(h, hipMemsetAsync(h->dual_cnt.p, 0, sizeof(int) * 4, st));
+    a.dpoly = h->dual_poly.p; a.dpoly_key = h->dual_pkey.p; a.dpcount = h->dual_cnt.p; a.dpcap = (long long)dpcap;
+    if (tt) hipLaunchKernelGGL((k_narrow_dual<true>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_narrow_dual<false>), dim3(grid), dim3(64), 0, st, a);
     if (h->any_bristle) {
-        if (tt) hipLaunchKernelGGL((k_narrow_dual<1, true>), dim3(grid), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_narrow_dual<1, false>), dim3(grid), dim3(64), 0, st, a);
+        const int pgrid = grid_for(dpcap, 64, 256 * 16);
+        hipLaunchKernelGGL((k_dual_poly<1>), dim3(pgrid), dim3(64), 0, st, a);
         hipLaunchKernelGGL(k_dual_eig, dim3(kgrid), dim3(64), 0, st, a);
-        if (tt) hipLaunchKernelGGL((k_narrow_dual<2, true>), dim3(grid), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_narrow_dual<2, false>), dim3(grid), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((k_dual_poly<2>), dim3(pgrid), dim3(64), 0, st, a);
     }
     hipLaunchKernelGGL(k_dual_final, dim3(kgrid), dim3(64), 0, st, a);
     HIP_TRY(h, hipGetLastError());
