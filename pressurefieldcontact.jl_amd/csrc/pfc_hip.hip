@@ -37,6 +37,7 @@ __global__ void k_prep_tri(int n, const double *__restrict__ pt, const int *__re
     TriRec r;
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = b.x; r.v[4] = b.y; r.v[5] = b.z;
     r.v[6] = c.x; r.v[7] = c.y; r.v[8] = c.z; r.n[0] = nh.x; r.n[1] = nh.y; r.n[2] = nh.z;
+    r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0.0;
     out[k] = r;
 }
 
@@ -832,6 +833,28 @@ __device__ __forceinline__ void accumulate_items(double *acc, int item, bool lis
     }
 }
 
+// Sums of N per-lane values over a whole wave through LDS: lane `lane` writes column `lane` of N rows (row stride 65
+// doubles: conflict-free both ways), lanes lane0 .. lane0+N-1 then add up one row each.  N + ~130 instructions per wave
+// instead of ~30 N for N segmented DPP scans; used when all work items of the wave belong to one item (97 % of the
+// waves of the C3 batch).  Both barriers are wave-local (the block is one wave).
+template <int N>
+__device__ __forceinline__ double lds_row_sums(double *buf, const double *v, bool any, int lane, int lane0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) buf[k * 65 + lane] = any ? v[k] : 0.0;
+    __syncthreads();
+    double t = 0.0;
+    const int row = lane - lane0;
+    if (row >= 0 && row < N) {
+        const double *r = buf + row * 65;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll 4
+        for (int j = 0; j < 64; j += 4) { t0 += r[j]; t1 += r[j + 1]; t2 += r[j + 2]; t3 += r[j + 3]; }
+        t = (t0 + t1) + (t2 + t3);
+    }
+    __syncthreads();
+    return t;
+}
+
 // Everything up to the per-item sums (regularized friction fused; bristle: normal wrench + patch moments).  For bristle
 // items the clipped polygon of every contributing pair is kept (34 doubles, SoA by compacted slot: every store
 // instruction of a wave writes consecutive doubles) so that the friction pass after k_eig (k_fric) re-integrates the
@@ -1218,7 +1241,6 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         // ==== phase 4 (wave-uniform): per-item reductions =============================================================
         const bool contributed = work && n_trac_lane > 0;
         {
-            accumulate_items<10>(g.acc, cw.item, active, contributed, sum, 0);
             // ---- compacted slots for (a) the polygons of contributing bristle pairs, kept for k_fric, and (b) when
             // pfc_eval_dual asked for it, the candidate indices of all contributing pairs.  ONE 64-bit atomic per wave
             // reserves both (pcount in the low word, scount in the high word): a second single-address atomic per wave
@@ -1243,25 +1265,50 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 if (keep && slot < g.pcap) {      // pcap >= ccap: cannot overflow
                     const size_t P = (size_t)g.pcap;
                     double *o = g.poly + slot;
-                    g.poly_item[slot] = (int)((unsigned)cw.item | ((unsigned)n_poly << 28));
-                    o[0] = nh.x; o[P] = nh.y; o[2 * P] = nh.z;
-                    o[3 * P] = cen.x; o[4 * P] = cen.y; o[5 * P] = cen.z;
-                    o[6 * P] = tp->epsr[0]; o[7 * P] = tp->epsr[1]; o[8 * P] = tp->epsr[2]; o[9 * P] = tp->epsr[3];
+                    // streaming stores: 0.5 GB per C3 batch must not evict the mesh records from the XCD's 4 MiB L2
+#define NT_(p, v) __builtin_nontemporal_store((v), (p))
+                    NT_(&g.poly_item[slot], (int)((unsigned)cw.item | ((unsigned)n_poly << 28)));
+                    NT_(o, nh.x); NT_(o + P, nh.y); NT_(o + 2 * P, nh.z);
+                    NT_(o + 3 * P, cen.x); NT_(o + 4 * P, cen.y); NT_(o + 5 * P, cen.z);
+                    NT_(o + 6 * P, tp->epsr[0]); NT_(o + 7 * P, tp->epsr[1]); NT_(o + 8 * P, tp->epsr[2]);
+                    NT_(o + 9 * P, tp->epsr[3]);
                     for (int k = 0; k < n_poly; ++k) {
-                        o[(10 + 3 * k) * P] = PR(k, 0); o[(11 + 3 * k) * P] = PR(k, 1); o[(12 + 3 * k) * P] = PR(k, 2);
+                        NT_(o + (10 + 3 * k) * P, PR(k, 0)); NT_(o + (11 + 3 * k) * P, PR(k, 1));
+                        NT_(o + (12 + 3 * k) * P, PR(k, 2));
                     }
+#undef NT_
                 }
+            }
+            // ---- the ten per-item sums.  Single-item wave (the rule: an item has ~30 waves of candidates): LDS transpose;
+            // otherwise segmented scans keyed by item.  The polygon ring is free from here on (its last reader was the
+            // polygon store above).
+            const unsigned long long am = __ballot(active);
+            const int item_first = __builtin_amdgcn_readlane(cw.item, am ? __builtin_ctzll(am) : 0);
+            const bool single = __all(!active || cw.item == item_first);
+            double t10 = 0.0;   // single: lane k < 10 holds total k
+            if (single) {
+                if (__any(contributed)) {
+                    t10 = lds_row_sums<10>(poly, sum, contributed, lane, 0);
+                    if (lane < 10 && t10 != 0.0) unsafeAtomicAdd(&g.acc[(size_t)item_first * kAccStride + lane], t10);
+                }
+            } else {
+                accumulate_items<10>(g.acc, cw.item, active, contributed, sum, 0);
             }
             if (__any(contributed && !reg)) {
                 // ---- patch-stiffness moments of the bristle model, one record per run of an item in this wave ----
                 const bool cb = contributed && !reg;
                 const Seg sg = seg_setup(active ? cw.item : -1);
                 // the run's own pressure centroid c_w = sum w r / sum w, broadcast from the run's tail
-                double Wt = seg_sum(cb ? sum[6] : 0.0, sg);
-                double cx = seg_sum(cb ? sum[7] : 0.0, sg), cy = seg_sum(cb ? sum[8] : 0.0, sg);
-                double cz = seg_sum(cb ? sum[9] : 0.0, sg);
-                Wt = __shfl(Wt, sg.tail_lane, 64);
-                cx = __shfl(cx, sg.tail_lane, 64); cy = __shfl(cy, sg.tail_lane, 64); cz = __shfl(cz, sg.tail_lane, 64);
+                double Wt, cx, cy, cz;
+                if (single) {
+                    Wt = readlane_f64(t10, 6); cx = readlane_f64(t10, 7); cy = readlane_f64(t10, 8); cz = readlane_f64(t10, 9);
+                } else {
+                    Wt = seg_sum(cb ? sum[6] : 0.0, sg);
+                    cx = seg_sum(cb ? sum[7] : 0.0, sg); cy = seg_sum(cb ? sum[8] : 0.0, sg);
+                    cz = seg_sum(cb ? sum[9] : 0.0, sg);
+                    Wt = __shfl(Wt, sg.tail_lane, 64);
+                    cx = __shfl(cx, sg.tail_lane, 64); cy = __shfl(cy, sg.tail_lane, 64); cz = __shfl(cz, sg.tail_lane, 64);
+                }
                 const double iW = (Wt > 0.0) ? 1.0 / Wt : 0.0;
                 const V3 cwv = mk3(cx * iW, cy * iW, cz * iW);
                 // lane moments: polygon centroid -> c_w (parallel axis; |d| is at most the patch size)
@@ -1294,10 +1341,35 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 }
 #pragma unroll
                 for (int k = 0; k < 6; ++k) v[21 + k] = q[k];
+                if (single) {
+                    // rows on lanes 5..31: the record is item, W, c_w, 27 moments
+                    double mine = lds_row_sums<27>(poly, v, cb, lane, 5);
+                    if (Wt > 0.0) {
+                        if (lane == 0) mine = (double)item_first;
+                        if (lane == 1) mine = Wt;
+                        if (lane == 2) mine = cwv.x;
+                        if (lane == 3) mine = cwv.y;
+                        if (lane == 4) mine = cwv.z;
+                        int slot = 0;
+                        if (lane == 0) slot = atomicAdd(g.rcount, 1);
+                        slot = __builtin_amdgcn_readfirstlane(slot);
+                        if (slot < g.rcap) {
+                            if (lane < kRecStride) g.rec[(size_t)slot * kRecStride + lane] = mine;
+                        } else if (lane == 0) {
+                            atomicOr(g.status, kStRecOvf);
+                        }
+                    }
+                }
                 double tot[27];
+                unsigned long long tails = 0;
+                if (!single) {
 #pragma unroll
-                for (int k = 0; k < 27; ++k) tot[k] = seg_sum(cb ? v[k] : 0.0, sg);
-                unsigned long long tails = __ballot(sg.tail && sg.valid && Wt > 0.0);
+                    for (int k = 0; k < 27; ++k) tot[k] = seg_sum(cb ? v[k] : 0.0, sg);
+                    tails = __ballot(sg.tail && sg.valid && Wt > 0.0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) tot[k] = 0.0;
+                }
                 while (tails) {
                     const int t = __builtin_ctzll(tails);
                     tails &= tails - 1;

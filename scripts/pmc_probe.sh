@@ -1,0 +1,13 @@
+#!/bin/bash
+# ad-hoc PMC probes of the bench workload: one counter group per pass (never combined with trace domains)
+# usage (GPU box): bash scripts/pmc_probe.sh <tag> "<CTR1 CTR2 ...>" ["<group 2>" ...]
+set -e
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=$1; shift
+cd /tmp && export TMPDIR=/tmp
+k=0
+for grp in "$@"; do
+  rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/${TAG}_g$k -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 > $R/gpurun_out/${TAG}_g$k.log 2>&1
+  k=$((k+1))
+done
+echo done
