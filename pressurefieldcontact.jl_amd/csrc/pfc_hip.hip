@@ -1923,14 +1923,14 @@ struct pfc_context {
     size_t pin_in_cap = 0, pin_out_cap = 0;
     unsigned long long epoch = 0;        // bumped whenever a device work buffer is reallocated
     // captured launch sequence (hipGraph) of the last evaluation shape
-    hipGraphExec_t gexec = nullptr;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [0] plain evaluation, [1] with the contributing-pair list (Dual)
     struct GraphKey {
         int n_items, levels, L, debug, bristle, surv;
         const void *p[7];
         void *stream;
         unsigned long long epoch;
-    } gkey = {};
-    bool ghave = false;
+    } gkey[2] = {};
+    bool ghave[2] = {false, false};
     bool want_surv = false;   // the narrowphase also lists the contributing candidates (pfc_eval_dual)
     int opt_graph = 1;
     size_t fcap = 0, ccap = 0, tcap = 0, rcap = 0, ucap = 0;
@@ -2186,21 +2186,22 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
         key.surv = h->want_surv ? 1 : 0;
         key.p[0] = d_ins_ids; key.p[1] = d_pose; key.p[2] = d_twist; key.p[3] = d_s; key.p[4] = d_wrench;
         key.p[5] = d_sdot; key.p[6] = d_counts; key.stream = (void *)st; key.epoch = h->epoch;
-        if (!h->ghave || std::memcmp(&key, &h->gkey, sizeof key) != 0) {
-            if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
-            h->ghave = false;
+        const int gi = key.surv;   // Radau alternates value and Dual evaluations: both graphs stay instantiated
+        if (!h->ghave[gi] || std::memcmp(&key, &h->gkey[gi], sizeof key) != 0) {
+            if (h->gexec[gi]) { (void)hipGraphExecDestroy(h->gexec[gi]); h->gexec[gi] = nullptr; }
+            h->ghave[gi] = false;
             hipGraph_t graph = nullptr;
             HIP_TRY(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             int rc = record_eval(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st, false);
             hipError_t e = hipStreamEndCapture(st, &graph);
             if (rc != PFC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             if (e != hipSuccess) return fail(h, PFC_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-            e = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+            e = hipGraphInstantiate(&h->gexec[gi], graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             if (e != hipSuccess) return fail(h, PFC_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-            h->gkey = key; h->ghave = true;
+            h->gkey[gi] = key; h->ghave[gi] = true;
         }
-        HIP_TRY(h, hipGraphLaunch(h->gexec, st));
+        HIP_TRY(h, hipGraphLaunch(h->gexec[gi], st));
     } else {
         int rc = record_eval(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st, prof);
         if (rc != PFC_OK) return rc;
@@ -2292,7 +2293,8 @@ void pfc_destroy(pfc_handle h) {
     h->h_ins.release(); h->h_counts.release();
     for (int k = 0; k < EV_COUNT; ++k)
         if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    for (int gi = 0; gi < 2; ++gi)
+        if (h->gexec[gi]) (void)hipGraphExecDestroy(h->gexec[gi]);
     if (h->h_tail) (void)hipHostFree(h->h_tail);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -2647,7 +2649,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "max_levels")) h->opt_max_levels = (int)value;
     else if (!std::strcmp(name, "bfs_levels")) h->opt_bfs_levels = (int)value;
     else if (!std::strcmp(name, "graph")) h->opt_graph = value != 0;
-    else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave = false; }
+    else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; }
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;
 }

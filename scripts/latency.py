@@ -20,4 +20,16 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
     st = m.stats()
     print(f"{name:45s} {dt*1e6:9.1f} us/eval   ops {st['candidates']:8d}  node tests {st['node_tests']:9d}  "
           f"-> {st['candidates']/dt:.3g} ops/s, {w.n_items/dt:.3g} contact pairs/s")
+    # the Dual evaluation of the same scene (6 partials, zero seeds: same work), alternating with value evaluations as
+    # Radau does
+    nd = 6
+    dz = (np.zeros((w.n_items, nd, 24)), np.zeros((w.n_items, nd, 6)), np.zeros((w.n_items, nd, 6)))
+    for _ in range(3):
+        m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *dz, w.ins_ids)
+    t0 = time.perf_counter()
+    for _ in range(n // 2):
+        m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *dz, w.ins_ids)
+        m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    dd = (time.perf_counter() - t0) / (n // 2) - dt
+    print(f"{'':45s} {dd*1e6:9.1f} us/Dual eval (6 partials)")
     m.close()

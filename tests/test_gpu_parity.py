@@ -178,3 +178,23 @@ def test_mixed_tri_tet_and_tet_tet_instructions(pfc):
     for k, r in enumerate(ref):
         _assert_item_parity(m, k, r, wrench, sdot, counts, 1e-8)
     m.close()
+
+
+def test_host_supplied_trees_with_improper_and_skewed_boxes(pfc):
+    """A host may pass its own flattened tree.  Leaf boxes whose R is a reflection (same box, one axis
+    negated) cannot be held as a unit quaternion, so every node pair that involves them is left undecided by the
+    single-precision broadphase and settled by the exact Float64 test: the candidate sets must still be the reference's
+    bit for bit.  Half of the leaves are flipped so that both paths are mixed inside the same waves."""
+    w = pfc.configs.c3_blob_tool(6, seed=21, n_div_blob=8, n_div_tool=6)
+    for ms in w.meshes:
+        t = ms.tree
+        leaves = np.nonzero(t.leaf != pfc.geometry.INTERNAL)[0]
+        flip = leaves[::2]
+        t.R[flip, 3:6] *= -1.0                       # negate the second axis: det R = -1, same box
+    m, wrench, sdot, counts = _eval(pfc, w)
+    ref = H.oracle_run(pfc, w)
+    for k in range(w.n_items):
+        _assert_item_parity(m, k, ref[k], wrench, sdot, counts, tol=TOL_TIGHT)
+    stats = m.stats()
+    assert stats["candidates"] == sum(int(r.counts[1]) for r in ref)
+    m.close()
