@@ -349,7 +349,7 @@ __device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, boo
 
 constexpr int kDfsBlock = 256;
 constexpr int kDfsWaves = kDfsBlock / 64;
-constexpr int kDfsStack32 = 4096;   // node pairs per workgroup (32 KiB)
+constexpr int kDfsStack32 = 2560;   // node pairs per workgroup (20 KiB)
 constexpr int kDfsOut32 = 1280;     // staged candidates per workgroup (10 KiB)
 
 // The exact Float64 BB_BB_intersect (general composition, src/obb/bb_intersection.jl:2-74) of the node pairs the
@@ -454,7 +454,7 @@ __device__ __forceinline__ void flush_candidates(const Dfs32Args &g, const int2 
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(kDfsBlock) k_bp_dfs32(Dfs32Args g) {
+__global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
     __shared__ int2 stk[kDfsStack32];
     __shared__ int2 ob[kDfsOut32];
     __shared__ int s_cnt[kDfsWaves][2];   // per wave: candidates, pushed pairs of the current iteration
