@@ -170,21 +170,33 @@ def main():
         bp_ms = stage["broadphase"] / K
         # SURVEY §8(d) accounting: algorithmic bytes / kernel time against the HBM peak.  Both kernels re-read their
         # 96..256-byte records from L2 / Infinity Cache across the poses of a batch, so "achieved" can exceed what HBM
-        # could deliver while the PMC traffic stays tiny: the kernels are Float64-issue / latency bound (see "valu").
-        roof_np = {"kernel": "k_narrow<0,false>", "bound": "hbm", "achieved": BYTES_PER_OP * st["candidates"] / (np_ms * 1e-3) / 1e9,
+        # could deliver while the PMC traffic stays tiny: the kernels are vector-issue / latency bound (see "valu").
+        roof_np = {"kernel": "k_narrow<false>", "bound": "hbm", "achieved": BYTES_PER_OP * st["candidates"] / (np_ms * 1e-3) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms_per_launch": np_ms,
                    "units_per_launch": st["candidates"], "bytes_per_unit": BYTES_PER_OP}
-        roof_bp = {"kernel": "k_bp_dfs32 (+ k_bp_expand seed levels, + k_bp_dfs Float64 resolver)", "bound": "hbm",
+        roof_bp = {"kernel": "k_bp_dfs32 (+ k_bp_expand seed levels when the batch has < 2048 items)", "bound": "hbm",
                    "achieved": BYTES_PER_NODE_TEST * st["node_tests"] / (bp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "traffic": None, "ms_per_launch": bp_ms,
                    "units_per_launch": st["node_tests"], "bytes_per_unit": BYTES_PER_NODE_TEST}
         for r in (roof_np, roof_bp):
             r["frac"] = r["achieved"] / r["peak"]
-        # vector-ALU view of the broadphase: one node test is ~440 single-precision vector instructions per wave of 64
-        # pairs (SQ_INSTS_VALU / iterations, profiles/), i.e. the kernel is instruction-issue bound
-        roof_bp["valu"] = {"valu_instructions_per_wave_iteration": 440,
-                           "issue_bound_ms": 440.0 * (st["node_tests"] / 64.0) * 2.0 / (1024 * 2.1e9) * 1e3,
-                           "note": "1024 SIMDs, 2 cycles per wave64 FP32 instruction at >= 2 waves per SIMD, 2.1 GHz"}
+        # vector-ALU view (what actually bounds both kernels): measured wave-level VALU instruction counts per unit
+        # (rocprofv3 SQ_INSTS_VALU, profiles/pmc_valu.json) x the issue cost of a wave64 instruction on a SIMD-32
+        # (MI355X_MICROARCH.md: 2 cycles single precision, 4 cycles double precision) over 1024 SIMDs at 2.4 GHz
+        pv = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        if os.path.exists(pv):
+            try:
+                vj = json.load(open(pv))
+                for r, key, unit_key, cyc, what in ((roof_bp, "k_bp_dfs32_valu_insts", "node_tests", 2.0, "single"),
+                                                    (roof_np, "k_narrow_valu_insts", "candidates", 4.0, "double")):
+                    per_unit = vj[key] / vj[unit_key]
+                    issue_ms = per_unit * r["units_per_launch"] * cyc / (1024 * 2.4e9) * 1e3
+                    r["valu"] = {"wave_instructions_per_unit": per_unit, "issue_bound_ms": issue_ms,
+                                 "frac_of_issue_peak": issue_ms / r["ms_per_launch"],
+                                 "note": f"{what}-precision wave64 VALU instruction = {cyc:.0f} cycles on a SIMD-32; 1024 SIMDs, "
+                                         "2.4 GHz; instruction counts from profiles/pmc_valu.json"}
+            except Exception:
+                pass
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # measured offline with rocprofv3 --pmc
         if os.path.exists(pmc):
             try:

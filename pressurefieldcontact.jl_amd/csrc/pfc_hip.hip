@@ -265,7 +265,6 @@ struct DfsArgs {
     int reserve;         // 3 * (max remaining depth) + 3 slots kept free for the pure depth-first mode
     unsigned long long *stamps;  // diagnostic builds: [8..12] cycles in pop+load / SAT / push+flush, iterations, lanes
     int no_filter;       // 1: skip the FP32 filter (every pair runs the Float64 test)
-    int resolver;        // 1: seeds are undecided pairs of k_bp_dfs32 (links already encoded, first test is a re-test)
 };
 
 // one ticket per wave from a device-wide counter: lane 0 takes it, the wave reads it back as a scalar
@@ -286,8 +285,8 @@ __device__ __forceinline__ int next_ticket(int *ctr) {
 // the host when the quaternion is made), T = R_a' R_a_b, t = R_a' v, R = T R_b, then the 15 axes
 // d = |T.L| - (r_a + r_b).  The error of R is below 72 u, so |d_float - d_reference| < 192 u S with
 // S = |v|_1 + sum e_a + sum e_b (internal-internal pairs carry no quaternion error: 16 u S).  d > E proves
-// separation, d < -E on all 15 axes proves overlap; an undecided pair (~1e-5 of its margin scale) is NOT decided here:
-// it is appended to the `und` list and re-tested, with the whole subtree below it, by the Float64 kernel.  The
+// separation, d < -E on all 15 axes proves overlap; an undecided pair (~1e-5 of its margin scale) is NOT decided by
+// this test: it is parked in LDS and settled at the top of the next iteration by the exact Float64 test.  The
 // candidate set and the node-test counts therefore equal the reference's bit for bit (tests/test_gpu_*.py).
 // =================================================================================================================
 struct Dfs32Args {
@@ -299,9 +298,7 @@ struct Dfs32Args {
     WorkRec *cand;
     int *ccount;
     int ccap;
-    WorkRec *und;        // undecided node pairs (links encoded): seeds of the Float64 resolver
-    int *ucount;
-    int ucap;
+    int *ucount;         // statistics: node pairs settled by the exact Float64 test
     int *icnt;
     unsigned *status;
     int reserve;
@@ -609,14 +606,10 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
         int sp = 1, n_out = 0, n_test = 0, n_cand = 0;
         // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
         if (lane == 0) {
-            int sa = s.a, sb = s.b;
-            if (!g.resolver) {
-                sa = (n1[s.a].leaf != kInternal) ? ~s.a : s.a;
-                sb = (n2[s.b].leaf != kInternal) ? ~s.b : s.b;
-            }
+            const int sa = (n1[s.a].leaf != kInternal) ? ~s.a : s.a;
+            const int sb = (n2[s.b].leaf != kInternal) ? ~s.b : s.b;
             stk[0] = make_int2(sa, sb);
         }
-        if (g.resolver) n_test = -1;   // the seed pair was already counted by k_bp_dfs32
         __syncthreads();
 #ifdef PFC_STAMPS
         unsigned long long c_load = 0, c_sat = 0, c_push = 0, c_iter = 0, c_lanes = 0;
@@ -1910,7 +1903,7 @@ struct pfc_context {
     int opt_debug = 0, opt_profile = 0, opt_max_levels = 0, opt_bfs_levels = -1, opt_no_filter = 0;
     // work buffers
     DevBuf<ItemRec> items;
-    DevBuf<WorkRec> frontier[2], cand, und;
+    DevBuf<WorkRec> frontier[2], cand;
     DevBuf<int> clip_n, icnt, trac_item;
     DevBuf<double> acc, res, trac_d, rec;   // trac_d: 8 arrays of tcap; rec: moment records of kRecStride doubles
     DevBuf<int> ctr;                   // [0]=ccount [1]=tcount [2..] fcount[levels+2]
@@ -1933,7 +1926,7 @@ struct pfc_context {
     bool ghave[2] = {false, false};
     bool want_surv = false;   // the narrowphase also lists the contributing candidates (pfc_eval_dual)
     int opt_graph = 1;
-    size_t fcap = 0, ccap = 0, tcap = 0, rcap = 0, ucap = 0;
+    size_t fcap = 0, ccap = 0, tcap = 0, rcap = 0;
     // host-pointer path staging
     DevBuf<double> h_pose, h_twist, h_s, h_wrench, h_sdot;
     DevBuf<int> h_ins, h_counts;
@@ -1948,7 +1941,7 @@ struct pfc_context {
     DevBuf<int> surv;                                       // candidate indices of contributing pairs
     DevBuf<int> poly_item;                                  // kept polygons of bristle pairs (k_narrow -> k_fric)
     DevBuf<double> poly;
-    long long last_undecided = 0;      // node pairs the Float32 broadphase left to the Float64 resolver
+    long long last_undecided = 0;      // node pairs the Float32 broadphase settled with the exact Float64 test
     long long last_tslots = 0;         // traction slots used by the last evaluation (>= traction points)
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
@@ -2018,9 +2011,7 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     size_t t = h->tcap ? h->tcap : 1u << 16;
     size_t rc = h->rcap ? h->rcap : 1u << 12;
     while (rc < c / 32 + (size_t)n_items * 2) rc *= 2;   // about one record per wave round and item boundary
-    size_t uc = h->ucap ? h->ucap : 1u << 14;
-    h->fcap = f; h->ccap = c; h->tcap = t; h->rcap = rc; h->ucap = uc;
-    if ((e = h->und.ensure(uc)) != hipSuccess) return e;
+    h->fcap = f; h->ccap = c; h->tcap = t; h->rcap = rc;
     if ((e = h->rec.ensure(rc * kRecStride)) != hipSuccess) return e;
     if ((e = h->frontier[0].ensure(f)) != hipSuccess) return e;
     if ((e = h->frontier[1].ensure(f)) != hipSuccess) return e;
@@ -2042,7 +2033,7 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     }
     const size_t caps1[] = {h->items.cap, h->acc.cap, h->res.cap, h->icnt.cap, h->ctr.cap, h->frontier[0].cap,
                             h->frontier[1].cap, h->cand.cap, h->clip_n.cap, h->trac_item.cap, h->trac_d.cap, h->rec.cap,
-                            h->tail.cap, h->und.cap};
+                            h->tail.cap};
     for (size_t k = 0; k < sizeof caps0 / sizeof caps0[0]; ++k)
         if (caps0[k] != caps1[k]) { ++h->epoch; break; }
     return hipSuccess;
@@ -2075,7 +2066,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
                 const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st, bool prof) {
     const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
     int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2, *rcount = h->ctr.p + 3;
-    int *ucount = h->ctr.p + 4, *next_seed2 = h->ctr.p + 5, *fcount = h->ctr.p + 6;
+    int *ucount = h->ctr.p + 4, *fcount = h->ctr.p + 6;
     int *pcount = h->ctr.p + ((levels + 9) & ~1);   // after the per-level frontier counts; 8-byte aligned pair
     HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(int) * ((size_t)levels + 12), st));
     HIP_TRY(h, hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * 4, st));
@@ -2114,16 +2105,15 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         if (h->opt_no_filter) {
             // Float64-only traversal (A/B checks)
             d.seeds = h->frontier[L & 1].p; d.n_seed = fcount + L; d.seed_cap = (int)h->fcap; d.next_seed = next_seed;
-            d.no_filter = 1; d.resolver = 0;
+            d.no_filter = 1;
             hipLaunchKernelGGL(k_bp_dfs, dim3(grid_for(bound, 1, 256 * 8)), dim3(64), 0, st, d);
         } else {
             Dfs32Args f;
             f.items = h->items.p; f.seeds = h->frontier[L & 1].p; f.n_seed = fcount + L; f.next_seed = next_seed;
             f.seed_cap = (int)h->fcap; f.cand = h->cand.p; f.ccount = ccount; f.ccap = (int)h->ccap;
-            f.und = h->und.p; f.ucount = ucount; f.ucap = (int)h->ucap; f.icnt = h->icnt.p; f.status = h->status.p;
+            f.ucount = ucount; f.icnt = h->icnt.p; f.status = h->status.p;
             f.reserve = 3 * levels + 3;
             hipLaunchKernelGGL(k_bp_dfs32, dim3(grid_for(bound, 1, 256 * 6)), dim3(kDfsBlock), 0, st, f);
-            (void)next_seed2;
         }
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));
@@ -2234,13 +2224,12 @@ int check_eval(pfc_context *h) {
     h->stats[6] = status; h->stats[7] = h->last_n_items;
     if (status & kStBadIns) return fail(h, PFC_ERR_BAD_ARG, "instruction id out of range in ins_ids");
     h->last_undecided = ctr[4];
-    if (status & (kStFrontierOvf | kStCandOvf | kStTracOvf | kStRecOvf | kStUndOvf)) {
+    if (status & (kStFrontierOvf | kStCandOvf | kStTracOvf | kStRecOvf)) {
         // VectorCache-style growth (src/obb/vector_cache.jl:13-17): at least double, at least the observed need
         if (status & kStFrontierOvf) { size_t f = h->fcap * 2; while (f < (size_t)fpeak) f *= 2; h->fcap = f; }
         if (status & kStCandOvf) { size_t c = h->ccap * 2; while (c < (size_t)ctr[0]) c *= 2; h->ccap = c; }
         if (status & kStTracOvf) { size_t t = h->tcap * 2; while (t < (size_t)ctr[1]) t *= 2; h->tcap = t; }
         if (status & kStRecOvf) { size_t r = h->rcap * 2; while (r < (size_t)ctr[3]) r *= 2; h->rcap = r; }
-        if (status & kStUndOvf) { size_t u = h->ucap * 2; while (u < (size_t)ctr[4]) u *= 2; h->ucap = u; }
         return fail(h, PFC_ERR_OVERFLOW, "work list overflow (status %u): capacities grown to frontier %zu, candidates %zu, tractions %zu, records %zu",
                     status, h->fcap, h->ccap, h->tcap, h->rcap);
     }
@@ -2288,7 +2277,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->d_ins) (void)hipFree(h->d_ins);
     h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
     h->clip_n.release(); h->icnt.release(); h->trac_item.release(); h->acc.release(); h->res.release();
-    h->trac_d.release(); h->rec.release(); h->und.release(); h->ctr.release(); h->status.release(); h->stamps.release();
+    h->trac_d.release(); h->rec.release(); h->ctr.release(); h->status.release(); h->stamps.release();
     h->h_pose.release(); h->h_twist.release(); h->h_s.release(); h->h_wrench.release(); h->h_sdot.release();
     h->h_ins.release(); h->h_counts.release();
     for (int k = 0; k < EV_COUNT; ++k)

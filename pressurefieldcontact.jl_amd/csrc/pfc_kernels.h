@@ -21,7 +21,6 @@ enum : unsigned {
     kStBadIns = 16u,
     kStAbort = 32u,
     kStRecOvf = 64u,
-    kStUndOvf = 128u,
 };
 
 // ---------------------------------------------------------------------------------------------------------------

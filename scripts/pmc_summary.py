@@ -25,8 +25,8 @@ def per_launch(name):
     return 1024.0 * (raw["FETCH_SIZE"].get(name, {}).get("per_call_KB", 0.0) + raw["WRITE_SIZE"].get(name, {}).get("per_call_KB", 0.0))
 
 out = {"k_bp_dfs32_bytes_per_launch": per_launch("pfc::k_bp_dfs32") + per_launch("pfc::k_bp_dfs") + per_launch("pfc::k_bp_expand"),
-       "k_narrow0_bytes_per_launch": per_launch("void pfc::k_narrow<0, false>"),
-       "k_narrow1_bytes_per_launch": per_launch("void pfc::k_narrow<1, false>"),
+       "k_narrow0_bytes_per_launch": per_launch("void pfc::k_narrow<false>"),
+       "k_fric_bytes_per_launch": per_launch("pfc::k_fric"),
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB x 1024, per launch, bench.py default "
                "workload (2048 poses); FETCH_SIZE is NOT doubled: MI355X_MICROARCH.md says it under-reports wide coalesced "
                "streaming reads by 2x and is uncalibrated for other widths; these kernels gather 16-byte pieces of "
