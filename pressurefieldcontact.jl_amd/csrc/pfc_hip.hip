@@ -829,12 +829,20 @@ __device__ __forceinline__ void accumulate_items(double *acc, int item, bool lis
 // Sums of N per-lane values over a whole wave through LDS: lane `lane` writes column `lane` of N rows (row stride 65
 // doubles: conflict-free both ways), lanes lane0 .. lane0+N-1 then add up one row each.  N + ~130 instructions per wave
 // instead of ~30 N for N segmented DPP scans; used when all work items of the wave belong to one item (97 % of the
-// waves of the C3 batch).  Both barriers are wave-local (the block is one wave).
+// waves of the C3 batch).
+// LDS ordering inside ONE wave (the block is a single wave): the LDS unit serves a wave's instructions in order, so a
+// compiler-level fence is all that is needed.  __syncthreads() would also drain vmcnt, i.e. wait for every outstanding
+// global store and atomic of the wave.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <int N>
 __device__ __forceinline__ double lds_row_sums(double *buf, const double *v, bool any, int lane, int lane0) {
 #pragma unroll
     for (int k = 0; k < N; ++k) buf[k * 65 + lane] = any ? v[k] : 0.0;
-    __syncthreads();
+    wave_lds_sync();
     double t = 0.0;
     const int row = lane - lane0;
     if (row >= 0 && row < N) {
@@ -844,7 +852,7 @@ __device__ __forceinline__ double lds_row_sums(double *buf, const double *v, boo
         for (int j = 0; j < 64; j += 4) { t0 += r[j]; t1 += r[j + 1]; t2 += r[j + 2]; t3 += r[j + 3]; }
         t = (t0 + t1) + (t2 + t3);
     }
-    __syncthreads();
+    wave_lds_sync();
     return t;
 }
 
