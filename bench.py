@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--friction", choices=["bristle", "regularized"], default="bristle",
                     help="friction model of the C3 instruction (BASELINE: bristle; regularized is an experiment knob)")
+    ap.add_argument("--split-min", type=int, default=-1, help="library option split_min (-1: library default 1024; 0: never split)")
     ap.add_argument("--bfs-levels", type=int, default=-1, help="broadphase BFS levels before the DFS kernel (-1 = auto)")
     args = ap.parse_args()
 
@@ -108,6 +109,8 @@ def main():
     m = pfc.configs.build_scenario(w, device=local_rank)
     if args.bfs_levels >= 0:
         m.set_option("bfs_levels", args.bfs_levels)
+    if args.split_min >= 0:
+        m.set_option("split_min", args.split_min)
     if os.environ.get("PFC_NO_FILTER"):
         m.set_option("no_filter", int(os.environ["PFC_NO_FILTER"]))     # experiment knob (1: FP64 only, 2: skip R loads - wrong results)
     n = w.n_items
@@ -154,6 +157,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     st = m.stats()
+    parts = m.last_parts()      # 2: the step ran as two concurrent half-batches (library option split_min)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(st["candidates"]), float(n), float(st["node_tests"]), float(st["tractions"])],
@@ -171,15 +175,20 @@ def main():
         # SURVEY §8(d) accounting: algorithmic bytes / kernel time against the HBM peak.  Both kernels re-read their
         # 96..256-byte records from L2 / Infinity Cache across the poses of a batch, so "achieved" can exceed what HBM
         # could deliver while the PMC traffic stays tiny: the kernels are vector-issue / latency bound (see "valu").
-        roof_np = {"kernel": "k_narrow<false>", "bound": "hbm", "achieved": BYTES_PER_OP * st["candidates"] / (np_ms * 1e-3) / 1e9,
+        roof_np = {"kernel": "k_narrow<false>", "bound": "hbm", "achieved": BYTES_PER_OP * st["candidates"] / parts / (np_ms * 1e-3) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms_per_launch": np_ms,
-                   "units_per_launch": st["candidates"], "bytes_per_unit": BYTES_PER_OP}
+                   "units_per_launch": st["candidates"] / parts, "bytes_per_unit": BYTES_PER_OP}
         roof_bp = {"kernel": "k_bp_dfs32 (+ k_bp_expand seed levels when the batch has < 2048 items)", "bound": "hbm",
-                   "achieved": BYTES_PER_NODE_TEST * st["node_tests"] / (bp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                   "achieved": BYTES_PER_NODE_TEST * st["node_tests"] / parts / (bp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "traffic": None, "ms_per_launch": bp_ms,
-                   "units_per_launch": st["node_tests"], "bytes_per_unit": BYTES_PER_NODE_TEST}
+                   "units_per_launch": st["node_tests"] / parts, "bytes_per_unit": BYTES_PER_NODE_TEST}
         for r in (roof_np, roof_bp):
             r["frac"] = r["achieved"] / r["peak"]
+            if parts > 1:
+                r["launch_note"] = (f"the step runs as {parts} concurrent half-batches on two streams: a launch processes "
+                                    "1/2 of the step's units WHILE kernels of the other half share the CUs, so per-launch "
+                                    "durations are longer than those of an exclusive launch (stage_ms_per_step = mean over "
+                                    "the half-launches; they overlap and do not add up to ms_per_step)")
         # vector-ALU view (what actually bounds both kernels): measured wave-level VALU instruction counts per unit
         # (rocprofv3 SQ_INSTS_VALU, profiles/pmc_valu.json) x the issue cost of a wave64 instruction on a SIMD-32
         # (MI355X_MICROARCH.md: 2 cycles single precision, 4 cycles double precision) over 1024 SIMDs at 2.4 GHz
@@ -226,6 +235,7 @@ def main():
             "contact_pairs_per_s": items_step * K / dt,
             "node_tests_per_s": nodes_step * K / dt,
             "stage_ms_per_step": {k: v / K for k, v in stage.items()},
+            "concurrent_parts": parts,
             "roofline": dominant,
             "roofline_other": other,
         }

@@ -166,7 +166,10 @@ int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, con
  * "bfs_levels" (-1 = automatic: level-synchronous seed expansion only until there are >= 2048 seed pairs),
  * "graph" (1 = capture the launch sequence into a hipGraph per evaluation shape and replay it; default 1),
  * "no_filter" (1 = run the whole broadphase in the exact Float64 kernel instead of the Float32 filter + Float64
- * resolver; same candidate set, for A/B checks). */
+ * resolver; same candidate set, for A/B checks), "split_min" (default 1024; 0 = never: an evaluation of at least
+ * this many items with ins_ids given is run as two concurrent halves on two streams with their own work lists, the
+ * vector-ALU-bound broadphase of one half sharing the CUs with the latency-bound narrowphase of the other; results,
+ * counters and stream ordering are those of the unsplit call). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);
 
 /* Totals of the last checked evaluation: out[0..7] = {node tests, candidate pairs, non-empty pairs, traction
@@ -174,8 +177,11 @@ int pfc_set_option(pfc_handle h, const char *name, long long value);
 int pfc_get_stats(pfc_handle h, long long *out8);
 
 /* Per-stage device time of the last evaluation in ms (profile option): out[0..5] = {setup, broadphase,
- * narrowphase, bristle passes (cop + K + eigen + friction), finalisation, total}.  Synchronises. */
+ * narrowphase, bristle passes (cop + K + eigen + friction), finalisation, total}.  Synchronises.  If the evaluation
+ * ran as two concurrent halves (pfc_last_parts() == 2) a stage time is the mean over the two half-launches, each of
+ * which processed half of the items while stages of the other half were running; total is the longer half. */
 int pfc_get_stage_ms(pfc_handle h, float *out6);
+int pfc_last_parts(pfc_handle h);   /* 1, or 2 if the last checked evaluation ran as two concurrent halves */
 
 /*
  * Debug views of the last evaluation (debug option), needed to restate test/test_normal.jl:31-41 and

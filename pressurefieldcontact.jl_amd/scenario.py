@@ -358,6 +358,10 @@ class MechanismScenario:
         k = ("node_tests", "candidates", "nonempty", "tractions", "levels", "frontier_peak", "status", "n_items")
         return dict(zip(k, [int(v) for v in out]))
 
+    def last_parts(self) -> int:
+        """1, or 2 if the last checked evaluation ran as two concurrent halves (option split_min)."""
+        return int(_lib.lib().pfc_last_parts(self._h))
+
     def stage_ms(self) -> dict:
         out = (C.c_float * 6)()
         self._check(_lib.lib().pfc_get_stage_ms(self._h, out))

@@ -190,3 +190,30 @@ def test_scatter_generalized_third_law(pfc):
     ref2 = O.scatter_generalized(wrench, x_w_r2, body_1b, np.zeros(n, dtype=np.int32), jac, None, 1)
     np.testing.assert_allclose(f2, ref2, rtol=1e-11, atol=1e-11 * np.abs(ref2).max())
     m.close()
+
+
+def test_split_evaluation_equals_unsplit(pfc):
+    """Batches of >= split_min items run as two concurrent halves on two streams (pfc_set_option "split_min"): same
+    per-item integers, same wrenches up to summation order, merged totals, and growth of the work lists of BOTH halves
+    from their small initial capacities (the first evaluations overflow and are re-issued inside pfc_eval)."""
+    w = pfc.configs.c3_blob_tool(1100, seed=31, n_div_blob=8, n_div_tool=6)
+    w.s[:] = np.random.default_rng(5).standard_normal((w.n_items, 6)) * 1e-3
+    out = {}
+    for split_min in (0, 1024):
+        m = pfc.configs.build_scenario(w)
+        m.set_option("split_min", split_min)
+        wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        out[split_min] = (wr, sd, ct, m.stats(), m.last_parts())
+        # a second call reuses the grown buffers and the captured graphs of both halves
+        wr2, sd2, ct2 = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        assert np.array_equal(ct2, ct)
+        np.testing.assert_allclose(wr2, wr, rtol=1e-11, atol=1e-11 * np.abs(wr).max())
+        m.close()
+    a, b = out[0], out[1024]
+    assert a[4] == 1 and b[4] == 2
+    assert np.array_equal(a[2], b[2])
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-11, atol=1e-11 * np.abs(a[0]).max())
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-7, atol=1e-7 * np.abs(a[1]).max())
+    for key in ("node_tests", "candidates", "nonempty", "tractions", "n_items"):
+        assert a[3][key] == b[3][key], key
+    assert np.all(a[2][:, 3] > 0)
