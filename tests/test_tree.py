@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from helpers import oracle_run, sorted_pairs
+from tree_reference import build_tree_py
 
 
 def _meshes(g):
@@ -36,7 +37,7 @@ def _check_leaf_boxes(g, m, t):
 def test_native_median_tree_matches_python_statement(pfc):
     g = pfc.geometry
     for m in _meshes(g):
-        tn, tp = g.build_tree(m, "median"), g.build_tree_py(m)
+        tn, tp = g.build_tree(m, "median"), build_tree_py(g, m)
         assert np.array_equal(tn.child, tp.child) and np.array_equal(tn.leaf, tp.leaf)
         internal = tn.leaf == g.INTERNAL
         np.testing.assert_array_equal(tn.c[internal], tp.c[internal])      # same arithmetic, same order
