@@ -1205,7 +1205,6 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         g.trac.dA[tpos] = dA; g.trac.p[tpos] = p;
                         ++tpos;
                     }
-                    V3 tk;
                     if (reg) {
                         // yes_contact!(::Regularized) (friction.jl:50-72) fused
                         V3 vt = vec_sub_vec_proj(rdot, nh);
@@ -1218,22 +1217,31 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                             double mu = clamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
                             T = (vt * (-mu)) / mg;
                         }
-                        tk = nh * p_dA + T * p_dA;
+                        const V3 tk = nh * p_dA + T * p_dA;
+                        const V3 ta = cross(r, tk);
+                        sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+                        sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
                     } else {
-                        // normal_wrench_cop (normal.jl:17-34) fused: pass 1 of the bristle model
-                        tk = nh * p_dA;
+                        // normal_wrench_cop (normal.jl:17-34) fused: pass 1 of the bristle model.  The traction of a
+                        // point is n̂ w (w = p dA) with n̂ constant over the polygon, so only W = sum w and the moments
+                        // of w about the polygon centroid are accumulated per point; sum w r, the force n̂ W and the
+                        // torque (sum w r) x n̂ follow after the loop (a quarter of the loop's instructions).
                         sum[6] += p_dA;
-                        sum[7] += p_dA * r.x; sum[8] += p_dA * r.y; sum[9] += p_dA * r.z;
                         const V3 rc = r - cen;
                         const double wx = p_dA * rc.x, wy = p_dA * rc.y, wz = p_dA * rc.z;
                         wr1[0] += wx; wr1[1] += wy; wr1[2] += wz;
                         wrr[0] += wx * rc.x; wrr[1] += wx * rc.y; wrr[2] += wx * rc.z;
                         wrr[3] += wy * rc.y; wrr[4] += wy * rc.z; wrr[5] += wz * rc.z;
                     }
-                    V3 ta = cross(r, tk);
-                    sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
-                    sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
                 }
+            }
+            if (!reg) {
+                const double W = sum[6];
+                const V3 Sr = mk3(wr1[0] + W * cen.x, wr1[1] + W * cen.y, wr1[2] + W * cen.z);   // sum w r
+                const V3 ta = cross(Sr, nh);
+                sum[0] = ta.x; sum[1] = ta.y; sum[2] = ta.z;
+                sum[3] = nh.x * W; sum[4] = nh.y * W; sum[5] = nh.z * W;
+                sum[7] = Sr.x; sum[8] = Sr.y; sum[9] = Sr.z;
             }
             if (store)  // unused slots of this lane's run (area <= 0 or p <= 0 points)
                 for (; tpos < tbase + slots; ++tpos) g.trac.item[tpos] = -1;
