@@ -115,6 +115,8 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
     const double v_c = it->v_c, mu_s = it->mu_s, mu_d = it->mu_d;
     const double tau = it->tau, k_bar = it->k_bar;
     const int nq = it->nq;
+    Du kW = du(0.0), km[3] = {du(0.0), du(0.0), du(0.0)};   // MODE 1 accumulators
+    Du kQ[6] = {du(0.0), du(0.0), du(0.0), du(0.0), du(0.0), du(0.0)};
     Du3 v2 = vert(n - 1);
     for (int k = 0; k < n; ++k) {
         const Du3 v1 = v2;
@@ -164,37 +166,16 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
                 sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
                 sum[3] += Tc.x; sum[4] += Tc.y; sum[5] += Tc.z;
             } else if constexpr (MODE == 1) {
-                // calc_patch_spatial_stiffness! (friction.jl:147-169), r - cop
+                // calc_patch_spatial_stiffness! (friction.jl:147-169) with x = r - cop.  n̂ is constant over the polygon, so
+                // per point only W = sum w, m1 = sum w x and Q = sum w x x' are accumulated; the 21 entries follow after
+                // the loop (below).
                 const Du3 x = r - cop;
-                const Du3 xn = dcross(x, nh);
-                const Du q1s = x.x * x.x, q2s = x.y * x.y, q3s = x.z * x.z;
-                const Du xy = x.x * x.y, xz = x.x * x.z, yz = x.y * x.z;
-                // K11 -= w ([x]x^2 + (x x n)(x x n)')
-                sum[0] += -(p_dA * ((-q2s - q3s) + xn.x * xn.x));
-                sum[1] += -(p_dA * (xy + xn.x * xn.y));
-                sum[2] += -(p_dA * (xz + xn.x * xn.z));
-                sum[3] += -(p_dA * ((-q1s - q3s) + xn.y * xn.y));
-                sum[4] += -(p_dA * (yz + xn.y * xn.z));
-                sum[5] += -(p_dA * ((-q1s - q2s) + xn.z * xn.z));
-                // K12 += w ([x]x - (x x n) n'), column-major
-                sum[6] += p_dA * (du(0.0) - xn.x * nh.x);
-                sum[7] += p_dA * (x.z - xn.y * nh.x);
-                sum[8] += p_dA * (-x.y - xn.z * nh.x);
-                sum[9] += p_dA * (-x.z - xn.x * nh.y);
-                sum[10] += p_dA * (du(0.0) - xn.y * nh.y);
-                sum[11] += p_dA * (x.x - xn.z * nh.y);
-                sum[12] += p_dA * (x.y - xn.x * nh.z);
-                sum[13] += p_dA * (-x.x - xn.y * nh.z);
-                sum[14] += p_dA * (du(0.0) - xn.z * nh.z);
-                // K22 += w (I - n n')
-                sum[15] += p_dA * (du(1.0) - nh.x * nh.x);
-                sum[16] += p_dA * (du(0.0) - nh.x * nh.y);
-                sum[17] += p_dA * (du(0.0) - nh.x * nh.z);
-                sum[18] += p_dA * (du(1.0) - nh.y * nh.y);
-                sum[19] += p_dA * (du(0.0) - nh.y * nh.z);
-                sum[20] += p_dA * (du(1.0) - nh.z * nh.z);
+                const Du wx = p_dA * x.x, wy = p_dA * x.y, wz = p_dA * x.z;
+                kW += p_dA;
+                km[0] += wx; km[1] += wy; km[2] += wz;
+                kQ[0] += wx * x.x; kQ[1] += wx * x.y; kQ[2] += wx * x.z;
+                kQ[3] += wy * x.y; kQ[4] += wy * x.z; kQ[5] += wz * x.z;
             } else {
-            Du3 tk;
             if (reg) {
                 // yes_contact!(::Regularized) (friction.jl:50-72)
                 const Du3 vt = dvec_sub_vec_proj(rdot, nh);
@@ -207,18 +188,44 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
                     const Du mu = dclamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
                     T = (vt * (-mu)) / mg;
                 }
-                tk = nh * p_dA + T * p_dA;
+                const Du3 tk = nh * p_dA + T * p_dA;
+                const Du3 ta = dcross(r, tk);
+                sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+                sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
             } else {
-                // normal_wrench_cop (normal.jl:17-34)
-                tk = nh * p_dA;
+                // normal_wrench_cop (normal.jl:17-34): the traction is n̂ w with n̂ constant over the polygon; force and
+                // torque follow from W and sum w r after the loop
                 sum[6] += p_dA;
                 sum[7] += p_dA * r.x; sum[8] += p_dA * r.y; sum[9] += p_dA * r.z;
             }
-            const Du3 ta = dcross(r, tk);
-            sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
-            sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
             }
         }
+    }
+    if constexpr (MODE == 0) {
+        if (!reg) {
+            const Du3 ta = dcross(dmk(sum[7], sum[8], sum[9]), nh);
+            sum[0] = ta.x; sum[1] = ta.y; sum[2] = ta.z;
+            sum[3] = nh.x * sum[6]; sum[4] = nh.y * sum[6]; sum[5] = nh.z * sum[6];
+        }
+    }
+    if constexpr (MODE == 1) {
+        // K22 = W (I - n n'),  K12 = [m1]x - (m1 x n) n',  K11 = -(Q - tr(Q) I) - [n]x Q [n]x'   (Q symmetric)
+        const Du3 m1 = dmk(km[0], km[1], km[2]);
+        const Du3 mn = dcross(m1, nh);
+        const Du tr = (kQ[0] + kQ[3]) + kQ[5];
+        const Du3 c0 = dmk(kQ[0], kQ[1], kQ[2]), c1 = dmk(kQ[1], kQ[3], kQ[4]), c2 = dmk(kQ[2], kQ[4], kQ[5]);
+        const Du3 a0 = dcross(nh, c0), a1 = dcross(nh, c1), a2 = dcross(nh, c2);                 // M = [n]x Q (columns)
+        // S = M [n]x': row i of S = n x (row i of M)
+        const Du3 r0 = dcross(nh, dmk(a0.x, a1.x, a2.x)), r1 = dcross(nh, dmk(a0.y, a1.y, a2.y));
+        const Du3 r2 = dcross(nh, dmk(a0.z, a1.z, a2.z));
+        sum[0] += -((kQ[0] - tr) + r0.x); sum[1] += -(kQ[1] + r0.y); sum[2] += -(kQ[2] + r0.z);
+        sum[3] += -((kQ[3] - tr) + r1.y); sum[4] += -(kQ[4] + r1.z); sum[5] += -((kQ[5] - tr) + r2.z);
+        sum[6] += du(0.0) - mn.x * nh.x; sum[7] += m1.z - mn.y * nh.x; sum[8] += -m1.y - mn.z * nh.x;
+        sum[9] += -m1.z - mn.x * nh.y; sum[10] += du(0.0) - mn.y * nh.y; sum[11] += m1.x - mn.z * nh.y;
+        sum[12] += m1.y - mn.x * nh.z; sum[13] += -m1.x - mn.y * nh.z; sum[14] += du(0.0) - mn.z * nh.z;
+        sum[15] += kW * (du(1.0) - nh.x * nh.x); sum[16] += kW * (du(0.0) - nh.x * nh.y);
+        sum[17] += kW * (du(0.0) - nh.x * nh.z); sum[18] += kW * (du(1.0) - nh.y * nh.y);
+        sum[19] += kW * (du(0.0) - nh.y * nh.z); sum[20] += kW * (du(1.0) - nh.z * nh.z);
     }
 }
 
