@@ -1914,6 +1914,7 @@ struct pfc_context {
     MeshDev *d_meshes = nullptr;
     InsDev *d_ins = nullptr;
     int max_levels = 1;
+    int max_leaves = 2;                // largest n_leaf(mesh_1) + n_leaf(mesh_2) over the instructions
     bool any_bristle = false, any_tet_tet = false;
     // options
     int opt_debug = 0, opt_profile = 0, opt_max_levels = 0, opt_bfs_levels = -1, opt_no_filter = 0;
@@ -2080,8 +2081,16 @@ int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
     if (h->opt_bfs_levels >= 0) {
         L = h->opt_bfs_levels;
     } else {
+        // Level-synchronous expansion only buys parallelism for the depth-first kernel (one workgroup per seed, ~1 000
+        // resident workgroups); each level is a launch (~8 us).  Measured optimum (scripts/latency.py, bench.py):
+        // big trees (a traversal is ~1.5 node tests per leaf) want >= 1 024 seeds, or 4 096 when there are only a few
+        // items; small trees are done in a few iterations per seed, so 64 seeds suffice (C4: 200 -> 144 us).  A large
+        // batch over small trees is usually a sparse-contact pile where a few pairs carry the work: one level spreads them.
+        const bool big = h->max_leaves >= 8192, mid = h->max_leaves >= 1024;
+        const double target = big ? (n_items >= 256 ? 1024.0 : 4096.0) : (mid ? 1024.0 : 64.0);
         double seeds = (double)n_items;
-        while (seeds < 2048.0 && L < 8) { seeds *= 4.0; ++L; }
+        while (seeds < target && L < 8) { seeds *= 4.0; ++L; }
+        if (L == 0 && !big && n_items >= 1024) L = 1;
     }
     return L > levels ? levels : L;
 }
@@ -2289,6 +2298,7 @@ int make_twin(pfc_context *h) {
     if (!t) return fail(h, PFC_ERR_NOMEM, "out of host memory");
     t->device = h->device; t->is_twin = true; t->finalized = true;
     t->ins = h->ins; t->d_meshes = h->d_meshes; t->d_ins = h->d_ins; t->max_levels = h->max_levels;
+    t->max_leaves = h->max_leaves;
     t->any_bristle = h->any_bristle; t->any_tet_tet = h->any_tet_tet; t->opt_split_min = 0;
     if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -2545,10 +2555,13 @@ int pfc_finalize(pfc_handle h) {
         HIP_TRY(h, hipMemcpy(h->d_meshes, md.data(), sizeof(MeshDev) * md.size(), hipMemcpyHostToDevice));
     }
     h->max_levels = 1;
+    h->max_leaves = 2;
     h->any_bristle = false;
     for (const InsDev &in : h->ins) {
         int lv = h->meshes[in.m1].depth + h->meshes[in.m2].depth + 1;
         if (lv > h->max_levels) h->max_levels = lv;
+        const int lf = (h->meshes[in.m1].n_node + 1) / 2 + (h->meshes[in.m2].n_node + 1) / 2;
+        if (lf > h->max_leaves) h->max_leaves = lf;
         if (in.model == PFC_BRISTLE) h->any_bristle = true;
         if (h->meshes[in.m1].n_tri == 0) h->any_tet_tet = true;
     }

@@ -10,6 +10,8 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
                 ("C4 256 scenes", pfc.configs.c2_box_on_plane(256, montecarlo=True)),
                 ("C5 pile 2016 instructions", pfc.configs.c5_pile())):
     m = pfc.configs.build_scenario(w)
+    if os.environ.get("PFC_BFS"):
+        m.set_option("bfs_levels", int(os.environ["PFC_BFS"]))
     for _ in range(5):
         m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
     n = 100
