@@ -1800,8 +1800,10 @@ __global__ void k_final(BrArgs g) {
 // Gathers everything the host needs to judge an evaluation into one small block (one D2H copy instead of five):
 // tail[0..3] status words, tail[4..11] totals {node tests, non-empty pairs, traction points, 0} as 64-bit,
 // tail[12..] the counter block (candidates, traction slots, seed ticket, records, frontier sizes per level).
-__global__ void __launch_bounds__(256) k_pack(int n_items, const int *icnt, const int *ctr, int n_ctr,
-                                               const unsigned *status, int *tail) {
+// Also leaves the counters and the status word zeroed for the next evaluation (two memset nodes less per launch
+// sequence: what a small scene pays is launches, not kernels); the packed copy in `tail` is what later readers use.
+__global__ void __launch_bounds__(256) k_pack(int n_items, const int *icnt, int *ctr, int n_ctr, unsigned *status,
+                                               int *tail) {
     __shared__ unsigned long long tot[3];
     if (threadIdx.x < 3) tot[threadIdx.x] = 0ull;
     __syncthreads();
@@ -1811,10 +1813,10 @@ __global__ void __launch_bounds__(256) k_pack(int n_items, const int *icnt, cons
     }
     atomicAdd(&tot[0], a); atomicAdd(&tot[1], b); atomicAdd(&tot[2], c);
     __syncthreads();
-    if (threadIdx.x < 4) tail[threadIdx.x] = (int)status[threadIdx.x];
+    if (threadIdx.x < 4) { tail[threadIdx.x] = (int)status[threadIdx.x]; status[threadIdx.x] = 0u; }
     if (threadIdx.x < 3) reinterpret_cast<unsigned long long *>(tail + 4)[threadIdx.x] = tot[threadIdx.x];
     if (threadIdx.x == 3) reinterpret_cast<unsigned long long *>(tail + 4)[3] = 0ull;
-    for (int k = threadIdx.x; k < n_ctr; k += blockDim.x) tail[12 + k] = ctr[k];
+    for (int k = threadIdx.x; k < n_ctr; k += blockDim.x) { tail[12 + k] = ctr[k]; ctr[k] = 0; }
 }
 
 // addGeneralizedForcesThirdLaw! (non_friction.jl:267-286): per item, the wrench on body 2 (frame r2) goes to the
@@ -2027,8 +2029,13 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     if ((e = h->acc.ensure((size_t)n_items * kAccStride)) != hipSuccess) return e;
     if ((e = h->res.ensure((size_t)n_items * kResStride)) != hipSuccess) return e;
     if ((e = h->icnt.ensure((size_t)n_items * 4)) != hipSuccess) return e;
-    if ((e = h->ctr.ensure((size_t)h->max_levels + 12)) != hipSuccess) return e;
-    if ((e = h->status.ensure(4)) != hipSuccess) return e;
+    {
+        const size_t c0 = h->ctr.cap, s0 = h->status.cap;
+        if ((e = h->ctr.ensure((size_t)h->max_levels + 12)) != hipSuccess) return e;
+        if ((e = h->status.ensure(4)) != hipSuccess) return e;
+        if (h->ctr.cap != c0 && (e = hipMemset(h->ctr.p, 0, sizeof(int) * h->ctr.cap)) != hipSuccess) return e;
+        if (h->status.cap != s0 && (e = hipMemset(h->status.p, 0, sizeof(unsigned) * h->status.cap)) != hipSuccess) return e;
+    }
     if ((e = h->stamps.ensure(16)) != hipSuccess) return e;
     size_t f = h->fcap ? h->fcap : 1u << 16;
     while (f < (size_t)n_items * 8) f *= 2;
@@ -2102,8 +2109,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2, *rcount = h->ctr.p + 3;
     int *ucount = h->ctr.p + 4, *fcount = h->ctr.p + 6;
     int *pcount = h->ctr.p + ((levels + 9) & ~1);   // after the per-level frontier counts; 8-byte aligned pair
-    HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(int) * ((size_t)levels + 12), st));
-    HIP_TRY(h, hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * 4, st));
+    // counters and status are zero here: k_pack of the previous evaluation (or ensure_work after an allocation) left them so
 #ifdef PFC_STAMPS
     HIP_TRY(h, hipMemsetAsync(h->stamps.p, 0, sizeof(unsigned long long) * 16, st));
 #endif
@@ -2699,8 +2705,8 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     else HIP_TRY(h, hipMemsetAsync(dsd, 0, sizeof(double) * nk * 6, st));
     HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
     DualArgs a;
-    a.items = h->items.p; a.cand = h->cand.p; a.ccount = h->ctr.p; a.ccap = (int)h->ccap;
-    a.surv = h->surv.p; a.scount = h->ctr.p + (((h->last_levels + 9) & ~1) + 1);
+    a.items = h->items.p; a.cand = h->cand.p; a.ccount = h->tail.p + 12; a.ccap = (int)h->ccap;   // packed copy of the counters
+    a.surv = h->surv.p; a.scount = h->tail.p + 12 + (((h->last_levels + 9) & ~1) + 1);
     a.n_items = n_items; a.n_dir = n_dir; a.d_pose = dp; a.d_twist = dt; a.d_s = dsd; a.icnt = h->icnt.p;
     a.dacc = h->dual_acc.p; a.dres = h->dual_res.p; a.d_wrench = h->dual_out.p; a.d_sdot = h->dual_out.p + nk * 6;
     a.status = h->status.p;
