@@ -1,0 +1,628 @@
+// pfc_bp.h -- broadphase kernels: level-synchronous seed expansion, the single-precision workgroup depth-first kernel with its cooperative exact test, and the all-Float64 descent kept for A/B checks.  Included by pfc_hip.hip inside namespace pfc (device code only).
+#pragma once
+
+// =================================================================================================================
+// broadphase: one level of the simultaneous descent (src/obb/tree_types.jl:88-111)
+// =================================================================================================================
+struct BpArgs {
+    const ItemRec *items;
+    const WorkRec *fin;
+    WorkRec *fout;
+    WorkRec *cand;
+    int *fcount;     // fcount[level] = size of fin, fcount[level + 1] accumulates the size of fout
+    int *ccount;     // candidate counter
+    int *icnt;
+    unsigned *status;
+    int level, fcap, ccap;
+};
+
+__device__ __forceinline__ void count_per_item(int *icnt, int item, int slot, bool listed, bool flag, int n = 1) {
+    // per-item integer counter: one atomic per run of equal items in the wave
+    if (__ballot(flag) == 0) return;
+    const Seg sg = seg_setup(listed ? item : -1);
+    const int t = seg_sum(flag ? n : 0, sg);
+    if (sg.tail && sg.valid && t != 0) atomicAdd(&icnt[4 * (size_t)item + slot], t);
+}
+
+__global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
+    int n_in = g.fcount[g.level];
+    if (n_in > g.fcap) n_in = g.fcap;  // the previous level overflowed (flagged there); never read past the buffer
+    const int stride = gridDim.x * blockDim.x;
+    const int lane = lane_id();
+    // every lane of a wave runs the same number of iterations so the wave-level ballots are well defined
+    const int n_round = (n_in + stride - 1) / stride;
+    for (int rd = 0; rd < n_round; ++rd) {
+        int idx = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool active = idx < n_in;
+        WorkRec w;
+        w.item = 0; w.a = 0; w.b = 0; w.pad = 0;
+        bool hit = false, la = false, lb = false;
+        int ca0 = 0, ca1 = 0, cb0 = 0, cb1 = 0, leaf_a = 0, leaf_b = 0;
+        if (active) {
+            w = g.fin[idx];
+            const ItemRec *it = g.items + w.item;
+            const NodeRec a = it->nodes1[w.a];
+            const NodeRec b = it->nodes2[w.b];
+            hit = bb_bb_intersect(a, b, it->R12, it->t12);
+            la = a.leaf != kInternal; lb = b.leaf != kInternal;
+            ca0 = node_index(a.child0); ca1 = node_index(a.child1); cb0 = node_index(b.child0); cb1 = node_index(b.child1);
+            leaf_a = a.leaf; leaf_b = b.leaf;
+        }
+        count_per_item(g.icnt, w.item, 0, active, active);
+        bool is_cand = hit && la && lb;
+        bool two = hit && (la != lb);
+        bool four = hit && !la && !lb;
+        unsigned long long mc = __ballot(is_cand), m2 = __ballot(two), m4 = __ballot(four);
+        // candidates
+        if (mc) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(g.ccount, __builtin_popcountll(mc));
+            base = __shfl(base, 0, 64);
+            if (is_cand) {
+                int pos = base + prefix_count(mc);
+                if (pos < g.ccap) {
+                    WorkRec c;
+                    c.item = w.item; c.a = leaf_a; c.b = leaf_b; c.pad = 0;
+                    g.cand[pos] = c;
+                } else {
+                    atomicOr(g.status, kStCandOvf);
+                }
+            }
+            count_per_item(g.icnt, w.item, 1, active, is_cand);
+        }
+        // children
+        if (m2 | m4) {
+            int tot = 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&g.fcount[g.level + 1], tot);
+            base = __shfl(base, 0, 64);
+            int pos = base + 2 * prefix_count(m2) + 4 * prefix_count(m4);
+            int nout = two ? 2 : (four ? 4 : 0);
+            if (nout) {
+                if (pos + nout <= g.fcap) {
+                    WorkRec c;
+                    c.item = w.item; c.pad = 0;
+                    if (two) {
+                        if (la) {  // leaf_1: descend tree_2 (:97-98)
+                            c.a = w.a; c.b = cb0; g.fout[pos] = c;
+                            c.b = cb1; g.fout[pos + 1] = c;
+                        } else {   // leaf_2: descend tree_1 (:101-103)
+                            c.b = w.b; c.a = ca0; g.fout[pos] = c;
+                            c.a = ca1; g.fout[pos + 1] = c;
+                        }
+                    } else {       // (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107)
+                        c.a = ca0; c.b = cb0; g.fout[pos] = c;
+                        c.a = ca1; c.b = cb0; g.fout[pos + 1] = c;
+                        c.a = ca0; c.b = cb1; g.fout[pos + 2] = c;
+                        c.a = ca1; c.b = cb1; g.fout[pos + 3] = c;
+                    }
+                } else {
+                    atomicOr(g.status, kStFrontierOvf);
+                }
+            }
+        }
+    }
+}
+
+// =================================================================================================================
+// broadphase, deep part: one wave per seed node pair, cooperative depth-first descent with the work stack in LDS.
+// Same node-pair tests as the recursion of tree_tree_intersect (src/obb/tree_types.jl:88-111), 64 at a time: each
+// iteration pops up to 64 node pairs from the top of the stack (one per lane), runs the SAT, and pushes the 2 or 4
+// child pairs / stages the leaf-leaf candidates with ballot + mbcnt prefix sums.  No global frontier, no global
+// atomics per test: a seed's candidates leave in runs of up to kDfsOut records (one atomic per flush), which also
+// keeps the candidate list grouped by item for the reductions downstream.
+// =================================================================================================================
+// In-kernel phase stamps (diagnostic builds only: -DPFC_STAMPS).  s_memtime ticks = shader cycles; the sums go to a
+// buffer of their own that no kernel reads (MI355X guide: 'In-kernel stamps').
+#ifdef PFC_STAMPS
+#define STAMP(t)                                                                 \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+#else
+#define STAMP(t) do { } while (0)
+#endif
+
+constexpr int kDfsStack = 1024;  // node pairs per wave (8 KiB)
+constexpr int kDfsOut = 320;     // staged candidates per wave (2.5 KiB)
+
+struct DfsArgs {
+    const ItemRec *items;
+    const WorkRec *seeds;
+    const int *n_seed;   // device counter
+    int *next_seed;      // device counter (zeroed per evaluation): dynamic seed queue head
+    int seed_cap;
+    WorkRec *cand;
+    int *ccount;
+    int ccap;
+    int *icnt;
+    unsigned *status;
+    int reserve;         // 3 * (max remaining depth) + 3 slots kept free for the pure depth-first mode
+    unsigned long long *stamps;  // diagnostic builds: [8..12] cycles in pop+load / SAT / push+flush, iterations, lanes
+    int no_filter;       // 1: skip the FP32 filter (every pair runs the Float64 test)
+};
+
+// one ticket per wave from a device-wide counter: lane 0 takes it, the wave reads it back as a scalar
+__device__ __forceinline__ int next_ticket(int *ctr) {
+    int t = 0;
+    if (lane_id() == 0) t = atomicAdd(ctr, 1);
+    return __builtin_amdgcn_readfirstlane(t);
+}
+
+// =================================================================================================================
+// broadphase main kernel: the same wave-cooperative depth-first descent as k_bp_dfs, in single precision on one
+// 64-byte NodeF line per node.  Measured (in-kernel stamps): the Float64 kernel is latency-bound at 2 waves per SIMD
+// (246 VGPRs, two 144-byte scattered records per lane and iteration), not ALU-bound; the Float32 kernel needs a
+// third of the registers and a third of the cache-line requests, and is exact in the following sense.
+//
+// For a node pair it forms v = R_a_b c_b + (t_a_b - c_a) in Float64 (the centre offset, of the order of the box
+// sizes), everything else in Float32: R_a, R_b from unit quaternions (|err| <= 8 u per entry, u = 2^-24, checked on
+// the host when the quaternion is made), T = R_a' R_a_b, t = R_a' v, R = T R_b, then the 15 axes
+// d = |T.L| - (r_a + r_b).  The error of R is below 72 u, so |d_float - d_reference| < 192 u S with
+// S = |v|_1 + sum e_a + sum e_b (internal-internal pairs carry no quaternion error: 16 u S).  d > E proves
+// separation, d < -E on all 15 axes proves overlap; an undecided pair (~1e-5 of its margin scale) is NOT decided by
+// this test: it is parked in LDS and settled at the top of the next iteration by the exact Float64 test.  The
+// candidate set and the node-test counts therefore equal the reference's bit for bit (tests/test_gpu_*.py).
+// =================================================================================================================
+struct Dfs32Args {
+    const ItemRec *items;
+    const WorkRec *seeds;
+    const int *n_seed;
+    int *next_seed;
+    int seed_cap;
+    WorkRec *cand;
+    int *ccount;
+    int ccap;
+    int *ucount;         // statistics: node pairs settled by the exact Float64 test
+    int *icnt;
+    unsigned *status;
+    int reserve;
+};
+
+__device__ __forceinline__ NodeF load_nodef(const NodeF *n) {
+    // four 16-byte loads of one 64-byte line
+    const int4 *p = reinterpret_cast<const int4 *>(n);
+    union { int4 v[4]; NodeF f; } u;
+    u.v[0] = p[0]; u.v[1] = p[1]; u.v[2] = p[2]; u.v[3] = p[3];
+    return u.f;
+}
+
+// one node pair of k_bp_dfs32: returns 0 = separated, 1 = overlapping, 2 = undecided
+__device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, bool any_leaf, const double *R12,
+                                             const float *R12f, const double *t12) {
+    // centre offset in Float64, then everything in Float32
+    float v[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        v[i] = (float)(((R12[i] * b.c[0] + R12[i + 3] * b.c[1]) + R12[i + 6] * b.c[2]) + (t12[i] - a.c[i]));
+    float Ra[9], Rb[9], T[9], R[9], t[3];
+    quat_to_R(a.q, Ra);
+    quat_to_R(b.q, Rb);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float r0 = Ra[3 * i], r1 = Ra[3 * i + 1], r2 = Ra[3 * i + 2];   // row i of R_a' = column i of R_a
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            T[i + 3 * j] = __builtin_fmaf(r2, R12f[3 * j + 2], __builtin_fmaf(r1, R12f[3 * j + 1], r0 * R12f[3 * j]));
+        t[i] = __builtin_fmaf(r2, v[2], __builtin_fmaf(r1, v[1], r0 * v[0]));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            R[i + 3 * j] = __builtin_fmaf(T[i + 6], Rb[3 * j + 2], __builtin_fmaf(T[i + 3], Rb[3 * j + 1], T[i] * Rb[3 * j]));
+    const float S = ((__builtin_fabsf(v[0]) + __builtin_fabsf(v[1])) + __builtin_fabsf(v[2])) +
+                    ((a.e[0] + a.e[1]) + a.e[2]) + ((b.e[0] + b.e[1]) + b.e[2]);
+    const float E = (any_leaf ? 1.15e-5f : 9.6e-7f) * S;   // 192 u, 16 u
+    int verdict = sat15_f32_core(a.e, b.e, t, R, E);
+    if (a.exact_only | b.exact_only) verdict = 2;
+    return verdict;
+}
+
+constexpr int kDfsBlock = 256;
+constexpr int kDfsWaves = kDfsBlock / 64;
+constexpr int kDfsStack32 = 2560;   // node pairs per workgroup (20 KiB)
+constexpr int kDfsOut32 = 1280;     // staged candidates per workgroup (10 KiB)
+
+// The exact Float64 BB_BB_intersect (general composition, src/obb/bb_intersection.jl:2-74) of the node pairs the
+// Float32 test leaves undecided (~2e-5 of all node tests), evaluated COOPERATIVELY: 16 lanes per pair.  Lanes 0..8
+// form one entry each of R_a' R_a_b, then of R_tot = (R_a' R_a_b) R_b (lanes 9..11 the translation), through LDS, and
+// lanes 0..14 test one of the 15 axes each.  Every entry / axis is the same expression, in the same order, as in
+// bb_compose() / sat15(), so the boolean is the reference's bit for bit, and the per-lane register need is a few
+// dozen instead of the ~220 of the one-lane-per-pair Float64 test (which cost the kernel a third of its occupancy
+// when inlined, and as a no-inline call needed scratch).  xs: 33 doubles per 16-lane group.
+__device__ __forceinline__ void exact_pairs_coop(const ItemRec *it, const double *pose, const int2 *und_l, int n_def,
+                                                 double *xs, int *und_v, int tid) {
+    const int grp = tid >> 4, sub = tid & 15;
+    double *T = xs + grp * 33, *tt = T + 9, *R = T + 12, *aR = T + 21, *t = T + 30;
+    for (int c0 = 0; c0 < n_def; c0 += kDfsBlock / 16) {
+        const int j = c0 + grp;
+        const bool valid = j < n_def;
+        int2 e = make_int2(0, 0);
+        if (valid) e = und_l[j];
+        const NodeRec *na = it->nodes1 + node_index(e.x), *nb = it->nodes2 + node_index(e.y);
+        if (valid && sub < 9) {
+            const int i = sub % 3, jj = sub / 3;
+            const double r0 = na->R[3 * i], r1 = na->R[3 * i + 1], r2 = na->R[3 * i + 2];
+            T[i + 3 * jj] = (r0 * pose[3 * jj] + r1 * pose[3 * jj + 1]) + r2 * pose[3 * jj + 2];
+        } else if (valid && sub < 12) {
+            const int i = sub - 9;
+            const double r0 = na->R[3 * i], r1 = na->R[3 * i + 1], r2 = na->R[3 * i + 2];
+            const double nt = ((-r0) * na->c[0] + (-r1) * na->c[1]) + (-r2) * na->c[2];
+            tt[i] = ((r0 * pose[9] + r1 * pose[10]) + r2 * pose[11]) + nt;
+        }
+        __syncthreads();
+        if (valid && sub < 9) {
+            const int i = sub % 3, jj = sub / 3;
+            const double r = (T[i] * nb->R[3 * jj] + T[i + 3] * nb->R[3 * jj + 1]) + T[i + 6] * nb->R[3 * jj + 2];
+            R[i + 3 * jj] = r;
+            aR[i + 3 * jj] = __builtin_fabs(r) + 1.0e-14;
+        } else if (valid && sub < 12) {
+            const int i = sub - 9;
+            t[i] = ((T[i] * nb->c[0] + T[i + 3] * nb->c[1]) + T[i + 6] * nb->c[2]) + tt[i];
+        }
+        __syncthreads();
+        bool sep = false;
+        if (valid && sub < 15) {
+            const double ea[3] = {na->e[0], na->e[1], na->e[2]}, eb[3] = {nb->e[0], nb->e[1], nb->e[2]};
+#define R_(i, j) R[(i) + 3 * (j)]
+#define AR_(i, j) aR[(i) + 3 * (j)]
+            if (sub < 3) {          // face test 1/2 (:29-32)
+                const int i = sub;
+                const double rb = (AR_(i, 0) * eb[0] + AR_(i, 1) * eb[1]) + AR_(i, 2) * eb[2];
+                sep = (ea[i] + rb) < __builtin_fabs(t[i]);
+            } else if (sub < 6) {   // face test 2/2 (:35-38)
+                const int jj = sub - 3;
+                const double tl = __builtin_fabs((R_(0, jj) * t[0] + R_(1, jj) * t[1]) + R_(2, jj) * t[2]);
+                const double ra = (AR_(0, jj) * ea[0] + AR_(1, jj) * ea[1]) + AR_(2, jj) * ea[2];
+                sep = (ra + eb[jj]) < tl;
+            } else {                // cross tests (:56-72): row m of the cross block, column jj
+                const int m = (sub - 6) / 3, jj = (sub - 6) % 3;
+                const int u = (m + 1) % 3, v = (m + 2) % 3;
+                const int p100 = jj == 0 ? 1 : 0, p221 = jj == 2 ? 1 : 2;
+                const double tl = __builtin_fabs(t[v] * R_(u, jj) - t[u] * R_(v, jj));
+                // sat15 writes the two products of ra with the lower axis index first; a + b == b + a exactly
+                const double ra = ea[u] * AR_(v, jj) + ea[v] * AR_(u, jj);
+                const double rb = eb[p100] * AR_(m, p221) + eb[p221] * AR_(m, p100);
+                sep = (ra + rb) < tl;
+            }
+#undef R_
+#undef AR_
+        }
+        const unsigned long long ms = __ballot(sep);
+        if (valid && sub == 0) und_v[j] = ((ms >> ((tid & 63) & ~15)) & 0xFFFFull) ? 0 : 1;
+        __syncthreads();
+    }
+}
+
+// One WORKGROUP (4 waves) per seed, one shared LDS stack: a seed of the 2 048-pose C3 batch is ~45 k node tests, i.e.
+// ~700 dependent iterations for a single wave -- that serial chain, not ALU or memory, bounded the one-wave-per-seed
+// version (every variant of its inner loop ran 2.0 ms).  Four waves pop 256 pairs per iteration from the same stack.
+
+// one ticket per workgroup: thread 0 takes it, LDS broadcast between two barriers
+__device__ __forceinline__ int next_ticket_block(int *ctr, int *slot) {
+    if (threadIdx.x == 0) *slot = atomicAdd(ctr, 1);
+    __syncthreads();
+    const int t = *slot;
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ void flush_candidates(const Dfs32Args &g, const int2 *ob, int n_out, int item, int tid,
+                                                 int *s_base) {
+    // all threads of the workgroup call this (n_out is uniform)
+    if (tid == 0) *s_base = atomicAdd(g.ccount, n_out);
+    __syncthreads();
+    const int base = *s_base;
+    if (base + n_out <= g.ccap) {
+        for (int j = tid; j < n_out; j += kDfsBlock) {
+            WorkRec c;
+            c.item = item; c.a = ob[j].x; c.b = ob[j].y; c.pad = 0;
+            g.cand[base + j] = c;
+        }
+    } else if (tid == 0) {
+        atomicOr(g.status, kStCandOvf);
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
+    __shared__ int2 stk[kDfsStack32];
+    __shared__ int2 ob[kDfsOut32];
+    __shared__ int s_cnt[kDfsWaves][2];   // per wave: candidates, pushed pairs of the current iteration
+    __shared__ int2 und_l[kDfsBlock];     // node pairs the Float32 test left undecided in the last iteration
+    __shared__ int und_v[kDfsBlock];      // their exact verdicts
+    __shared__ double xs[(kDfsBlock / 16) * 33];
+    __shared__ int s_seed, s_base, s_def;
+    __shared__ double s_pose[12];         // R_a_b (9, column-major), t_a_b (3) of the current seed's item
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int n_seed = *g.n_seed;
+    if (n_seed > g.seed_cap) n_seed = g.seed_cap;
+    // one ticket per workgroup (same loop shape as k_bp_dfs: condition in the for header, no break)
+    for (int sd = next_ticket_block(g.next_seed, &s_seed); sd < n_seed; sd = next_ticket_block(g.next_seed, &s_seed)) {
+        const WorkRec s = g.seeds[__builtin_amdgcn_readfirstlane(sd)];
+        const int item = __builtin_amdgcn_readfirstlane(s.item);   // uniform: scalar loads of the pose below
+        const ItemRec *it = g.items + item;
+        // the item's pose lives in LDS (broadcast reads inside the iteration) rather than in 33 registers that would
+        // stay live across the call of the exact test
+        if (tid < 9) s_pose[tid] = it->R12[tid];
+        else if (tid < 12) s_pose[tid] = it->t12[tid - 9];
+        const NodeF *n1 = it->nf1, *n2 = it->nf2;
+        int sp = 1, n_out = 0, n_test = 0, n_cand = 0, n_def = 0, n_und = 0;
+        if (tid == 0) {
+            // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
+            const int sa = (it->nodes1[s.a].leaf != kInternal) ? ~s.a : s.a;
+            const int sb = (it->nodes2[s.b].leaf != kInternal) ? ~s.b : s.b;
+            stk[0] = make_int2(sa, sb);
+            s_def = 0;
+        }
+        __syncthreads();
+        // every workgroup must reach its exit: the iteration guard stops a corrupt (cyclic) tree from spinning forever
+        for (int guard = 0; (sp > 0 || n_def > 0) && guard < (1 << 22); ++guard) {
+            // Either settle the pairs the previous iteration left undecided (exact Float64 test; their children still
+            // have the room that iteration reserved for them), or pop up to 256 pairs, but never more than the stack can
+            // take back as children (4 per pair).  n_def is uniform over the workgroup.
+            const bool settle = n_def > 0;
+            int pw = (kDfsStack32 - g.reserve - sp) / 3;
+            int p = sp < kDfsBlock ? sp : kDfsBlock;
+            if (pw < 1) pw = 1;
+            if (p > pw) p = pw;
+            if (settle) {
+                p = n_def;
+                exact_pairs_coop(it, s_pose, und_l, n_def, xs, und_v, tid);   // ends with a barrier
+            }
+            const bool act = tid < p;
+            int2 e = make_int2(0, 0);
+            if (act) e = settle ? und_l[tid] : stk[sp - 1 - tid];
+            __syncthreads();
+            if (!settle) { sp -= p; n_test += p; } else { n_und += p; }
+            int verdict = 0, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            if (settle && act) verdict = und_v[tid];
+            const bool la = act && e.x < 0, lb = act && e.y < 0;
+            if (act) {
+                const NodeF a = load_nodef(n1 + node_index(e.x));
+                const NodeF b = load_nodef(n2 + node_index(e.y));
+                a0 = a.link0; a1 = a.link1; b0 = b.link0; b1 = b.link1;
+                if (!settle) {
+                    double R12[9], t12[3];
+                    float R12f[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) { R12[k] = s_pose[k]; R12f[k] = (float)R12[k]; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
+                    verdict = test_pair_f32(a, b, la || lb, R12, R12f, t12);
+                }
+            }
+            // an undecided pair is parked for the next iteration (verdict 2 only comes from the Float32 test)
+            if (verdict == 2) und_l[atomicAdd(&s_def, 1)] = e;
+            const bool hit = verdict == 1;
+            const bool is_cand = hit && la && lb;
+            const bool two = hit && (la != lb);
+            const bool four = hit && !la && !lb;
+            const unsigned long long mc = __ballot(is_cand), m2 = __ballot(two), m4 = __ballot(four);
+            if (lane == 0) {
+                s_cnt[wave][0] = __builtin_popcountll(mc);
+                s_cnt[wave][1] = 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
+            }
+            __syncthreads();
+            n_def = s_def;   // read by everyone between this barrier and the next; reset after the next
+            int c_off = 0, p_off = 0, c_tot = 0, p_tot = 0;
+#pragma unroll
+            for (int w = 0; w < kDfsWaves; ++w) {
+                const int c = s_cnt[w][0], q = s_cnt[w][1];
+                if (w < wave) { c_off += c; p_off += q; }
+                c_tot += c; p_tot += q;
+            }
+            if (is_cand) ob[n_out + c_off + prefix_count(mc)] = make_int2(a0, b0);   // leaf: link0 = element index
+            if (two | four) {
+                const int pos = sp + p_off + 2 * prefix_count(m2) + 4 * prefix_count(m4);
+                if (two) {
+                    if (la) {  // leaf_1: descend tree_2 (:97-98)
+                        stk[pos] = make_int2(e.x, b0); stk[pos + 1] = make_int2(e.x, b1);
+                    } else {   // leaf_2: descend tree_1 (:101-103)
+                        stk[pos] = make_int2(a0, e.y); stk[pos + 1] = make_int2(a1, e.y);
+                    }
+                } else {       // (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107)
+                    stk[pos] = make_int2(a0, b0); stk[pos + 1] = make_int2(a1, b0);
+                    stk[pos + 2] = make_int2(a0, b1); stk[pos + 3] = make_int2(a1, b1);
+                }
+            }
+            n_out += c_tot;
+            sp += p_tot;
+            __syncthreads();
+            if (tid == 0) s_def = 0;   // ordered before the next iteration's parking by its first barrier
+            if (n_out > kDfsOut32 - kDfsBlock || (sp == 0 && n_def == 0 && n_out > 0)) {
+                flush_candidates(g, ob, n_out, item, tid, &s_base);
+                n_cand += n_out;
+                n_out = 0;
+            }
+        }
+        if (tid == 0) {
+            if (sp > 0 || n_def > 0) atomicOr(g.status, kStAbort);
+            atomicAdd(&g.icnt[4 * (size_t)item], n_test);
+            if (n_cand) atomicAdd(&g.icnt[4 * (size_t)item + 1], n_cand);
+            if (n_und) atomicAdd(g.ucount, n_und);   // statistics
+        }
+    }
+}
+
+// first 64 bytes of a NodeRec (c, e, links, flags) as four 16-byte loads
+struct NodeHead {
+    double c[3], e[3];
+    int child0, child1, leaf, aabb;
+};
+__device__ __forceinline__ NodeHead load_head(const NodeRec *n) {
+    NodeHead h;
+    const double2 *p = reinterpret_cast<const double2 *>(n);
+    const double2 a = p[0], b = p[1], c = p[2];
+    const int4 l = reinterpret_cast<const int4 *>(n)[3];
+    h.c[0] = a.x; h.c[1] = a.y; h.c[2] = b.x; h.e[0] = b.y; h.e[1] = c.x; h.e[2] = c.y;
+    h.child0 = l.x; h.child1 = l.y; h.leaf = l.z; h.aabb = l.w;
+    return h;
+}
+
+__global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
+    __shared__ int2 stk[kDfsStack];
+    __shared__ int2 ob[kDfsOut];
+    const int lane = threadIdx.x;
+    int n_seed = *g.n_seed;
+    if (n_seed > g.seed_cap) n_seed = g.seed_cap;
+    // dynamic seed queue: seeds differ in work by orders of magnitude (most of a contact lives in one subtree)
+    for (int sd = next_ticket(g.next_seed); sd < n_seed; sd = next_ticket(g.next_seed)) {
+        const WorkRec s = g.seeds[sd];
+        const int item = __builtin_amdgcn_readfirstlane(s.item);
+        const ItemRec *it = g.items + item;
+        double R12[9], aR12[9], t12[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { R12[k] = it->R12[k]; aR12[k] = __builtin_fabs(R12[k]) + 1.0e-14; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t12[k] = it->t12[k];
+        const NodeRec *n1 = it->nodes1, *n2 = it->nodes2;
+        int sp = 1, n_out = 0, n_test = 0, n_cand = 0;
+        // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
+        if (lane == 0) {
+            const int sa = (n1[s.a].leaf != kInternal) ? ~s.a : s.a;
+            const int sb = (n2[s.b].leaf != kInternal) ? ~s.b : s.b;
+            stk[0] = make_int2(sa, sb);
+        }
+        __syncthreads();
+#ifdef PFC_STAMPS
+        unsigned long long c_load = 0, c_sat = 0, c_push = 0, c_iter = 0, c_lanes = 0;
+#endif
+        // every wave must reach its exit: the iteration guard stops a corrupt (cyclic) tree from spinning forever
+        for (int guard = 0; sp > 0 && guard < (1 << 22); ++guard) {
+            unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+            (void)u0; (void)u1; (void)u2; (void)u3;
+            STAMP(u0);
+            // wide mode while there is room for 4 children per popped pair above the depth-first reserve
+            int pw = (kDfsStack - g.reserve - sp) / 3;
+            int p = sp < 64 ? sp : 64;
+            if (pw < 1) pw = 1;
+            if (p > pw) p = pw;
+            const bool act = lane < p;
+            int2 e = make_int2(0, 0);
+            if (act) e = stk[sp - 1 - lane];
+            __syncthreads();
+            sp -= p;
+            n_test += p;
+            const bool la = act && e.x < 0, lb = act && e.y < 0;
+            const int ia = node_index(e.x), ib = node_index(e.y);
+            // The path is chosen per wave, never per lane: popped pairs sit at similar depths, so a wave is usually
+            // all internal-internal (axis-aligned shortcut: R_tot = R_a_b, 128 bytes per pair) or reaches the
+            // tight-fitted leaves together (general composition; exact for identity rotations too).  Leaf-ness comes
+            // with the link, so all loads of the iteration are issued before the first use.
+            const bool general = __any(la || lb);
+            NodeHead a, b;
+            a.leaf = kInternal; b.leaf = kInternal; a.child0 = a.child1 = b.child0 = b.child1 = 0; a.aabb = b.aabb = 1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a.c[k] = a.e[k] = b.c[k] = b.e[k] = 0.0; }
+            double Ra[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0}, Rb[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+            if (act) {
+                a = load_head(n1 + ia);
+                b = load_head(n2 + ib);
+                if (general) {
+                    if (la) {
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) Ra[k] = n1[ia].R[k];
+                    }
+                    if (lb) {
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) Rb[k] = n2[ib].R[k];
+                    }
+                }
+            }
+#ifdef PFC_STAMPS
+            { double keep = a.c[0] + b.c[0] + Ra[4] + Rb[4]; asm volatile("" ::"v"(keep)); }   // the loads have landed
+#endif
+            STAMP(u1);
+            // The Float64 composition gives R_tot and t; the 15 axes are decided by the single-precision filter
+            // (sat15_f32) and only undecided pairs (within ~1e-6 of touching) run the Float64 test.
+            double Rt[9], aRt[9], tt3[3];
+            if (!general) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { Rt[k] = R12[k]; aRt[k] = aR12[k]; }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    tt3[i] = ((R12[i] * b.c[0] + R12[i + 3] * b.c[1]) + R12[i + 6] * b.c[2]) + (t12[i] - a.c[i]);
+            } else {
+                NodeRec fa, fb;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { fa.c[k] = a.c[k]; fa.e[k] = a.e[k]; fb.c[k] = b.c[k]; fb.e[k] = b.e[k]; }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { fa.R[k] = Ra[k]; fb.R[k] = Rb[k]; }
+                bb_compose(fa, fb, R12, t12, Rt, aRt, tt3);
+            }
+            bool hit = false;
+            int verdict = 0;
+            if (act) verdict = (g.no_filter & 1) ? 2 : sat15_f32(a.e, b.e, tt3, Rt);
+            hit = verdict == 1;
+            if (verdict == 2) hit = sat15(a.e, b.e, tt3, Rt, aRt);
+#ifdef PFC_STAMPS
+            {
+                const unsigned long long mu = __ballot(verdict == 2);
+                if (lane == 0 && mu && g.stamps) { atomicAdd(&g.stamps[13], (unsigned long long)__builtin_popcountll(mu)); atomicAdd(&g.stamps[14], 1ull); }
+                if (lane == 0 && general && g.stamps) atomicAdd(&g.stamps[15], 1ull);
+            }
+#endif
+            const int ca0 = a.child0, ca1 = a.child1, cb0 = b.child0, cb1 = b.child1;   // links (sign = leaf)
+            const int leaf_a = a.leaf, leaf_b = b.leaf;
+            const bool is_cand = hit && la && lb;
+            const bool two = hit && (la != lb);
+            const bool four = hit && !la && !lb;
+            const unsigned long long mc = __ballot(is_cand), m2 = __ballot(two), m4 = __ballot(four);
+            STAMP(u2);
+            if (is_cand) ob[n_out + prefix_count(mc)] = make_int2(leaf_a, leaf_b);
+            n_out += __builtin_popcountll(mc);
+            if (two | four) {
+                int pos = sp + 2 * prefix_count(m2) + 4 * prefix_count(m4);
+                if (two) {
+                    if (la) {  // leaf_1: descend tree_2 (:97-98)
+                        stk[pos] = make_int2(e.x, cb0); stk[pos + 1] = make_int2(e.x, cb1);
+                    } else {   // leaf_2: descend tree_1 (:101-103)
+                        stk[pos] = make_int2(ca0, e.y); stk[pos + 1] = make_int2(ca1, e.y);
+                    }
+                } else {       // (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107)
+                    stk[pos] = make_int2(ca0, cb0); stk[pos + 1] = make_int2(ca1, cb0);
+                    stk[pos + 2] = make_int2(ca0, cb1); stk[pos + 3] = make_int2(ca1, cb1);
+                }
+            }
+            sp += 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
+            __syncthreads();
+            if (n_out > kDfsOut - 64 || (sp == 0 && n_out > 0)) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(g.ccount, n_out);
+                base = __shfl(base, 0, 64);
+                if (base + n_out <= g.ccap) {
+                    for (int j = lane; j < n_out; j += 64) {
+                        WorkRec c;
+                        c.item = item; c.a = ob[j].x; c.b = ob[j].y; c.pad = 0;
+                        g.cand[base + j] = c;
+                    }
+                } else if (lane == 0) {
+                    atomicOr(g.status, kStCandOvf);
+                }
+                n_cand += n_out;
+                n_out = 0;
+                __syncthreads();
+            }
+#ifdef PFC_STAMPS
+            STAMP(u3);
+            c_load += u1 - u0; c_sat += u2 - u1; c_push += u3 - u2; c_iter += 1; c_lanes += p;
+#endif
+        }
+#ifdef PFC_STAMPS
+        if (lane == 0 && g.stamps) {
+            atomicAdd(&g.stamps[8], c_load); atomicAdd(&g.stamps[9], c_sat); atomicAdd(&g.stamps[10], c_push);
+            atomicAdd(&g.stamps[11], c_iter); atomicAdd(&g.stamps[12], c_lanes);
+        }
+#endif
+        if (lane == 0) {
+            if (sp > 0) atomicOr(g.status, kStAbort);
+            if (n_test) atomicAdd(&g.icnt[4 * (size_t)item], n_test);
+            if (n_cand) atomicAdd(&g.icnt[4 * (size_t)item + 1], n_cand);
+        }
+    }
+}
+

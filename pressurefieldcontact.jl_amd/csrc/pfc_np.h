@@ -1,0 +1,768 @@
+// pfc_np.h -- narrowphase: gather, clip, quadrature and per-item reductions (k_narrow), bristle friction over the kept polygons (k_fric).  Included by pfc_hip.hip inside namespace pfc (device code only).
+#pragma once
+
+// =================================================================================================================
+// narrowphase
+// =================================================================================================================
+struct TracSoA {
+    int *item;
+    double *nx, *ny, *nz, *rx, *ry, *rz, *dA, *p;
+};
+
+struct NpArgs {
+    const ItemRec *items;
+    const WorkRec *cand;
+    const int *ccount;
+    int ccap;
+    double *acc;
+    double *rec;       // moment records (bristle)
+    int *rcount;
+    int rcap;
+    int *icnt;
+    int *clip_n;     // per candidate, or null
+    // clipped polygons of bristle items, kept for the friction pass (k_fric): SoA [field][slot], slot < pcap
+    int *poly_item;  // item | n_poly << 28
+    double *poly;    // 34 fields: n̂ 3, centroid 3, ϵ_r² 4, vertices 8 x 3 (frame r²)
+    int *pcount;
+    int pcap;
+    int *surv;       // candidate indices of the pairs that contributed traction points (work list of the Dual passes)
+    int *scount;
+    TracSoA trac;
+    int *tcount;
+    int tcap;
+    unsigned *status;
+    int debug;       // materialise traction points for every item
+    unsigned long long *stamps;  // diagnostic builds: [0..5] cycles in gather / clip / reserve / integrate / reduce, rounds
+};
+
+constexpr int kNpBlock = 64;  // one wave per block: 16 KiB of LDS polygon staging per wave
+
+// weightPoly (src/math_kernel/utility.jl:21-26) on 4-vectors held in LDS slots
+// polygon ring in LDS: 8 physical slots x 4 coords per lane, [slot][coord][lane] layout (conflict-free per-lane
+// dynamic indexing); logical vertex k of a lane lives in physical slot (rbase + k) & 7
+#define PR(k, c) poly[((((rbase) + (k)) & 7) * 4 + (c)) * kNpBlock + lane]
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// Per-item accumulation of N per-lane partial sums.  Segmented scan per value, then the N totals of each run are
+// transposed onto lanes 0..N-1 (readlane from the run's tail) and leave as ONE wave-wide FP64 atomic instruction
+// on N consecutive accumulator slots: single-lane atomics are issue-bound (one wave instruction per ~50 ns per CU,
+// MI355X guide 'Global float atomics'), a 37-lane one costs the same as a 1-lane one.
+template <int N>
+__device__ __forceinline__ void accumulate_items(double *acc, int item, bool listed, bool any, const double *v, int n0,
+                                                 int stride = kAccStride) {
+    // listed: the lane holds a work-list entry (its item keys the run even if it contributes nothing, so empty
+    // polygons do not chop an item's run into pieces); any: the lane has a contribution
+    static_assert(N <= 64, "one value per lane");
+    if (__ballot(any) == 0) return;
+    const Seg sg = seg_setup(listed ? item : -1);
+    double tot[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) tot[k] = seg_sum(any ? v[k] : 0.0, sg);
+    unsigned long long tails = __ballot(sg.tail && sg.valid);
+    const int lane = lane_id();
+    while (tails) {
+        const int t = __builtin_ctzll(tails);
+        tails &= tails - 1;
+        const int item_t = __builtin_amdgcn_readlane(item, t);
+        double mine = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double x = readlane_f64(tot[k], t);
+            if (lane == k) mine = x;
+        }
+        if (lane < N && mine != 0.0) unsafeAtomicAdd(&acc[(size_t)item_t * stride + n0 + lane], mine);
+    }
+}
+
+// Sums of N per-lane values over a whole wave through LDS: lane `lane` writes column `lane` of N rows (row stride 65
+// doubles: conflict-free both ways), lanes lane0 .. lane0+N-1 then add up one row each.  N + ~130 instructions per wave
+// instead of ~30 N for N segmented DPP scans; used when all work items of the wave belong to one item (97 % of the
+// waves of the C3 batch).
+// LDS ordering inside ONE wave (the block is a single wave): the LDS unit serves a wave's instructions in order, so a
+// compiler-level fence is all that is needed.  __syncthreads() would also drain vmcnt, i.e. wait for every outstanding
+// global store and atomic of the wave.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int N>
+__device__ __forceinline__ double lds_row_sums(double *buf, const double *v, bool any, int lane, int lane0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) buf[k * 65 + lane] = any ? v[k] : 0.0;
+    wave_lds_sync();
+    double t = 0.0;
+    const int row = lane - lane0;
+    if (row >= 0 && row < N) {
+        const double *r = buf + row * 65;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll 4
+        for (int j = 0; j < 64; j += 4) { t0 += r[j]; t1 += r[j + 1]; t2 += r[j + 2]; t3 += r[j + 3]; }
+        t = (t0 + t1) + (t2 + t3);
+    }
+    wave_lds_sync();
+    return t;
+}
+
+// Everything up to the per-item sums (regularized friction fused; bristle: normal wrench + patch moments).  For bristle
+// items the clipped polygon of every contributing pair is kept (34 doubles, SoA by compacted slot: every store
+// instruction of a wave writes consecutive doubles) so that the friction pass after k_eig (k_fric) re-integrates the
+// bit-identical traction points without gathering and clipping again.  Materialising the TractionCache itself was
+// measured at 2.7x the whole clip + quadrature (9 scattered 8-byte stores per point, ~12 points per polygon); it is only
+// kept in debug mode (pfc_debug_tractions).
+//
+// TT: the scenario contains tet-tet instructions (non_friction.jl:166-194); compiled out otherwise so that the common
+// tri-tet-only scenario does not pay the registers of the plane / tet intersection.
+template <bool TT>
+__global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
+    __shared__ double poly[8 * 4 * kNpBlock];
+    const int lane = threadIdx.x;
+    int n_c = *g.ccount;
+    if (n_c > g.ccap) n_c = g.ccap;
+    const int stride = gridDim.x * kNpBlock;
+    const int n_round = (n_c + stride - 1) / stride;
+    for (int rd = 0; rd < n_round; ++rd) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+        (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5;
+        STAMP(t0);
+        const int idx = rd * stride + blockIdx.x * kNpBlock + lane;
+        const bool active = idx < n_c;
+        WorkRec cw;
+        cw.item = 0; cw.a = 0; cw.b = 0; cw.pad = 0;
+        if (active) cw = g.cand[idx];
+        const ItemRec *it = g.items + cw.item;
+        const TetRec *tp = it->tet + cw.b;
+        const int nq = it->nq;
+        const bool reg = it->model == PFC_REGULARIZED;
+        const bool materialise = active && g.debug;
+        const bool work = active;
+        int n_poly = 0, rbase = 0;
+        V3 nh = mk3(0.0, 0.0, 0.0);
+        // ==== phase 1 (divergent): gather, transform to tet coordinates, clip ========================================
+        if (work) {
+            double R21[9], t21[3];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R21[k] = it->R21[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t21[k] = it->t21[k];
+            double z[4][4];      // input polygon (3 or 4 vertices) in the coordinates of tet 2
+            int n_in = 0;
+            V3 nh_in = mk3(0.0, 0.0, 0.0);
+            double Z[16];        // x_ζ2_r2
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
+            if (!TT || it->tet1 == nullptr) {
+                // ---- tri-tet op (non_friction.jl:196-215) -----------------------------------------------------------
+                const TriRec tr = it->tri[cw.a];
+                // x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (:204); last row of x_r2_r1.mat is (0 0 0 1)
+                double X[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
+                    X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + Z[i + 12];
+                }
+                // v_k = x_ζ2_r1 * onePad(vert_k) (:205-207)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        z[k][i] = ((X[i] * tr.v[3 * k] + X[i + 4] * tr.v[3 * k + 1]) + X[i + 8] * tr.v[3 * k + 2]) + X[i + 12];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[3][i] = 0.0;
+                n_in = 3;
+                // n̂2 = R(x_r2_r1) * n̂_r1 (:211-212)
+                nh_in = mk3((R21[0] * tr.n[0] + R21[3] * tr.n[1]) + R21[6] * tr.n[2],
+                            (R21[1] * tr.n[0] + R21[4] * tr.n[1]) + R21[7] * tr.n[2],
+                            (R21[2] * tr.n[0] + R21[5] * tr.n[1]) + R21[8] * tr.n[2]);
+            } else {
+                // ---- tet-tet op (non_friction.jl:166-194) -----------------------------------------------------------
+                const TetRec *t1 = it->tet1 + cw.a;
+                double plane[4];
+                {
+                    // ϵ_plane_r2 = (Ē2 ϵ2) x_ζ2_r2 - (Ē1 ϵ1) (x_ζ1_r1 x_r1_r2)   (find_plane_tet :164, :174-177)
+                    double R12[9], t12[3], Z1[16], X1[16];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) R12[k] = it->R12[k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t12[k] = it->t12[k];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) Z1[k] = t1->xzr[k];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            X1[i + 4 * j] = (Z1[i] * R12[3 * j] + Z1[i + 4] * R12[3 * j + 1]) + Z1[i + 8] * R12[3 * j + 2];
+                        X1[i + 12] = ((Z1[i] * t12[0] + Z1[i + 4] * t12[1]) + Z1[i + 8] * t12[2]) + Z1[i + 12];
+                    }
+                    double Ee1[4], Ee2[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        Ee1[j] = it->Ebar1 * it->eps1[4 * (size_t)cw.a + j];
+                        Ee2[j] = it->Ebar * it->eps2[4 * (size_t)cw.b + j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double p1 = ((Ee1[0] * X1[4 * j] + Ee1[1] * X1[4 * j + 1]) + Ee1[2] * X1[4 * j + 2]) + Ee1[3] * X1[4 * j + 3];
+                        const double p2 = ((Ee2[0] * Z[4 * j] + Ee2[1] * Z[4 * j + 1]) + Ee2[2] * Z[4 * j + 2]) + Ee2[3] * Z[4 * j + 3];
+                        plane[j] = p2 - p1;
+                    }
+                }
+                // x_r2_ζ1 = x_r2_r1.mat * x_r1_ζ1: the vertices of tet 1 in frame r2 (:180); proj = plane * tet (:19)
+                V3 P[4];
+                double proj[4];
+                int n_neg = 0, n_pos = 0;
+                unsigned posm = 0, negm = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double vx = t1->xrz[3 * j], vy = t1->xrz[3 * j + 1], vz = t1->xrz[3 * j + 2];
+                    P[j] = mk3(((R21[0] * vx + R21[3] * vy) + R21[6] * vz) + t21[0],
+                               ((R21[1] * vx + R21[4] * vy) + R21[7] * vz) + t21[1],
+                               ((R21[2] * vx + R21[5] * vy) + R21[8] * vz) + t21[2]);
+                    proj[j] = ((plane[0] * P[j].x + plane[1] * P[j].y) + plane[2] * P[j].z) + plane[3];
+                    if (proj[j] < 0.0) { ++n_neg; negm |= 1u << j; }
+                    if (0.0 < proj[j]) { ++n_pos; posm |= 1u << j; }
+                }
+                // clip_plane_tet (plane_tet_intersection.jl:9-106).  weightPoly(v[i1], v[i2], proj[i1], proj[i2]) does
+                // not depend on the order of (i1, i2) bit for bit, so one edge function serves every case.
+                V3 q[4];
+                q[0] = q[1] = q[2] = q[3] = mk3(0.0, 0.0, 0.0);
+                int n_q = 0;
+#define PW_(i1, i2) (P[i2] * (proj[i1] / (proj[i1] - proj[i2])) - P[i1] * (proj[i2] / (proj[i1] - proj[i2])))
+                if (n_pos != 0 && n_neg != 0) {
+                    int lone = -1;
+                    if (n_pos == 1) lone = __builtin_ctz(posm);
+                    else if (n_neg == 1) lone = __builtin_ctz(negm);
+                    if (lone >= 0) {
+                        V3 a, b, c;   // :52-79
+                        if (lone == 0) { a = PW_(1, 0); b = PW_(3, 0); c = PW_(2, 0); }
+                        else if (lone == 1) { a = PW_(0, 1); b = PW_(2, 1); c = PW_(3, 1); }
+                        else if (lone == 2) { a = PW_(0, 2); b = PW_(3, 2); c = PW_(1, 2); }
+                        else { a = PW_(0, 3); b = PW_(1, 3); c = PW_(2, 3); }
+                        double pl = (lone == 0) ? proj[0] : (lone == 1) ? proj[1] : (lone == 2) ? proj[2] : proj[3];
+                        n_q = 3;
+                        if (0.0 < pl) { q[0] = a; q[1] = b; q[2] = c; } else { q[0] = c; q[1] = b; q[2] = a; }
+                    } else {
+                        V3 a, b, c, d;   // :81-106
+                        const bool p0 = (posm & 1u) != 0, p1 = (posm & 2u) != 0, p2 = (posm & 4u) != 0;
+                        if (p0 == p1) { a = PW_(1, 2); b = PW_(1, 3); c = PW_(0, 3); d = PW_(0, 2); }
+                        else if (p0 == p2) { a = PW_(0, 1); b = PW_(0, 3); c = PW_(2, 3); d = PW_(2, 1); }
+                        else { a = PW_(0, 2); b = PW_(0, 1); c = PW_(3, 1); d = PW_(3, 2); }
+                        n_q = 4;
+                        if (0.0 < proj[0]) { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+                        else { q[0] = d; q[1] = c; q[2] = b; q[3] = a; }
+                    }
+                }
+#undef PW_
+                // poly_ζ2 = one_pad_then_mul(x_ζ2_r2, poly_r2), then zero_small_coordinates (:184-187)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double v = ((Z[i] * q[k].x + Z[i + 4] * q[k].y) + Z[i + 8] * q[k].z) + Z[i + 12];
+                        z[k][i] = v * ((1.0e-14 < __builtin_fabs(v)) ? 1.0 : 0.0);
+                    }
+                n_in = n_q;
+                nh_in = normalize(mk3(plane[0], plane[1], plane[2]));   // :190
+            }
+            bool finite = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) finite &= (k >= n_in) || (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
+            if (!finite) atomicOr(g.status, kStNonFinite);
+            // Trivial reject: if every vertex is non-positive on some plane the clip is empty.  Bit-exact shortcut:
+            // every clipped vertex is c1*p2 - c2*p1 with c1 >= 0 >= c2 (static_clip.jl:197-201), whose sign on that
+            // plane is exact, so Sutherland-Hodgman returns the empty polygon at that plane (:44).
+            bool reject = !finite || n_in < 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0) && (n_in < 4 || z[3][i] <= 0.0);
+            if (!reject) {
+                STAMP(t1);
+                // ---- clip_in_tet_coordinates (static_clip.jl:7-23,34-201), polygon ring in LDS, clipped in place ---
+                int n = n_in;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < n_in) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) PR(k, i) = z[k][i];
+                    }
+                bool err = false;
+                for (int i = 0; i < 4 && n > 0; ++i) {
+                    unsigned nonpos = 0, nonneg = 0;
+                    for (int k = 0; k < n; ++k) {
+                        double sv = PR(k, i);
+                        nonpos |= (unsigned)(sv <= 0.0) << k;
+                        nonneg |= (unsigned)(0.0 <= sv) << k;
+                    }
+                    const unsigned full = (1u << n) - 1u;
+                    if (nonpos == full) { n = 0; break; }       // :44
+                    if (nonneg == full) continue;               // :45-46
+                    // first k with is_non_pos[k] && !is_non_pos[k+1] (cyclic) (:48-50)
+                    unsigned nxt = ((nonpos >> 1) | ((nonpos & 1u) << (n - 1))) & full;
+                    unsigned cand_start = nonpos & ~nxt & full;
+                    if (cand_start == 0) { err = true; n = 0; break; }  // "Non-finite vertex likely" (:52)
+                    const int st = __builtin_ctz(cand_start);
+                    // cut_clip (:135-195): drop trailing vertices while z_{m-1} is non-positive
+                    int m = n;
+                    while (m > 3) {
+                        int k2 = st + m - 2; if (k2 >= n) k2 -= n;
+                        if ((nonpos >> k2) & 1u) --m; else break;
+                    }
+                    int k1 = st + 1; if (k1 >= n) k1 -= n;
+                    int kl = st + m - 1; if (kl >= n) kl -= n;   // z_m (last)
+                    int kp = st + m - 2; if (kp >= n) kp -= n;   // z_{m-1}
+                    // inside test of the last vertex: 0 < z for arity 3..5 (:140,150,162), 0 <= z for 6..7 (:176,188)
+                    const bool inside = (m <= 5) ? (((nonpos >> kl) & 1u) == 0) : (((nonneg >> kl) & 1u) != 0);
+                    // z_start = clip_node(z1, z2); z_end = clip_node(z1, z_m) or clip_node(z_m, z_{m-1}); both are
+                    // formed in registers before the ring is touched
+                    double zs[4], ze[4];
+                    {
+                        double w1 = PR(st, i), w2 = PR(k1, i);
+                        double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) zs[c] = c1 * PR(k1, c) - c2 * PR(st, c);
+                    }
+                    {
+                        const int kn = inside ? st : kl, kq = inside ? kl : kp;
+                        double w1 = PR(kn, i), w2 = PR(kq, i);
+                        double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ze[c] = c1 * PR(kq, c) - c2 * PR(kn, c);
+                    }
+                    const int ncopy = inside ? (m - 1) : (m - 2);   // z2 .. z_m  or  z2 .. z_{m-1} stay in the polygon
+                    // In place: the new polygon starts at old logical st.  Kept vertices st+1 .. n-1 do not move;
+                    // kept vertices that wrapped around (old logical 0 .. ) move up by n slots, in increasing order
+                    // (a destination is either a free slot or the source of an earlier move).
+                    for (int q = n - st - 1; q < ncopy; ++q) {
+                        const int src = st + 1 + q - n, dst = st + 1 + q;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { const double t = PR(src, c); PR(dst, c) = t; }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { PR(st, c) = zs[c]; PR(st + ncopy + 1, c) = ze[c]; }
+                    rbase = (rbase + st) & 7;
+                    n = ncopy + 2;
+                    if (m == 7) break;  // the 7-vertex method returns the polygon directly (:185-195)
+                }
+                if (err) atomicOr(g.status, kStNonFinite);
+                n_poly = n;
+                if (n >= 3) nh = nh_in;
+            }
+        }
+        if (g.clip_n && active) g.clip_n[idx] = n_poly;
+        STAMP(t2);
+        // ==== phase 2 (wave-uniform): reserve a contiguous run of traction slots for the whole wave ================
+        // A lane with an n-gon owns n * nq consecutive slots, so the traction points of a wave (and, because the
+        // candidate list is grouped by item, of an item) are contiguous: the later per-point passes then reduce
+        // wave-uniformly with one atomic per wave instead of one per lane.
+        const int slots = (materialise && n_poly >= 3) ? n_poly * nq : 0;
+        int tbase = 0;
+        if (g.debug) {
+            int incl = seg_incl_scan(slots);
+            const int tot = __shfl(incl, 63, 64);
+            int base = 0;
+            if (tot > 0) {
+                if (lane == 0) base = atomicAdd(g.tcount, tot);
+                base = __shfl(base, 0, 64);
+            }
+            tbase = base + incl - slots;
+        }
+        STAMP(t3);
+        // ==== phase 3 (divergent): integrate_over_polygon_patch! (non_friction.jl:217-234) ============================
+        double sum[10], wr1[3], wrr[6];   // wr1, wrr: first / second moments of w about the polygon centroid
+#pragma unroll
+        for (int k = 0; k < 10; ++k) sum[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wrr[k] = 0.0;
+        wr1[0] = wr1[1] = wr1[2] = 0.0;
+        V3 cen = mk3(0.0, 0.0, 0.0);
+        int n_trac_lane = 0;
+        if (n_poly >= 3) {
+            const int n = n_poly;
+            // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98), converted in place (x, y, z)
+            {
+                double V[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
+                for (int k = 0; k < n; ++k) {
+                    const double z0 = PR(k, 0), z1 = PR(k, 1), z2 = PR(k, 2), z3 = PR(k, 3);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        PR(k, c) = ((V[c] * z0 + V[c + 3] * z1) + V[c + 6] * z2) + V[c + 9] * z3;
+                }
+            }
+            // centroid(poly_r2, n̂2) (poly_eight.jl:35-52)
+            {
+                V3 a = mk3(PR(0, 0), PR(0, 1), PR(0, 2));
+                V3 cc = mk3(PR(1, 0), PR(1, 1), PR(1, 2));
+                double cum_sum = 0.0;
+                V3 cum_prod = mk3(0.0, 0.0, 0.0);
+                for (int k = 2; k < n; ++k) {
+                    V3 b = cc;
+                    cc = mk3(PR(k, 0), PR(k, 1), PR(k, 2));
+                    double ar = triangle_area(a, b, cc, nh);
+                    cum_prod = cum_prod + ((a + b) + cc) * (1.0 / 3.0) * ar;
+                    cum_sum += ar;
+                }
+                cen = (cum_sum == 0.0) ? a : cum_prod / cum_sum;
+            }
+            const double er0 = tp->epsr[0], er1 = tp->epsr[1], er2 = tp->epsr[2], er3 = tp->epsr[3];
+            const V3 w = ld3(it->w), vl = ld3(it->v);
+            const double chi = it->chi, Ebar = it->Ebar;
+            const double v_c = it->v_c, mu_s = it->mu_s, mu_d = it->mu_d;
+            const bool store = materialise && (tbase + slots <= g.tcap);
+            if (materialise && !store) atomicOr(g.status, kStTracOvf);
+            int tpos = tbase;
+            V3 v2 = mk3(PR(n - 1, 0), PR(n - 1, 1), PR(n - 1, 2));
+            for (int k = 0; k < n; ++k) {
+                V3 v1 = v2;
+                v2 = mk3(PR(k, 0), PR(k, 1), PR(k, 2));
+                double area = triangle_area(v1, v2, cen, nh);
+                if (!(0.0 < area)) continue;  // :232
+                for (int q = 0; q < nq; ++q) {
+                    // TriTetQuadRule rules 1 and 2, literal decimals of src/clip/quadrature.jl:24-39
+                    double q0, q1, q2, qw;
+                    if (nq == 1) {
+                        q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
+                    } else {
+                        const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
+                        q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
+                        qw = 0.33333333333333331483;
+                    }
+                    // fillTractionCacheInnerLoop! (:251-265)
+                    V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
+                               (v1.z * q0 + v2.z * q1) + cen.z * q2);
+                    double eq = __builtin_fma(er0, r.x, er3);
+                    eq = __builtin_fma(er1, r.y, eq);
+                    eq = __builtin_fma(er2, r.z, eq);
+                    V3 rdot = vl + cross(w, r);
+                    double ee = -dot(mk3(er0, er1, er2), rdot);
+                    double damp = fmax(0.0, 1.0 + chi * ee);
+                    double p = eq * Ebar * damp;
+                    double dA = qw * area;
+                    if (!(0.0 < p)) continue;  // :245
+                    ++n_trac_lane;
+                    double p_dA = p * dA;
+                    if (store) {
+                        g.trac.item[tpos] = cw.item;
+                        g.trac.nx[tpos] = nh.x; g.trac.ny[tpos] = nh.y; g.trac.nz[tpos] = nh.z;
+                        g.trac.rx[tpos] = r.x; g.trac.ry[tpos] = r.y; g.trac.rz[tpos] = r.z;
+                        g.trac.dA[tpos] = dA; g.trac.p[tpos] = p;
+                        ++tpos;
+                    }
+                    if (reg) {
+                        // yes_contact!(::Regularized) (friction.jl:50-72) fused
+                        V3 vt = vec_sub_vec_proj(rdot, nh);
+                        double m2 = dot(vt, vt);
+                        V3 T;
+                        if (m2 < v_c * v_c) {
+                            T = (vt * (-mu_s)) / v_c;
+                        } else {
+                            double mg = __builtin_sqrt(m2);
+                            double mu = clamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
+                            T = (vt * (-mu)) / mg;
+                        }
+                        const V3 tk = nh * p_dA + T * p_dA;
+                        const V3 ta = cross(r, tk);
+                        sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+                        sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
+                    } else {
+                        // normal_wrench_cop (normal.jl:17-34) fused: pass 1 of the bristle model.  The traction of a
+                        // point is n̂ w (w = p dA) with n̂ constant over the polygon, so only W = sum w and the moments
+                        // of w about the polygon centroid are accumulated per point; sum w r, the force n̂ W and the
+                        // torque (sum w r) x n̂ follow after the loop (a quarter of the loop's instructions).
+                        sum[6] += p_dA;
+                        const V3 rc = r - cen;
+                        const double wx = p_dA * rc.x, wy = p_dA * rc.y, wz = p_dA * rc.z;
+                        wr1[0] += wx; wr1[1] += wy; wr1[2] += wz;
+                        wrr[0] += wx * rc.x; wrr[1] += wx * rc.y; wrr[2] += wx * rc.z;
+                        wrr[3] += wy * rc.y; wrr[4] += wy * rc.z; wrr[5] += wz * rc.z;
+                    }
+                }
+            }
+            if (!reg) {
+                const double W = sum[6];
+                const V3 Sr = mk3(wr1[0] + W * cen.x, wr1[1] + W * cen.y, wr1[2] + W * cen.z);   // sum w r
+                const V3 ta = cross(Sr, nh);
+                sum[0] = ta.x; sum[1] = ta.y; sum[2] = ta.z;
+                sum[3] = nh.x * W; sum[4] = nh.y * W; sum[5] = nh.z * W;
+                sum[7] = Sr.x; sum[8] = Sr.y; sum[9] = Sr.z;
+            }
+            if (store)  // unused slots of this lane's run (area <= 0 or p <= 0 points)
+                for (; tpos < tbase + slots; ++tpos) g.trac.item[tpos] = -1;
+        }
+        STAMP(t4);
+        // ==== phase 4 (wave-uniform): per-item reductions =============================================================
+        const bool contributed = work && n_trac_lane > 0;
+        {
+            // ---- compacted slots for (a) the polygons of contributing bristle pairs, kept for k_fric, and (b) when
+            // pfc_eval_dual asked for it, the candidate indices of all contributing pairs.  ONE 64-bit atomic per wave
+            // reserves both (pcount in the low word, scount in the high word): a second single-address atomic per wave
+            // cost 0.6 ms on the C3 batch.
+            const bool keep = contributed && !reg;
+            const bool list = contributed && g.surv != nullptr;
+            if (__any(keep || list)) {
+                const unsigned long long km = __ballot(keep), sm = __ballot(list);
+                unsigned long long base2 = 0;
+                if (lane == 0) {
+                    if (g.surv == nullptr)
+                        base2 = (unsigned)atomicAdd(g.pcount, __popcll(km));
+                    else
+                        base2 = atomicAdd(reinterpret_cast<unsigned long long *>(g.pcount),
+                                          ((unsigned long long)__popcll(sm) << 32) | (unsigned long long)__popcll(km));
+                }
+                const int base = __builtin_amdgcn_readfirstlane((int)(base2 & 0xFFFFFFFFull));
+                const int sbase = __builtin_amdgcn_readfirstlane((int)(base2 >> 32));
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (list) g.surv[sbase + __popcll(sm & below)] = idx;   // <= ccap entries
+                const int slot = base + __popcll(km & below);
+                if (keep && slot < g.pcap) {      // pcap >= ccap: cannot overflow
+                    const size_t P = (size_t)g.pcap;
+                    double *o = g.poly + slot;
+                    // streaming stores: 0.5 GB per C3 batch must not evict the mesh records from the XCD's 4 MiB L2
+#define NT_(p, v) __builtin_nontemporal_store((v), (p))
+                    NT_(&g.poly_item[slot], (int)((unsigned)cw.item | ((unsigned)n_poly << 28)));
+                    NT_(o, nh.x); NT_(o + P, nh.y); NT_(o + 2 * P, nh.z);
+                    NT_(o + 3 * P, cen.x); NT_(o + 4 * P, cen.y); NT_(o + 5 * P, cen.z);
+                    NT_(o + 6 * P, tp->epsr[0]); NT_(o + 7 * P, tp->epsr[1]); NT_(o + 8 * P, tp->epsr[2]);
+                    NT_(o + 9 * P, tp->epsr[3]);
+                    for (int k = 0; k < n_poly; ++k) {
+                        NT_(o + (10 + 3 * k) * P, PR(k, 0)); NT_(o + (11 + 3 * k) * P, PR(k, 1));
+                        NT_(o + (12 + 3 * k) * P, PR(k, 2));
+                    }
+#undef NT_
+                }
+            }
+            // ---- the ten per-item sums.  Single-item wave (the rule: an item has ~30 waves of candidates): LDS transpose;
+            // otherwise segmented scans keyed by item.  The polygon ring is free from here on (its last reader was the
+            // polygon store above).
+            const unsigned long long am = __ballot(active);
+            const int item_first = __builtin_amdgcn_readlane(cw.item, am ? __builtin_ctzll(am) : 0);
+            const bool single = __all(!active || cw.item == item_first);
+            double t10 = 0.0;   // single: lane k < 10 holds total k
+            if (single) {
+                if (__any(contributed)) {
+                    t10 = lds_row_sums<10>(poly, sum, contributed, lane, 0);
+                    if (lane < 10 && t10 != 0.0) unsafeAtomicAdd(&g.acc[(size_t)item_first * kAccStride + lane], t10);
+                }
+            } else {
+                accumulate_items<10>(g.acc, cw.item, active, contributed, sum, 0);
+            }
+            if (__any(contributed && !reg)) {
+                // ---- patch-stiffness moments of the bristle model, one record per run of an item in this wave ----
+                const bool cb = contributed && !reg;
+                const Seg sg = seg_setup(active ? cw.item : -1);
+                // the run's own pressure centroid c_w = sum w r / sum w, broadcast from the run's tail
+                double Wt, cx, cy, cz;
+                if (single) {
+                    Wt = readlane_f64(t10, 6); cx = readlane_f64(t10, 7); cy = readlane_f64(t10, 8); cz = readlane_f64(t10, 9);
+                } else {
+                    Wt = seg_sum(cb ? sum[6] : 0.0, sg);
+                    cx = seg_sum(cb ? sum[7] : 0.0, sg); cy = seg_sum(cb ? sum[8] : 0.0, sg);
+                    cz = seg_sum(cb ? sum[9] : 0.0, sg);
+                    Wt = __shfl(Wt, sg.tail_lane, 64);
+                    cx = __shfl(cx, sg.tail_lane, 64); cy = __shfl(cy, sg.tail_lane, 64); cz = __shfl(cz, sg.tail_lane, 64);
+                }
+                const double iW = (Wt > 0.0) ? 1.0 / Wt : 0.0;
+                const V3 cwv = mk3(cx * iW, cy * iW, cz * iW);
+                // lane moments: polygon centroid -> c_w (parallel axis; |d| is at most the patch size)
+                const double W = sum[6];
+                const V3 d = cen - cwv;
+                const V3 m1 = mk3(wr1[0] + W * d.x, wr1[1] + W * d.y, wr1[2] + W * d.z);   // sum w (r - c_w)
+                double q[6];                                                              // sum w (r-c_w)(r-c_w)'
+                q[0] = wrr[0] + 2.0 * wr1[0] * d.x + W * d.x * d.x;
+                q[1] = wrr[1] + wr1[0] * d.y + wr1[1] * d.x + W * d.x * d.y;
+                q[2] = wrr[2] + wr1[0] * d.z + wr1[2] * d.x + W * d.x * d.z;
+                q[3] = wrr[3] + 2.0 * wr1[1] * d.y + W * d.y * d.y;
+                q[4] = wrr[4] + wr1[1] * d.z + wr1[2] * d.y + W * d.y * d.z;
+                q[5] = wrr[5] + 2.0 * wr1[2] * d.z + W * d.z * d.z;
+                // n̂ is constant over a lane's polygon: sum w n n' = W n n', sum w (x x n) n' = (m1 x n) n',
+                // sum w (x x n)(x x n)' = [n]x Q [n]x'
+                double v[27];
+                v[0] = W * nh.x * nh.x; v[1] = W * nh.x * nh.y; v[2] = W * nh.x * nh.z;
+                v[3] = W * nh.y * nh.y; v[4] = W * nh.y * nh.z; v[5] = W * nh.z * nh.z;
+                const V3 an = cross(m1, nh);
+                v[6] = an.x * nh.x; v[7] = an.y * nh.x; v[8] = an.z * nh.x;
+                v[9] = an.x * nh.y; v[10] = an.y * nh.y; v[11] = an.z * nh.y;
+                v[12] = an.x * nh.z; v[13] = an.y * nh.z; v[14] = an.z * nh.z;
+                {
+                    const V3 c0 = mk3(q[0], q[1], q[2]), c1 = mk3(q[1], q[3], q[4]), c2 = mk3(q[2], q[4], q[5]);
+                    const V3 m0 = cross(nh, c0), m1c = cross(nh, c1), m2 = cross(nh, c2);       // M = [n]x Q
+                    // Saa = M [n]x': row i of Saa = n x (row i of M)
+                    const V3 r0 = cross(nh, mk3(m0.x, m1c.x, m2.x)), r1 = cross(nh, mk3(m0.y, m1c.y, m2.y));
+                    const V3 r2 = cross(nh, mk3(m0.z, m1c.z, m2.z));
+                    v[15] = r0.x; v[16] = r0.y; v[17] = r0.z; v[18] = r1.y; v[19] = r1.z; v[20] = r2.z;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v[21 + k] = q[k];
+                if (single) {
+                    // rows on lanes 5..31: the record is item, W, c_w, 27 moments
+                    double mine = lds_row_sums<27>(poly, v, cb, lane, 5);
+                    if (Wt > 0.0) {
+                        if (lane == 0) mine = (double)item_first;
+                        if (lane == 1) mine = Wt;
+                        if (lane == 2) mine = cwv.x;
+                        if (lane == 3) mine = cwv.y;
+                        if (lane == 4) mine = cwv.z;
+                        int slot = 0;
+                        if (lane == 0) slot = atomicAdd(g.rcount, 1);
+                        slot = __builtin_amdgcn_readfirstlane(slot);
+                        if (slot < g.rcap) {
+                            if (lane < kRecStride) g.rec[(size_t)slot * kRecStride + lane] = mine;
+                        } else if (lane == 0) {
+                            atomicOr(g.status, kStRecOvf);
+                        }
+                    }
+                }
+                double tot[27];
+                unsigned long long tails = 0;
+                if (!single) {
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) tot[k] = seg_sum(cb ? v[k] : 0.0, sg);
+                    tails = __ballot(sg.tail && sg.valid && Wt > 0.0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) tot[k] = 0.0;
+                }
+                while (tails) {
+                    const int t = __builtin_ctzll(tails);
+                    tails &= tails - 1;
+                    // lanes 0..31 assemble the record: item, W, c_w, 27 moments
+                    double mine = 0.0;
+                    if (lane == 0) mine = (double)__builtin_amdgcn_readlane(cw.item, t);
+                    { const double x = readlane_f64(Wt, t); if (lane == 1) mine = x; }
+                    { const double x = readlane_f64(cwv.x, t); if (lane == 2) mine = x; }
+                    { const double x = readlane_f64(cwv.y, t); if (lane == 3) mine = x; }
+                    { const double x = readlane_f64(cwv.z, t); if (lane == 4) mine = x; }
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) {
+                        const double x = readlane_f64(tot[k], t);
+                        if (lane == 5 + k) mine = x;
+                    }
+                    int slot = 0;
+                    if (lane == 0) slot = atomicAdd(g.rcount, 1);
+                    slot = __builtin_amdgcn_readfirstlane(slot);
+                    if (slot < g.rcap) {
+                        if (lane < kRecStride) g.rec[(size_t)slot * kRecStride + lane] = mine;
+                    } else if (lane == 0) {
+                        atomicOr(g.status, kStRecOvf);
+                    }
+                }
+            }
+            count_per_item(g.icnt, cw.item, 2, active, active && n_poly >= 3);
+            count_per_item(g.icnt, cw.item, 3, active, contributed, n_trac_lane);
+        }
+#ifdef PFC_STAMPS
+        STAMP(t5);
+        if (lane == 0 && g.stamps) {
+            // t1 is only stamped when lane 0's wave entered the clip; fold gather+clip when it was not
+            if (t1 == 0) t1 = t2;
+            atomicAdd(&g.stamps[0], t1 - t0); atomicAdd(&g.stamps[1], t2 - t1); atomicAdd(&g.stamps[2], t3 - t2);
+            atomicAdd(&g.stamps[3], t4 - t3); atomicAdd(&g.stamps[4], t5 - t4); atomicAdd(&g.stamps[5], 1ull);
+        }
+#endif
+    }
+}
+#undef PR
+
+// Bristle friction pass (after k_eig): calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48)
+// over the polygons k_narrow kept.  One lane per kept polygon, every load is a coalesced read of consecutive slots;
+// the fan / quadrature arithmetic is the one of k_narrow, so the traction points are bit-identical.
+struct FricArgs {
+    const ItemRec *items;
+    const int *poly_item;
+    const double *poly;
+    const int *pcount;
+    int pcap;
+    const double *res;
+    double *acc;
+};
+__global__ void __launch_bounds__(64) k_fric(FricArgs g) {
+    const int lane = threadIdx.x;
+    int n_p = *g.pcount;
+    if (n_p > g.pcap) n_p = g.pcap;
+    const size_t P = (size_t)g.pcap;
+    const int stride = gridDim.x * 64;
+    const int n_round = (n_p + stride - 1) / stride;
+    for (int rd = 0; rd < n_round; ++rd) {
+        const int idx = rd * stride + blockIdx.x * 64 + lane;
+        const bool active = idx < n_p;
+        double sum[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sum[k] = 0.0;
+        int item = 0;
+        bool contributed = false;
+        if (active) {
+            const unsigned pk = (unsigned)g.poly_item[idx];
+            item = (int)(pk & 0x0FFFFFFFu);
+            const int n = (int)(pk >> 28);
+            const ItemRec *it = g.items + item;
+            const double *o = g.poly + idx;
+            const V3 nh = mk3(o[0], o[P], o[2 * P]);
+            const V3 cen = mk3(o[3 * P], o[4 * P], o[5 * P]);
+            const double er0 = o[6 * P], er1 = o[7 * P], er2 = o[8 * P], er3 = o[9 * P];
+            const int nq = it->nq;
+            const V3 w = ld3(it->w), vl = ld3(it->v);
+            const double chi = it->chi, Ebar = it->Ebar, mu_s = it->mu_s, mu_d = it->mu_d;
+            const double tau = it->tau, k_bar = it->k_bar;
+            const double *res = g.res + (size_t)item * kResStride;
+            const V3 cop = ld3(res + kResCop), Da = ld3(res + kResDelta), Dl = ld3(res + kResDelta + 3);
+            V3 v2 = mk3(o[(10 + 3 * (n - 1)) * P], o[(11 + 3 * (n - 1)) * P], o[(12 + 3 * (n - 1)) * P]);
+            for (int k = 0; k < n; ++k) {
+                const V3 v1 = v2;
+                v2 = mk3(o[(10 + 3 * k) * P], o[(11 + 3 * k) * P], o[(12 + 3 * k) * P]);
+                const double area = triangle_area(v1, v2, cen, nh);
+                if (!(0.0 < area)) continue;
+                for (int q = 0; q < nq; ++q) {
+                    double q0, q1, q2, qw;
+                    if (nq == 1) {
+                        q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
+                    } else {
+                        const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
+                        q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
+                        qw = 0.33333333333333331483;
+                    }
+                    const V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
+                                     (v1.z * q0 + v2.z * q1) + cen.z * q2);
+                    double eq = __builtin_fma(er0, r.x, er3);
+                    eq = __builtin_fma(er1, r.y, eq);
+                    eq = __builtin_fma(er2, r.z, eq);
+                    const V3 rdot = vl + cross(w, r);
+                    const double ee = -dot(mk3(er0, er1, er2), rdot);
+                    const double damp = fmax(0.0, 1.0 + chi * ee);
+                    const double p = eq * Ebar * damp;
+                    const double dA = qw * area;
+                    if (!(0.0 < p)) continue;
+                    contributed = true;
+                    const double p_dA = p * dA;
+                    const V3 x = r - cop;
+                    const V3 del = Dl + cross(Da, x);
+                    V3 Ts = (del + rdot * tau) * (-k_bar);
+                    Ts = vec_sub_vec_proj(Ts, nh);
+                    const double m2 = dot(Ts, Ts);
+                    V3 T;
+                    if (m2 < mu_s * mu_s) {
+                        T = Ts;
+                    } else {
+                        const double mg = __builtin_sqrt(m2);
+                        const double mu = clamped_piecewise(mg, 2 * mu_s, 3 * mu_s, mu_s, mu_d);
+                        T = (Ts * mu) / mg;
+                    }
+                    const V3 Tc = T * p_dA;
+                    const V3 ta = cross(x, Tc);
+                    sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
+                    sum[3] += Tc.x; sum[4] += Tc.y; sum[5] += Tc.z;
+                }
+            }
+        }
+        accumulate_items<6>(g.acc, item, active, contributed, sum, kAccFric);
+    }
+}
+
