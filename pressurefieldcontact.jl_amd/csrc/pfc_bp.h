@@ -196,7 +196,8 @@ __device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, boo
     float v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-        v[i] = (float)(((R12[i] * b.c[0] + R12[i + 3] * b.c[1]) + R12[i + 6] * b.c[2]) + (t12[i] - a.c[i]));
+        // fused: the rounding of this Float64 offset is far inside the error radius E of the Float32 test
+        v[i] = (float)__builtin_fma(R12[i + 6], b.c[2], __builtin_fma(R12[i + 3], b.c[1], __builtin_fma(R12[i], b.c[0], t12[i] - a.c[i])));
     float Ra[9], Rb[9], T[9], R[9], t[3];
     quat_to_R(a.q, Ra);
     quat_to_R(b.q, Rb);
