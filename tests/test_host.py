@@ -269,3 +269,35 @@ def test_sharded_evaluation_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def _build_c_example(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "box_on_plane")
+    csrc = os.path.join(root, "pressurefieldcontact.jl_amd", "csrc")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "box_on_plane.c"), "-L", csrc, "-lpfc_hip", f"-Wl,-rpath,{csrc}", "-lm",
+                    "-o", exe], check=True)
+    return exe
+
+
+def test_c_example_builds_and_refuses_without_gpu(pfc, tmp_path):
+    """examples/box_on_plane.c binds the C ABI from plain C (what a Julia ccall shim binds).  Without a HIP device it
+    must stop at pfc_create: there is no CPU fallback behind the ABI."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked test")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_matches_analytic_normal_wrench(pfc, tmp_path):
+    """test/test_normal.jl:2-49 through the C ABI from a C program: exact normal wrench of a box on the half-plane."""
+    import subprocess
+    r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
