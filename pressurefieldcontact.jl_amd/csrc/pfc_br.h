@@ -95,11 +95,8 @@ __global__ void __launch_bounds__(64) k_shift(ShiftArgs g) {
     }
 }
 
-// Jacobi eigen-solver for a symmetric 6x6 (stands in for LAPACK eigen!(Hermitian), friction.jl:88).  One thread per
-// item, so the kernel's duration is the length of the serial dependency chain: the sweep uses the round-robin
-// ordering (5 rounds of 3 index-disjoint pairs).  The three rotations of a round read disjoint entries of A, so their
-// angle computations (the sqrt / divide chains) are independent and overlap; every index is a compile-time constant
-// after unrolling, so A and V live in registers (runtime-indexed arrays would go to scratch).
+// Jacobi eigen-solver for a symmetric 6x6 (stands in for LAPACK eigen!(Hermitian), friction.jl:88): rotation angle of
+// one pivot, then the wave-cooperative round-robin iteration.
 __device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq, double &cs, double &sn) {
     // apq == 0: identity rotation
     const double theta = (aqq - app) / (2.0 * apq);
@@ -108,142 +105,132 @@ __device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq,
     cs = 1.0 / __builtin_sqrt(t * t + 1.0);
     sn = t * cs;
 }
-template <int P, int Q>
-__device__ __forceinline__ void jacobi_apply(double *A, double *V, double cs, double sn) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double akp = A[k + 6 * P], akq = A[k + 6 * Q];
-        A[k + 6 * P] = cs * akp - sn * akq; A[k + 6 * Q] = sn * akp + cs * akq;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double apk = A[P + 6 * k], aqk = A[Q + 6 * k];
-        A[P + 6 * k] = cs * apk - sn * aqk; A[Q + 6 * k] = sn * apk + cs * aqk;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double vkp = V[k + 6 * P], vkq = V[k + 6 * Q];
-        V[k + 6 * P] = cs * vkp - sn * vkq; V[k + 6 * Q] = sn * vkp + cs * vkq;
-    }
-}
-template <int P0, int Q0, int P1, int Q1, int P2, int Q2>
-__device__ __forceinline__ void jacobi_round(double *A, double *V) {
-    double c0, s0, c1, s1, c2, s2;
-    jacobi_angle(A[7 * P0], A[7 * Q0], A[P0 + 6 * Q0], c0, s0);
-    jacobi_angle(A[7 * P1], A[7 * Q1], A[P1 + 6 * Q1], c1, s1);
-    jacobi_angle(A[7 * P2], A[7 * Q2], A[P2 + 6 * Q2], c2, s2);
-    jacobi_apply<P0, Q0>(A, V, c0, s0);
-    jacobi_apply<P1, Q1>(A, V, c1, s1);
-    jacobi_apply<P2, Q2>(A, V, c2, s2);
-}
-__device__ __forceinline__ void jacobi6(double *A, double *V, double *w) {
-#pragma unroll
-    for (int i = 0; i < 36; ++i) V[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) V[7 * i] = 1.0;
+// Round-robin Jacobi (5 rounds of 3 index-disjoint pivots per sweep) carried by ONE WAVE: lane e = i + 6 j (e < 36) owns
+// A[i][j] and V[i][j] in LDS.  The three rotations of a round touch disjoint index pairs, so together they map entry
+// (i, j) through the rotation of i's pair (rows) and of j's pair (columns):
+//     new = a_i (a_j A_ij + b_j A_i,pj) + b_i (a_j A_pi,j + b_j A_pi,pj)        (columns first, then rows)
+// with (a, b) = (c, -s) for the smaller index of a pair and (c, +s) for the larger.  Every lane recomputes the two
+// rotation angles it needs from the shared diagonal / pivot entries (broadcast LDS reads) instead of waiting for
+// another lane to publish them.  A round is ~200 instructions and two LDS round trips; the first version (one thread
+// per item, matrices in registers, three overlapped rotations per round) had a 45 us dependency chain, a fifth of the
+// latency of a single bristle evaluation.  Converged when every off-diagonal entry is below the rounding floor of the
+// matrix (eps * largest diagonal) or negligible against its own two diagonal entries; also stops once (after 4
+// sweeps) a sweep no longer halves the off-diagonal mass (nothing but rounding noise is left to annihilate).
+__device__ __forceinline__ void jacobi6_wave(double *A, double *V, int lane) {
+    const bool ent = lane < 36;
+    const int i = ent ? lane % 6 : 0, j = ent ? lane / 6 : 0;
+    if (ent) V[lane] = (i == j) ? 1.0 : 0.0;
+    wave_lds_sync();
+    // partner of every index in the five rounds (0,5)(1,4)(2,3) | (0,4)(3,5)(1,2) | (0,3)(2,4)(1,5) | (0,2)(1,3)(4,5) | (0,1)(2,5)(3,4)
+    const int PT[5][6] = {{5, 4, 3, 2, 1, 0}, {4, 2, 1, 5, 0, 3}, {3, 5, 4, 0, 2, 1}, {2, 3, 0, 1, 5, 4}, {1, 0, 5, 4, 3, 2}};
     double off_prev = 1.79769313486231570815e308;
     for (int sweep = 0; sweep < 40; ++sweep) {
-        // Converged when every off-diagonal entry is below the rounding floor of the matrix (eps * largest diagonal)
-        // or negligible against its own two diagonal entries; also stop once (after 4 sweeps) a sweep no longer
-        // halves the off-diagonal mass (nothing but rounding noise is left to annihilate).  Waiting for an absolute 1e-17
-        // would spin through all sweeps: entries coupled to the large eigenvalues never get below eps * |A|.
-        double off = 0.0, dmax = 0.0;
-        bool done = true;
+        double dmax = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) dmax = fmax(dmax, __builtin_fabs(A[7 * i]));
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int j = i + 1; j < 6; ++j) {
-                const double a = __builtin_fabs(A[i + 6 * j]);
-                off += a * a;
-                done &= a <= 2.3e-16 * dmax || a * a <= 1e-30 * __builtin_fabs(A[7 * i] * A[7 * j]);
-            }
+        for (int k = 0; k < 6; ++k) dmax = fmax(dmax, __builtin_fabs(A[7 * k]));
+        const bool upper = ent && i < j;
+        const double a = upper ? __builtin_fabs(A[lane]) : 0.0;
+        const bool ok = !upper || a <= 2.3e-16 * dmax || a * a <= 1e-30 * __builtin_fabs(A[7 * i] * A[7 * j]);
+        const bool done = __all(ok);
+        const double off = wave_sum(a * a);
         if (done || (sweep >= 4 && !(off < 0.5 * off_prev))) break;
         off_prev = off;
-        jacobi_round<0, 5, 1, 4, 2, 3>(A, V);
-        jacobi_round<0, 4, 3, 5, 1, 2>(A, V);
-        jacobi_round<0, 3, 2, 4, 1, 5>(A, V);
-        jacobi_round<0, 2, 1, 3, 4, 5>(A, V);
-        jacobi_round<0, 1, 2, 5, 3, 4>(A, V);
+        for (int r = 0; r < 5; ++r) {
+            const int pi = PT[r][i], pj = PT[r][j];
+            double ai, bi, aj, bj;
+            {
+                const int p = i < pi ? i : pi, q = i < pi ? pi : i;
+                double cs, sn;
+                jacobi_angle(A[7 * p], A[7 * q], A[p + 6 * q], cs, sn);
+                ai = cs; bi = (i == p) ? -sn : sn;
+            }
+            {
+                const int p = j < pj ? j : pj, q = j < pj ? pj : j;
+                double cs, sn;
+                jacobi_angle(A[7 * p], A[7 * q], A[p + 6 * q], cs, sn);
+                aj = cs; bj = (j == p) ? -sn : sn;
+            }
+            const double t0 = aj * A[i + 6 * j] + bj * A[i + 6 * pj];      // columns first ...
+            const double t1 = aj * A[pi + 6 * j] + bj * A[pi + 6 * pj];
+            const double an = ai * t0 + bi * t1;                            // ... then rows
+            const double vn = aj * V[i + 6 * j] + bj * V[i + 6 * pj];
+            wave_lds_sync();
+            if (ent) { A[lane] = an; V[lane] = vn; }
+            wave_lds_sync();
+        }
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) w[i] = A[7 * i];
 }
 
-// decompose_K! / calc_K̄_sqrt_inv / Δ² (friction.jl:85-132): one thread per bristle item in contact
+// decompose_K! / calc_K̄_sqrt_inv / Δ² (friction.jl:85-132): one wave per bristle item in contact
 __global__ void __launch_bounds__(64) k_eig(BrArgs g) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double K[36], A[36], V[36], Kis[36], sig[6], Sinv[6];
+    const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= g.n_items) return;
     const ItemRec *it = g.items + i;
-    if (it->model != PFC_BRISTLE || g.icnt[4 * (size_t)i + 3] == 0) return;
+    if (it->model != PFC_BRISTLE || g.icnt[4 * (size_t)i + 3] == 0) return;   // uniform over the wave
     const double *a = g.acc + (size_t)i * kAccStride;
     double *r = g.res + (size_t)i * kResStride;
     // cop = sum w r / sum w (normal.jl:33)
     const double S = a[kAccIp];
-    const double c[3] = {a[kAccIpc] / S, a[kAccIpc + 1] / S, a[kAccIpc + 2] / S};
-    r[kResCop] = c[0]; r[kResCop + 1] = c[1]; r[kResCop + 2] = c[2];
+    if (lane < 3) r[kResCop + lane] = a[kAccIpc + lane] / S;
     // calc_patch_spatial_stiffness! (friction.jl:147-169) from the moments about the cop (x = r - cop):
     //   K22 = S I - sum w n n'      K12 = -sum w (x x n) n'   (sum w [x]x = 0 about the cop)
     //   K11 = -(sum w x x' - tr(.) I + sum w (x x n)(x x n)')
-    const int s6[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};  // symmetric 3x3 from 6 unique
-    double Snn[9], San[9], Saa[9], Srr[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        Snn[k] = a[kAccSnn + s6[k]]; Saa[k] = a[kAccSaa + s6[k]]; San[k] = a[kAccSan + k]; Srr[k] = a[kAccSrr + s6[k]];
+    if (lane < 36) {
+        const int s6[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};  // symmetric 3x3 from 6 unique
+        const int ii = lane % 6, jj = lane / 6;
+        const int bi = ii % 3, bj = jj % 3;
+        const double I = (bi == bj) ? 1.0 : 0.0;
+        double kv;
+        if (ii < 3 && jj < 3) {
+            const double trC = (a[kAccSrr] + a[kAccSrr + 3]) + a[kAccSrr + 5];
+            kv = -(a[kAccSrr + s6[bi + 3 * bj]] - trC * I + a[kAccSaa + s6[bi + 3 * bj]]);
+        } else if (ii >= 3 && jj >= 3) {
+            kv = S * I - a[kAccSnn + s6[bi + 3 * bj]];
+        } else if (ii < 3) {
+            kv = -a[kAccSan + bi + 3 * bj];        // K12[bi][bj]
+        } else {
+            kv = -a[kAccSan + bj + 3 * bi];        // K21 = K12'
+        }
+        kv *= it->k_bar;
+        K[lane] = kv;
+        r[kResK + lane] = kv;
     }
-    const double trC = Srr[0] + Srr[4] + Srr[8];
-    double K[36];
+    wave_lds_sync();
+    if (lane < 6) {
+        const double t1 = (K[0] + K[7]) + K[14], t2 = (K[21] + K[28]) + K[35];
+        Sinv[lane] = lane < 3 ? (1.0 / __builtin_sqrt(t1)) * it->magic : 1.0 / __builtin_sqrt(t2);
+    }
+    wave_lds_sync();
+    if (lane < 36) {
+        const int ii = lane % 6, jj = lane / 6;
+        const double kij = (ii <= jj) ? K[ii + 6 * jj] : K[jj + 6 * ii];   // Hermitian: upper triangle authoritative
+        A[lane] = (Sinv[ii] * kij) * Sinv[jj];
+    }
+    wave_lds_sync();
+    jacobi6_wave(A, V, lane);
+    if (lane < 6) {
+        double mx = A[0];
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii) {
-            const double I = (ii == j) ? 1.0 : 0.0;
-            const double k11 = -(Srr[ii + 3 * j] - trC * I + Saa[ii + 3 * j]);
-            const double k12 = -San[ii + 3 * j];
-            const double k22 = S * I - Snn[ii + 3 * j];
-            K[ii + 6 * j] = k11;
-            K[ii + 6 * (j + 3)] = k12;
-            K[(j + 3) + 6 * ii] = k12;
-            K[(ii + 3) + 6 * (j + 3)] = k22;
-        }
-#pragma unroll
-    for (int k = 0; k < 36; ++k) { K[k] *= it->k_bar; r[kResK + k] = K[k]; }
-    double t1 = (K[0] + K[7]) + K[14], t2 = (K[21] + K[28]) + K[35];
-    double s1 = 1.0 / __builtin_sqrt(t1), s2 = 1.0 / __builtin_sqrt(t2);
-    double Sinv[6];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { Sinv[k] = s1 * it->magic; Sinv[k + 3] = s2; }
-    double Kb[36], V[36], sig[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-#pragma unroll
-        for (int ii = 0; ii < 6; ++ii) {
-            double kij = (ii <= j) ? K[ii + 6 * j] : K[j + 6 * ii];
-            Kb[ii + 6 * j] = (Sinv[ii] * kij) * Sinv[j];
-        }
-    jacobi6(Kb, V, sig);
-    double mx = sig[0];
-#pragma unroll
-    for (int k = 1; k < 6; ++k) mx = fmax(mx, sig[k]);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) sig[k] = 1.0 / __builtin_sqrt(fmax(sig[k], mx * 1.0e-16));
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-#pragma unroll
-        for (int ii = 0; ii < 6; ++ii) {
-            double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc += (V[ii + 6 * k] * sig[k]) * V[j + 6 * k];
-            r[kResKis + ii + 6 * j] = acc;
-        }
-#pragma unroll
-    for (int ii = 0; ii < 6; ++ii) {
+        for (int k = 1; k < 6; ++k) mx = fmax(mx, A[7 * k]);
+        sig[lane] = 1.0 / __builtin_sqrt(fmax(A[7 * lane], mx * 1.0e-16));
+    }
+    wave_lds_sync();
+    if (lane < 36) {
+        const int ii = lane % 6, jj = lane / 6;
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc += r[kResKis + ii + 6 * k] * it->s[k];
-        r[kResDelta + ii] = Sinv[ii] * acc;
-        r[kResSinv + ii] = Sinv[ii];
+        for (int k = 0; k < 6; ++k) acc += (V[ii + 6 * k] * sig[k]) * V[jj + 6 * k];
+        Kis[lane] = acc;
+        r[kResKis + lane] = acc;
+    }
+    wave_lds_sync();
+    if (lane < 6) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc += Kis[lane + 6 * k] * it->s[k];
+        r[kResDelta + lane] = Sinv[lane] * acc;
+        r[kResSinv + lane] = Sinv[lane];
     }
 }
 

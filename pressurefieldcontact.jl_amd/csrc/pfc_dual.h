@@ -589,147 +589,130 @@ __global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
     }
 }
 
-// symmetric 6x6 eigen-decomposition (cyclic Jacobi), column-major; one thread
-__device__ inline void dual_jacobi6(double *A, double *V, double *w) {
-    for (int i = 0; i < 36; ++i) V[i] = 0.0;
-    for (int i = 0; i < 6; ++i) V[7 * i] = 1.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, dia = 0.0;
-        for (int i = 0; i < 6; ++i)
-            for (int j = 0; j < 6; ++j)
-                if (i != j) off += A[i + 6 * j] * A[i + 6 * j]; else dia += A[7 * i] * A[7 * i];
-        if (off <= 1e-300 || off <= 1e-34 * dia) break;
-        for (int p = 0; p < 5; ++p)
-            for (int q = p + 1; q < 6; ++q) {
-                const double apq = A[p + 6 * q];
-                if (apq == 0.0) continue;
-                const double theta = (A[7 * q] - A[7 * p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / __builtin_sqrt(t * t + 1.0), sn = t * cs;
-                for (int k = 0; k < 6; ++k) {
-                    const double akp = A[k + 6 * p], akq = A[k + 6 * q];
-                    A[k + 6 * p] = cs * akp - sn * akq; A[k + 6 * q] = sn * akp + cs * akq;
-                }
-                for (int k = 0; k < 6; ++k) {
-                    const double apk = A[p + 6 * k], aqk = A[q + 6 * k];
-                    A[p + 6 * k] = cs * apk - sn * aqk; A[q + 6 * k] = sn * apk + cs * aqk;
-                }
-                for (int k = 0; k < 6; ++k) {
-                    const double vkp = V[k + 6 * p], vkq = V[k + 6 * q];
-                    V[k + 6 * p] = cs * vkp - sn * vkq; V[k + 6 * q] = sn * vkp + cs * vkq;
-                }
-            }
-    }
-    for (int i = 0; i < 6; ++i) w[i] = A[7 * i];
-}
+// forward declarations (pfc_br.h, included after this header)
+__device__ __forceinline__ void jacobi6_wave(double *A, double *V, int lane);
 
-// per (item, direction): cop, decompose_K! (friction.jl:96-117) with the Frechet derivative of K̄^{-1/2}, Delta (:130-131)
+// per (item, direction), one wave: cop, decompose_K! (friction.jl:96-117) with the Frechet derivative of K̄^{-1/2},
+// Delta (:130-131).  Lane e = i + 6 j (e < 36) owns entry (i, j) of every 6 x 6 matrix; the matrices live in LDS.
+// (The first version ran one thread per (item, direction) with its matrices in scratch: a 0.4 ms dependency chain,
+// half of the latency of a Dual evaluation of a single bristle scene.)
 __global__ void __launch_bounds__(64) k_dual_eig(DualArgs g) {
-    const int key = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double Kv[36], Kd[36], A[36], dK[36], V[36], T[36], M[36], KisV[36], KisD[36];
+    __shared__ double SinvV[6], SinvD[6], f[6], fp[6], fx[6], lam[6];
+    __shared__ int clamped[6];
+    const int key = blockIdx.x, lane = threadIdx.x;
     if (key >= g.n_items * g.n_dir) return;
     const int item = key / g.n_dir;
     const ItemRec *it = g.items + item;
-    if (it->model == PFC_REGULARIZED || g.icnt[4 * (size_t)item + 3] <= 0) return;
+    if (it->model == PFC_REGULARIZED || g.icnt[4 * (size_t)item + 3] <= 0) return;   // uniform over the wave
     const double *a = g.dacc + (size_t)key * kDaStride;
     double *res = g.dres + (size_t)key * kDrStride;
-    {
+    if (lane < 3) {
         const Du ip = du(a[kDaA + 6], a[kDaA + 16]);
-        for (int k = 0; k < 3; ++k) {
-            const Du c = du(a[kDaA + 7 + k], a[kDaA + 17 + k]) / ip;
-            res[kDrCop + k] = c.v; res[kDrCop + 3 + k] = c.d;
-        }
+        const Du c = du(a[kDaA + 7 + lane], a[kDaA + 17 + lane]) / ip;
+        res[kDrCop + lane] = c.v; res[kDrCop + 3 + lane] = c.d;
     }
-    const double k_bar = it->k_bar;
-    Du K[36];
-    {
-        const double *b = a + kDaB;
-        auto S = [&](int k) { return du(b[k], b[21 + k]) * k_bar; };
+    const bool ent = lane < 36;
+    const int i = ent ? lane % 6 : 0, j = ent ? lane / 6 : 0;
+    if (ent) {
+        // K from the 21 sums of pass B: K11 (xx xy xz yy yz zz), K12 (9, column-major), K22 (6); K21 = K12'
         const int u11[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
-        for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i) {
-                K[i + 6 * j] = S(u11[i][j]);
-                K[i + 6 * (j + 3)] = S(6 + i + 3 * j);
-                K[(i + 3) + 6 * j] = S(6 + j + 3 * i);
-                K[(i + 3) + 6 * (j + 3)] = S(15 + u11[i][j]);
-            }
+        const int bi = i % 3, bj = j % 3;
+        int k;
+        if (i < 3 && j < 3) k = u11[bi][bj];
+        else if (i >= 3 && j >= 3) k = 15 + u11[bi][bj];
+        else if (i < 3) k = 6 + bi + 3 * bj;
+        else k = 6 + bj + 3 * bi;
+        const double *b = a + kDaB;
+        const Du kv = du(b[k], b[21 + k]) * it->k_bar;
+        Kv[lane] = kv.v; Kd[lane] = kv.d;
     }
-    const Du t1 = (K[0] + K[7]) + K[14], t2 = (K[21] + K[28]) + K[35];
-    const Du s1 = du(1.0) / dsqrt(t1), s2 = du(1.0) / dsqrt(t2);
-    Du Sinv[6];
-    for (int k = 0; k < 3; ++k) { Sinv[k] = s1 * it->magic; Sinv[k + 3] = s2; }
-    double A[36], V[36], lam[6], dK[36];
-    for (int j = 0; j < 6; ++j)
-        for (int i = 0; i < 6; ++i) {
-            const Du kij = (i <= j) ? K[i + 6 * j] : K[j + 6 * i];
-            const Du kb = (Sinv[i] * kij) * Sinv[j];
-            A[i + 6 * j] = kb.v; dK[i + 6 * j] = kb.d;
-        }
-    dual_jacobi6(A, V, lam);
-    double mx = lam[0];
-    int imx = 0;
-    for (int k = 1; k < 6; ++k) if (lam[k] > mx) { mx = lam[k]; imx = k; }
-    double T[36], M[36];
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < 6; ++k) s += dK[i + 6 * k] * V[k + 6 * j];
-            T[i + 6 * j] = s;
-        }
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < 6; ++k) s += V[k + 6 * i] * T[k + 6 * j];
-            M[i + 6 * j] = s;
-        }
-    const double floor_v = mx * 1.0e-16, dfloor = M[imx + 6 * imx] * 1.0e-16;
-    double f[6], fp[6], fx[6];
-    bool clamped[6];
-    for (int k = 0; k < 6; ++k) {
-        clamped[k] = !(lam[k] > floor_v);
-        const double x = clamped[k] ? floor_v : lam[k];
-        f[k] = 1.0 / __builtin_sqrt(x);
-        const double dfdx = -0.5 * f[k] / x;
-        fp[k] = clamped[k] ? 0.0 : dfdx;
-        fx[k] = clamped[k] ? dfdx * dfloor : 0.0;
+    wave_lds_sync();
+    if (lane < 6) {
+        const Du t1 = (du(Kv[0], Kd[0]) + du(Kv[7], Kd[7])) + du(Kv[14], Kd[14]);
+        const Du t2 = (du(Kv[21], Kd[21]) + du(Kv[28], Kd[28])) + du(Kv[35], Kd[35]);
+        const Du sv = lane < 3 ? (du(1.0) / dsqrt(t1)) * it->magic : du(1.0) / dsqrt(t2);
+        SinvV[lane] = sv.v; SinvD[lane] = sv.d;
     }
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-            double gij;
-            if (i == j) gij = fp[i];
-            else if (clamped[i] && clamped[j]) gij = 0.0;
-            else if (lam[i] != lam[j]) gij = (f[i] - f[j]) / (lam[i] - lam[j]);
-            else gij = fp[i];
-            M[i + 6 * j] *= gij;
-        }
-    for (int k = 0; k < 6; ++k) M[7 * k] += fx[k];
-    Du Kis[36];
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < 6; ++k) s += (V[i + 6 * k] * f[k]) * V[j + 6 * k];
-            Kis[i + 6 * j].v = s;
-        }
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < 6; ++k) s += M[i + 6 * k] * V[j + 6 * k];
-            T[i + 6 * j] = s;
-        }
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < 6; ++k) s += V[i + 6 * k] * T[k + 6 * j];
-            Kis[i + 6 * j].d = s;
-        }
-    const double *ds = g.d_s + (size_t)key * 6;
-    for (int i = 0; i < 6; ++i) {
+    wave_lds_sync();
+    if (ent) {
+        const int e = (i <= j) ? i + 6 * j : j + 6 * i;   // Hermitian: upper triangle authoritative
+        const Du kb = (du(SinvV[i], SinvD[i]) * du(Kv[e], Kd[e])) * du(SinvV[j], SinvD[j]);
+        A[lane] = kb.v; dK[lane] = kb.d;
+    }
+    wave_lds_sync();
+    jacobi6_wave(A, V, lane);
+    // M = V' dK V
+    if (ent) {
+        double x = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x += dK[i + 6 * k] * V[k + 6 * j];
+        T[lane] = x;
+    }
+    wave_lds_sync();
+    if (ent) {
+        double x = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x += V[k + 6 * i] * T[k + 6 * j];
+        M[lane] = x;
+    }
+    wave_lds_sync();
+    if (lane < 6) {
+        double mx = A[0];
+        int imx = 0;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) if (A[7 * k] > mx) { mx = A[7 * k]; imx = k; }
+        const double floor_v = mx * 1.0e-16, dfloor = M[imx + 6 * imx] * 1.0e-16;   // d(sigma_max) = v_max' dK v_max
+        const double l = A[7 * lane];
+        const bool cl = !(l > floor_v);          // max(sigma, floor): ties take the floor
+        const double x = cl ? floor_v : l;
+        const double fv = 1.0 / __builtin_sqrt(x), dfdx = -0.5 * fv / x;
+        lam[lane] = l; f[lane] = fv; clamped[lane] = cl ? 1 : 0;
+        fp[lane] = cl ? 0.0 : dfdx;              // df/dsigma of the own eigenvalue
+        fx[lane] = cl ? dfdx * dfloor : 0.0;     // df through the floor
+    }
+    wave_lds_sync();
+    double gm = 0.0;
+    if (ent) {
+        double gij;
+        if (i == j) gij = fp[i];
+        else if (clamped[i] && clamped[j]) gij = 0.0;
+        else if (lam[i] != lam[j]) gij = (f[i] - f[j]) / (lam[i] - lam[j]);
+        else gij = fp[i];
+        gm = gij * M[lane] + (i == j ? fx[i] : 0.0);
+        double x = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x += (V[i + 6 * k] * f[k]) * V[j + 6 * k];
+        KisV[lane] = x;
+    }
+    wave_lds_sync();
+    if (ent) M[lane] = gm;          // G o M (+ floor terms on the diagonal)
+    wave_lds_sync();
+    if (ent) {
+        double x = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x += M[i + 6 * k] * V[j + 6 * k];
+        T[lane] = x;
+    }
+    wave_lds_sync();
+    if (ent) {
+        double x = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x += V[i + 6 * k] * T[k + 6 * j];
+        KisD[lane] = x;
+        res[kDrKis + lane] = KisV[lane]; res[kDrKis + 36 + lane] = x;
+    }
+    wave_lds_sync();
+    if (lane < 6) {
+        const double *ds = g.d_s + (size_t)key * 6;
         Du acc = du(0.0);
-        for (int k = 0; k < 6; ++k) acc += Kis[i + 6 * k] * du(it->s[k], ds[k]);
-        const Du dl = Sinv[i] * acc;
-        res[kDrDelta + i] = dl.v; res[kDrDelta + 6 + i] = dl.d;
-        res[kDrSinv + i] = Sinv[i].v; res[kDrSinv + 6 + i] = Sinv[i].d;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc += du(KisV[lane + 6 * k], KisD[lane + 6 * k]) * du(it->s[k], ds[k]);
+        const Du sv = du(SinvV[lane], SinvD[lane]);
+        const Du dl = sv * acc;
+        res[kDrDelta + lane] = dl.v; res[kDrDelta + 6 + lane] = dl.d;
+        res[kDrSinv + lane] = sv.v; res[kDrSinv + 6 + lane] = sv.d;
     }
-    for (int k = 0; k < 36; ++k) { res[kDrKis + k] = Kis[k].v; res[kDrKis + 36 + k] = Kis[k].d; }
 }
 
 // per (item, direction): total wrench and sdot partials (friction.jl:134-143, :77-81)

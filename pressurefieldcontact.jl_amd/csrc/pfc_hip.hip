@@ -441,7 +441,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         ShiftArgs sh;
         sh.rec = h->rec.p; sh.rcount = rcount; sh.rcap = (int)h->rcap; sh.acc = h->acc.p;
         hipLaunchKernelGGL(k_shift, dim3(grid_for(h->rcap, 64, 2048)), dim3(64), 0, st, sh);
-        hipLaunchKernelGGL(k_eig, dim3(grid_for(n_items, 64, 1 << 20)), dim3(64), 0, st, br);
+        hipLaunchKernelGGL(k_eig, dim3(n_items), dim3(64), 0, st, br);   // one wave per item
         FricArgs fr;
         fr.items = h->items.p; fr.poly_item = h->poly_item.p; fr.poly = h->poly.p; fr.pcount = pcount;
         fr.pcap = (int)h->ccap; fr.res = h->res.p; fr.acc = h->acc.p;
@@ -989,7 +989,7 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     if (h->any_bristle) {
         const int pgrid = grid_for(dpcap, 64, 256 * 16);
         hipLaunchKernelGGL((k_dual_poly<1>), dim3(pgrid), dim3(64), 0, st, a);
-        hipLaunchKernelGGL(k_dual_eig, dim3(kgrid), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_dual_eig, dim3((unsigned)nk), dim3(64), 0, st, a);   // one wave per (item, direction)
         hipLaunchKernelGGL((k_dual_poly<2>), dim3(pgrid), dim3(64), 0, st, a);
     }
     hipLaunchKernelGGL(k_dual_final, dim3(kgrid), dim3(64), 0, st, a);
