@@ -961,10 +961,29 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     HIP_TRY(h, h->dual_res.ensure(nk * kDrStride));
     HIP_TRY(h, h->dual_out.ensure(nk * 12));
     double *dp = h->dual_in.p, *dt = dp + nk * 24, *dsd = dt + nk * 6;
-    HIP_TRY(h, hipMemcpyAsync(dp, d_pose, sizeof(double) * nk * 24, hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipMemcpyAsync(dt, d_twist, sizeof(double) * nk * 6, hipMemcpyHostToDevice, st));
-    if (d_s) HIP_TRY(h, hipMemcpyAsync(dsd, d_s, sizeof(double) * nk * 6, hipMemcpyHostToDevice, st));
-    else HIP_TRY(h, hipMemsetAsync(dsd, 0, sizeof(double) * nk * 6, st));
+    // one pinned block up (d_pose | d_twist | d_s), one down (d_wrench | d_sdot), as in pfc_eval (whose staging
+    // buffers are free again at this point)
+    const size_t in_bytes = sizeof(double) * nk * 36, out_bytes = sizeof(double) * nk * 12;
+    if (h->pin_in_cap < in_bytes) {
+        if (h->pin_in) (void)hipHostFree(h->pin_in);
+        h->pin_in = nullptr; h->pin_in_cap = 0;
+        HIP_TRY(h, hipHostMalloc(&h->pin_in, in_bytes * 2));
+        h->pin_in_cap = in_bytes * 2;
+    }
+    if (h->pin_out_cap < out_bytes) {
+        if (h->pin_out) (void)hipHostFree(h->pin_out);
+        h->pin_out = nullptr; h->pin_out_cap = 0;
+        HIP_TRY(h, hipHostMalloc(&h->pin_out, out_bytes * 2));
+        h->pin_out_cap = out_bytes * 2;
+    }
+    {
+        double *pi = (double *)h->pin_in;
+        std::memcpy(pi, d_pose, sizeof(double) * nk * 24);
+        std::memcpy(pi + nk * 24, d_twist, sizeof(double) * nk * 6);
+        if (d_s) std::memcpy(pi + nk * 30, d_s, sizeof(double) * nk * 6);
+        else std::memset(pi + nk * 30, 0, sizeof(double) * nk * 6);
+        HIP_TRY(h, hipMemcpyAsync(dp, pi, in_bytes, hipMemcpyHostToDevice, st));
+    }
     HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
     DualArgs a;
     a.items = h->items.p; a.cand = h->cand.p; a.ccount = h->tail.p + 12; a.ccap = (int)h->ccap;   // packed copy of the counters
@@ -994,9 +1013,10 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     }
     hipLaunchKernelGGL(k_dual_final, dim3(kgrid), dim3(64), 0, st, a);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(d_wrench, a.d_wrench, sizeof(double) * nk * 6, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipMemcpyAsync(d_sdot, a.d_sdot, sizeof(double) * nk * 6, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(h->pin_out, h->dual_out.p, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
+    std::memcpy(d_wrench, h->pin_out, sizeof(double) * nk * 6);
+    std::memcpy(d_sdot, (const double *)h->pin_out + nk * 6, sizeof(double) * nk * 6);
     return PFC_OK;
 }
 
