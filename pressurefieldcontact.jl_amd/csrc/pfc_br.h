@@ -5,6 +5,10 @@
 // bristle model: cop, patch stiffness, 6x6 eigen, friction pass, finalisation
 // =================================================================================================================
 struct BrArgs {
+    int *ctr;            // counter block, packed into tail and zeroed by k_final
+    int n_ctr;
+    unsigned *status;
+    int *tail;
     const ItemRec *items;
     int n_items;
     double *acc;
@@ -235,9 +239,7 @@ __global__ void __launch_bounds__(64) k_eig(BrArgs g) {
 }
 
 // yes_contact! / no_contact! epilogue (friction.jl:76-81,119-143; non_friction.jl:77-83)
-__global__ void k_final(BrArgs g) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.n_items) return;
+__device__ __forceinline__ void final_item(const BrArgs &g, int i) {
     const ItemRec *it = g.items + i;
     const double *a = g.acc + (size_t)i * kAccStride;
     const double *r = g.res + (size_t)i * kResStride;
@@ -269,26 +271,30 @@ __global__ void k_final(BrArgs g) {
     }
 }
 
-// Gathers everything the host needs to judge an evaluation into one small block (one D2H copy instead of five):
-// tail[0..3] status words, tail[4..11] totals {node tests, non-empty pairs, traction points, 0} as 64-bit,
-// tail[12..] the counter block (candidates, traction slots, seed ticket, records, frontier sizes per level).
-// Also leaves the counters and the status word zeroed for the next evaluation (two memset nodes less per launch
-// sequence: what a small scene pays is launches, not kernels); the packed copy in `tail` is what later readers use.
-__global__ void __launch_bounds__(256) k_pack(int n_items, const int *icnt, int *ctr, int n_ctr, unsigned *status,
-                                               int *tail) {
+// k_final: the per-item epilogue, and -- in block 0, after its own items -- the packing of everything the host needs
+// to judge an evaluation into one small block (one D2H copy instead of five): tail[0..3] status words, tail[4..11] totals
+// {node tests, non-empty pairs, traction points, 0} as 64-bit, tail[12..] the counter block (candidates, traction slots,
+// seed ticket, records, frontier sizes per level).  The packing only reads what earlier kernels wrote, so it does not
+// wait for the other blocks; it also leaves the counters and the status word zeroed for the next evaluation.  (What a
+// small scene pays is launches, not kernels: this used to be a kernel of its own plus two memset nodes.)
+__global__ void __launch_bounds__(128) k_final(BrArgs g) {
     __shared__ unsigned long long tot[3];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < g.n_items) final_item(g, i);
+    if (blockIdx.x != 0) return;
     if (threadIdx.x < 3) tot[threadIdx.x] = 0ull;
     __syncthreads();
     unsigned long long a = 0, b = 0, c = 0;
-    for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
-        a += (unsigned)icnt[4 * (size_t)i]; b += (unsigned)icnt[4 * (size_t)i + 2]; c += (unsigned)icnt[4 * (size_t)i + 3];
+    for (int k = threadIdx.x; k < g.n_items; k += blockDim.x) {
+        a += (unsigned)g.icnt[4 * (size_t)k]; b += (unsigned)g.icnt[4 * (size_t)k + 2]; c += (unsigned)g.icnt[4 * (size_t)k + 3];
     }
     atomicAdd(&tot[0], a); atomicAdd(&tot[1], b); atomicAdd(&tot[2], c);
     __syncthreads();
-    if (threadIdx.x < 4) { tail[threadIdx.x] = (int)status[threadIdx.x]; status[threadIdx.x] = 0u; }
+    int *tail = g.tail;
+    if (threadIdx.x < 4) { tail[threadIdx.x] = (int)g.status[threadIdx.x]; g.status[threadIdx.x] = 0u; }
     if (threadIdx.x < 3) reinterpret_cast<unsigned long long *>(tail + 4)[threadIdx.x] = tot[threadIdx.x];
     if (threadIdx.x == 3) reinterpret_cast<unsigned long long *>(tail + 4)[3] = 0ull;
-    for (int k = threadIdx.x; k < n_ctr; k += blockDim.x) { tail[12 + k] = ctr[k]; ctr[k] = 0; }
+    for (int k = threadIdx.x; k < g.n_ctr; k += blockDim.x) { tail[12 + k] = g.ctr[k]; g.ctr[k] = 0; }
 }
 
 // addGeneralizedForcesThirdLaw! (non_friction.jl:267-286): per item, the wrench on body 2 (frame r2) goes to the

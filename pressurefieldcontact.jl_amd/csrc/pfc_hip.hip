@@ -7,7 +7,7 @@
 //   pfc_np.h       narrowphase: k_narrow (gather, clip in an LDS polygon ring, fan quadrature, pressure, regularized
 //                  friction, bristle moments, kept polygons), k_fric (bristle friction over kept polygons)
 //   pfc_dual.h     the same path on (value, partial) numbers: k_narrow_dual, k_dual_poly, k_dual_eig, k_dual_final
-//   pfc_br.h       k_shift, k_eig (6x6 Jacobi), k_final, k_pack, k_scatter, k_selftest
+//   pfc_br.h       k_shift, k_eig (6x6 Jacobi, one wave per item), k_final (+ result packing), k_scatter, k_selftest
 // This file: mesh record preparation (k_prep_tri, k_prep_tet), per-item setup (k_setup_items), work-list management,
 // hipGraph capture / replay, the two-half evaluation and every extern "C" entry point.
 #include "pfc_kernels.h"
@@ -437,6 +437,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     br.items = h->items.p; br.n_items = n_items; br.acc = h->acc.p; br.res = h->res.p; br.icnt = h->icnt.p;
     br.trac = trac_view(h); br.tcount = tcount; br.tcap = (int)h->tcap; br.wrench = d_wrench; br.sdot = d_sdot;
     br.counts = d_counts;
+    br.ctr = h->ctr.p; br.n_ctr = levels + 12; br.status = h->status.p; br.tail = h->tail.p;
     if (h->any_bristle) {
         ShiftArgs sh;
         sh.rec = h->rec.p; sh.rcount = rcount; sh.rcap = (int)h->rcap; sh.acc = h->acc.p;
@@ -450,7 +451,6 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BR], st));
     hipLaunchKernelGGL(k_final, dim3(grid_for(n_items, 128, 1 << 20)), dim3(128), 0, st, br);
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_FIN], st));
-    hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, st, n_items, h->icnt.p, h->ctr.p, levels + 12, h->status.p, h->tail.p);
     HIP_TRY(h, hipGetLastError());
     return PFC_OK;
 }
