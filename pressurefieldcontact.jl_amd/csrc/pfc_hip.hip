@@ -190,7 +190,7 @@ struct pfc_context {
     DevBuf<int> ctr;                   // [0]=ccount [1]=tcount [2..] fcount[levels+2]
     DevBuf<unsigned> status;
     DevBuf<unsigned long long> stamps;   // diagnostic builds
-    DevBuf<int> tail;                    // k_pack output (status, totals, counters)
+    DevBuf<int> tail;                    // packed status, totals, counters (block 0 of k_final)
     int *h_tail = nullptr;               // pinned host mirror of tail
     size_t h_tail_cap = 0;
     void *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-buffer path
@@ -371,7 +371,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2, *rcount = h->ctr.p + 3;
     int *ucount = h->ctr.p + 4, *fcount = h->ctr.p + 6;
     int *pcount = h->ctr.p + ((levels + 9) & ~1);   // after the per-level frontier counts; 8-byte aligned pair
-    // counters and status are zero here: k_pack of the previous evaluation (or ensure_work after an allocation) left them so
+    // counters and status are zero here: k_final of the previous evaluation (or ensure_work after an allocation) left them so
 #ifdef PFC_STAMPS
     HIP_TRY(h, hipMemsetAsync(h->stamps.p, 0, sizeof(unsigned long long) * 16, st));
 #endif
