@@ -179,6 +179,7 @@ struct Dfs32Args {
     int *icnt;
     unsigned *status;
     int reserve;
+    unsigned long long *stamps;   // diagnostic builds: [8..12] cycles in pop+load / test / barrier+prefix / push, iterations
 };
 
 __device__ __forceinline__ NodeF load_nodef(const NodeF *n) {
@@ -360,11 +361,16 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
             s_def = 0;
         }
         __syncthreads();
+#ifdef PFC_STAMPS
+        unsigned long long c_a = 0, c_b = 0, c_c = 0, c_d = 0, c_it = 0, c_p = 0;
+#endif
         // every workgroup must reach its exit: the iteration guard stops a corrupt (cyclic) tree from spinning forever
         for (int guard = 0; (sp > 0 || n_def > 0) && guard < (1 << 22); ++guard) {
             // Either settle the pairs the previous iteration left undecided (exact Float64 test; their children still
             // have the room that iteration reserved for them), or pop up to 256 pairs, but never more than the stack can
             // take back as children (4 per pair).  n_def is uniform over the workgroup.
+            unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0; (void)u0; (void)u1; (void)u2; (void)u3; (void)u4;
+            STAMP(u0);
             const bool settle = n_def > 0;
             int pw = (kDfsStack32 - g.reserve - sp) / 3;
             int p = sp < kDfsBlock ? sp : kDfsBlock;
@@ -386,6 +392,10 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
                 const NodeF a = load_nodef(n1 + node_index(e.x));
                 const NodeF b = load_nodef(n2 + node_index(e.y));
                 a0 = a.link0; a1 = a.link1; b0 = b.link0; b1 = b.link1;
+#ifdef PFC_STAMPS
+                { float keep = a.e[0] + b.e[0] + a.q[3] + b.q[3]; asm volatile("" ::"v"(keep)); }   // the loads have landed
+                STAMP(u1);
+#endif
                 if (!settle) {
                     double R12[9], t12[3];
                     float R12f[9];
@@ -396,6 +406,7 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
                     verdict = test_pair_f32(a, b, la || lb, R12, R12f, t12);
                 }
             }
+            STAMP(u2);
             // an undecided pair is parked for the next iteration (verdict 2 only comes from the Float32 test)
             if (verdict == 2) und_l[atomicAdd(&s_def, 1)] = e;
             const bool hit = verdict == 1;
@@ -408,6 +419,7 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
                 s_cnt[wave][1] = 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
             }
             __syncthreads();
+            STAMP(u3);
             n_def = s_def;   // read by everyone between this barrier and the next; reset after the next
             int c_off = 0, p_off = 0, c_tot = 0, p_tot = 0;
 #pragma unroll
@@ -439,7 +451,19 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
                 n_cand += n_out;
                 n_out = 0;
             }
+#ifdef PFC_STAMPS
+            STAMP(u4);
+            if (!settle) {   // summed in registers: an atomic per iteration would itself dominate the timing
+                c_a += u1 - u0; c_b += u2 - u1; c_c += u3 - u2; c_d += u4 - u3; c_it += 1; c_p += (unsigned long long)p;
+            }
+#endif
         }
+#ifdef PFC_STAMPS
+        if (tid == 0 && g.stamps) {
+            atomicAdd(&g.stamps[8], c_a); atomicAdd(&g.stamps[9], c_b); atomicAdd(&g.stamps[10], c_c);
+            atomicAdd(&g.stamps[13], c_d); atomicAdd(&g.stamps[11], c_it); atomicAdd(&g.stamps[12], c_p);
+        }
+#endif
         if (tid == 0) {
             if (sp > 0 || n_def > 0) atomicOr(g.status, kStAbort);
             atomicAdd(&g.icnt[4 * (size_t)item], n_test);

@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(64) k_shift(ShiftArgs g) {
     const int lane = threadIdx.x;
     for (int base = blockIdx.x * 64; base < n_r; base += gridDim.x * 64) {
         const int i = base + lane;
-        if (i < n_r) {
+        items[lane] = -1;
+        if (i < n_r && g.rec[(size_t)i * kRecStride + 1] > 0.0) {   // W = 0: a reserved slot that was not needed
             const double *r = g.rec + (size_t)i * kRecStride;
             const int item = (int)r[0];
             const double W = r[1];
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(64) k_shift(ShiftArgs g) {
         __syncthreads();
         const int n_here = (n_r - base < 64) ? (n_r - base) : 64;
         for (int q = 0; q < n_here; ++q) {
-            if (lane < 27) {
+            if (lane < 27 && items[q] >= 0) {
                 const double x = out[q * 28 + lane];
                 if (x != 0.0) unsafeAtomicAdd(&g.acc[(size_t)items[q] * kAccStride + kAccSnn + lane], x);
             }

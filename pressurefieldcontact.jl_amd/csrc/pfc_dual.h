@@ -251,12 +251,15 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
         const bool active = dir < n_dir && idx < n_c;
         WorkRec cw;
         cw.item = 0; cw.a = 0; cw.b = 0; cw.pad = 0;
-        if (active) cw = g.cand[g.surv[idx]];
+        int ci = -1;
+        if (active) ci = g.surv[idx];   // -1: the pair had a polygon but did not contribute in the value pass
+        if (ci >= 0) cw = g.cand[ci];
         const ItemRec *it = g.items + cw.item;
         const TetRec *tp = it->tet + cw.b;
         const bool reg = it->model == PFC_REGULARIZED;
-        const int key = active ? cw.item * n_dir + dir : -1;
-        const bool work = active && g.icnt[4 * (size_t)cw.item + 3] > 0;
+        const bool live = active && ci >= 0;
+        const int key = live ? cw.item * n_dir + dir : -1;
+        const bool work = live && g.icnt[4 * (size_t)cw.item + 3] > 0;
         int n_poly = 0, rbase = 0;
         Du3 nh = dmk(du(0.0), du(0.0), du(0.0));
         if (work) {
@@ -532,7 +535,7 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
         double flat[2 * NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) { flat[k] = sum[k].v; flat[NS + k] = sum[k].d; }
-        accumulate_items<2 * NS>(g.dacc, key, active, work && n_trac_lane > 0, flat, kDaA, kDaStride);
+        accumulate_items<2 * NS>(g.dacc, key, live, work && n_trac_lane > 0, flat, kDaA, kDaStride);
     }
 }
 #undef PV

@@ -413,7 +413,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
             Dfs32Args f;
             f.items = h->items.p; f.seeds = h->frontier[L & 1].p; f.n_seed = fcount + L; f.next_seed = next_seed;
             f.seed_cap = (int)h->fcap; f.cand = h->cand.p; f.ccount = ccount; f.ccap = (int)h->ccap;
-            f.ucount = ucount; f.icnt = h->icnt.p; f.status = h->status.p;
+            f.ucount = ucount; f.icnt = h->icnt.p; f.status = h->status.p; f.stamps = h->stamps.p;
             f.reserve = 3 * levels + 3;
             hipLaunchKernelGGL(k_bp_dfs32, dim3(grid_for(bound, 1, 256 * 6)), dim3(kDfsBlock), 0, st, f);
         }

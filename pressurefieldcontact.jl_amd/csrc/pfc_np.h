@@ -125,6 +125,9 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
     if (n_c > g.ccap) n_c = g.ccap;
     const int stride = gridDim.x * kNpBlock;
     const int n_round = (n_c + stride - 1) / stride;
+#ifdef PFC_STAMPS
+    unsigned long long st_c[6] = {0, 0, 0, 0, 0, 0}, st_r[3] = {0, 0, 0};
+#endif
     for (int rd = 0; rd < n_round; ++rd) {
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
         (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5;
@@ -374,6 +377,31 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             }
             tbase = base + incl - slots;
         }
+        // Slots of the lists this wave will append to at the END of the round are reserved HERE, before the integration:
+        // the returning atomics (~1-2 us each under load) then complete behind ~17 000 cycles of quadrature instead of
+        // stalling the reductions.  What a lane will contribute is not known yet, so the reservation is for every lane
+        // that has a polygon (bristle lanes: a kept-polygon slot; with the Dual list on: a contributing-pair slot) and
+        // for one moment record per run of an item; slots that turn out unused get an empty marker.
+        const bool has_poly = work && n_poly >= 3;
+        const bool polyb = has_poly && !reg;
+        const bool polys = has_poly && g.surv != nullptr;
+        const unsigned long long km = __ballot(polyb), sm = __ballot(polys);
+        // heads of the runs of equal items among the active lanes (the candidate list is grouped by item)
+        const int item_prev = __shfl_up(cw.item, 1, 64);
+        const unsigned long long am = __ballot(active);
+        const unsigned long long heads = __ballot(active && (lane == 0 || item_prev != cw.item || !((am >> (lane - 1)) & 1ull)));
+        unsigned long long base2_raw = 0;
+        int rbase_raw = 0;
+        if (lane == 0) {
+            if (km | sm) {
+                if (g.surv == nullptr)
+                    base2_raw = (unsigned)atomicAdd(g.pcount, __popcll(km));
+                else   // ONE 64-bit atomic: pcount in the low word, scount in the high word
+                    base2_raw = atomicAdd(reinterpret_cast<unsigned long long *>(g.pcount),
+                                          ((unsigned long long)__popcll(sm) << 32) | (unsigned long long)__popcll(km));
+            }
+            if (km) rbase_raw = atomicAdd(g.rcount, __popcll(heads));
+        }
         STAMP(t3);
         // ==== phase 3 (divergent): integrate_over_polygon_patch! (non_friction.jl:217-234) ============================
         double sum[10], wr1[3], wrr[6];   // wr1, wrr: first / second moments of w about the polygon centroid
@@ -502,48 +530,40 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         // ==== phase 4 (wave-uniform): per-item reductions =============================================================
         const bool contributed = work && n_trac_lane > 0;
         {
-            // ---- compacted slots for (a) the polygons of contributing bristle pairs, kept for k_fric, and (b) when
-            // pfc_eval_dual asked for it, the candidate indices of all contributing pairs.  ONE 64-bit atomic per wave
-            // reserves both (pcount in the low word, scount in the high word): a second single-address atomic per wave
-            // cost 0.6 ms on the C3 batch.
+            // ---- (a) the polygons of contributing bristle pairs, kept for k_fric, and (b) when pfc_eval_dual asked for it,
+            // the candidate indices of the contributing pairs, in the slots reserved before the integration (lanes that
+            // had a polygon but no pressure point leave an empty marker).
             const bool keep = contributed && !reg;
-            const bool list = contributed && g.surv != nullptr;
-            if (__any(keep || list)) {
-                const unsigned long long km = __ballot(keep), sm = __ballot(list);
-                unsigned long long base2 = 0;
-                if (lane == 0) {
-                    if (g.surv == nullptr)
-                        base2 = (unsigned)atomicAdd(g.pcount, __popcll(km));
-                    else
-                        base2 = atomicAdd(reinterpret_cast<unsigned long long *>(g.pcount),
-                                          ((unsigned long long)__popcll(sm) << 32) | (unsigned long long)__popcll(km));
-                }
-                const int base = __builtin_amdgcn_readfirstlane((int)(base2 & 0xFFFFFFFFull));
-                const int sbase = __builtin_amdgcn_readfirstlane((int)(base2 >> 32));
+            if (km | sm) {
+                const int base = __builtin_amdgcn_readfirstlane((int)(base2_raw & 0xFFFFFFFFull));
+                const int sbase = __builtin_amdgcn_readfirstlane((int)(base2_raw >> 32));
                 const unsigned long long below = (1ull << lane) - 1ull;
-                if (list) g.surv[sbase + __popcll(sm & below)] = idx;   // <= ccap entries
+                if (polys) g.surv[sbase + __popcll(sm & below)] = contributed ? idx : -1;   // <= ccap entries
                 const int slot = base + __popcll(km & below);
-                if (keep && slot < g.pcap) {      // pcap >= ccap: cannot overflow
+                if (polyb && slot < g.pcap) {      // pcap >= ccap: cannot overflow
                     const size_t P = (size_t)g.pcap;
                     double *o = g.poly + slot;
                     // streaming stores: 0.5 GB per C3 batch must not evict the mesh records from the XCD's 4 MiB L2
 #define NT_(p, v) __builtin_nontemporal_store((v), (p))
-                    NT_(&g.poly_item[slot], (int)((unsigned)cw.item | ((unsigned)n_poly << 28)));
-                    NT_(o, nh.x); NT_(o + P, nh.y); NT_(o + 2 * P, nh.z);
-                    NT_(o + 3 * P, cen.x); NT_(o + 4 * P, cen.y); NT_(o + 5 * P, cen.z);
-                    NT_(o + 6 * P, tp->epsr[0]); NT_(o + 7 * P, tp->epsr[1]); NT_(o + 8 * P, tp->epsr[2]);
-                    NT_(o + 9 * P, tp->epsr[3]);
-                    for (int k = 0; k < n_poly; ++k) {
-                        NT_(o + (10 + 3 * k) * P, PR(k, 0)); NT_(o + (11 + 3 * k) * P, PR(k, 1));
-                        NT_(o + (12 + 3 * k) * P, PR(k, 2));
+                    NT_(&g.poly_item[slot], keep ? (int)((unsigned)cw.item | ((unsigned)n_poly << 28)) : 0);
+                    if (keep) {
+                        NT_(o, nh.x); NT_(o + P, nh.y); NT_(o + 2 * P, nh.z);
+                        NT_(o + 3 * P, cen.x); NT_(o + 4 * P, cen.y); NT_(o + 5 * P, cen.z);
+                        NT_(o + 6 * P, tp->epsr[0]); NT_(o + 7 * P, tp->epsr[1]); NT_(o + 8 * P, tp->epsr[2]);
+                        NT_(o + 9 * P, tp->epsr[3]);
+                        for (int k = 0; k < n_poly; ++k) {
+                            NT_(o + (10 + 3 * k) * P, PR(k, 0)); NT_(o + (11 + 3 * k) * P, PR(k, 1));
+                            NT_(o + (12 + 3 * k) * P, PR(k, 2));
+                        }
                     }
 #undef NT_
                 }
             }
+            unsigned long long r1 = 0, r2 = 0, r3 = 0; (void)r1; (void)r2; (void)r3;
+            STAMP(r1);
             // ---- the ten per-item sums.  Single-item wave (the rule: an item has ~30 waves of candidates): LDS transpose;
             // otherwise segmented scans keyed by item.  The polygon ring is free from here on (its last reader was the
             // polygon store above).
-            const unsigned long long am = __ballot(active);
             const int item_first = __builtin_amdgcn_readlane(cw.item, am ? __builtin_ctzll(am) : 0);
             const bool single = __all(!active || cw.item == item_first);
             double t10 = 0.0;   // single: lane k < 10 holds total k
@@ -555,8 +575,12 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             } else {
                 accumulate_items<10>(g.acc, cw.item, active, contributed, sum, 0);
             }
+            STAMP(r2);
+            // ---- patch-stiffness moments of the bristle model, one record per run of an item in this wave, in the slots
+            // reserved before the integration (run r of the wave -> slot rbase + r; a run without a record gets W = 0)
+            const int rbase = __builtin_amdgcn_readfirstlane(rbase_raw);
+            unsigned long long rec_done = 0;   // bit r: run r has its record
             if (__any(contributed && !reg)) {
-                // ---- patch-stiffness moments of the bristle model, one record per run of an item in this wave ----
                 const bool cb = contributed && !reg;
                 const Seg sg = seg_setup(active ? cw.item : -1);
                 // the run's own pressure centroid c_w = sum w r / sum w, broadcast from the run's tail
@@ -611,14 +635,13 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         if (lane == 2) mine = cwv.x;
                         if (lane == 3) mine = cwv.y;
                         if (lane == 4) mine = cwv.z;
-                        int slot = 0;
-                        if (lane == 0) slot = atomicAdd(g.rcount, 1);
-                        slot = __builtin_amdgcn_readfirstlane(slot);
+                        const int slot = rbase;   // the wave's single run
                         if (slot < g.rcap) {
                             if (lane < kRecStride) g.rec[(size_t)slot * kRecStride + lane] = mine;
                         } else if (lane == 0) {
                             atomicOr(g.status, kStRecOvf);
                         }
+                        rec_done |= 1ull;
                     }
                 }
                 double tot[27];
@@ -646,29 +669,54 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         const double x = readlane_f64(tot[k], t);
                         if (lane == 5 + k) mine = x;
                     }
-                    int slot = 0;
-                    if (lane == 0) slot = atomicAdd(g.rcount, 1);
-                    slot = __builtin_amdgcn_readfirstlane(slot);
+                    const int run = __popcll(heads & ((2ull << t) - 1ull)) - 1;   // heads at or before the tail lane
+                    const int slot = rbase + run;
                     if (slot < g.rcap) {
                         if (lane < kRecStride) g.rec[(size_t)slot * kRecStride + lane] = mine;
                     } else if (lane == 0) {
                         atomicOr(g.status, kStRecOvf);
                     }
+                    rec_done |= 1ull << run;
                 }
             }
-            count_per_item(g.icnt, cw.item, 2, active, active && n_poly >= 3);
-            count_per_item(g.icnt, cw.item, 3, active, contributed, n_trac_lane);
+            if (km) {   // reserved but unused record slots: W = 0
+                const int n_run = __popcll(heads);
+                if (lane < n_run && !((rec_done >> lane) & 1ull) && rbase + lane < g.rcap)
+                    g.rec[(size_t)(rbase + lane) * kRecStride + 1] = 0.0;
+            }
+            STAMP(r3);
+#ifdef PFC_STAMPS
+            st_r[0] += r1 - t4; st_r[1] += r2 - r1; st_r[2] += r3 - r2;
+#endif
+            if (single) {   // one item: a popcount and one integer wave sum instead of two segmented scans
+                const int n_ne = __popcll(__ballot(has_poly));
+                int nt = contributed ? n_trac_lane : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) nt += __shfl_xor(nt, o, 64);
+                if (lane == 0 && am) {
+                    if (n_ne) atomicAdd(&g.icnt[4 * (size_t)item_first + 2], n_ne);
+                    if (nt) atomicAdd(&g.icnt[4 * (size_t)item_first + 3], nt);
+                }
+            } else {
+                count_per_item(g.icnt, cw.item, 2, active, has_poly);
+                count_per_item(g.icnt, cw.item, 3, active, contributed, n_trac_lane);
+            }
         }
 #ifdef PFC_STAMPS
         STAMP(t5);
-        if (lane == 0 && g.stamps) {
-            // t1 is only stamped when lane 0's wave entered the clip; fold gather+clip when it was not
-            if (t1 == 0) t1 = t2;
-            atomicAdd(&g.stamps[0], t1 - t0); atomicAdd(&g.stamps[1], t2 - t1); atomicAdd(&g.stamps[2], t3 - t2);
-            atomicAdd(&g.stamps[3], t4 - t3); atomicAdd(&g.stamps[4], t5 - t4); atomicAdd(&g.stamps[5], 1ull);
+        if (rd * stride + blockIdx.x * kNpBlock < n_c) {   // rounds with work; summed in registers (an atomic per round
+            if (t1 == 0) t1 = t2;                           // on one address would itself dominate the timing)
+            st_c[0] += t1 - t0; st_c[1] += t2 - t1; st_c[2] += t3 - t2; st_c[3] += t4 - t3; st_c[4] += t5 - t4; st_c[5] += 1;
         }
 #endif
     }
+#ifdef PFC_STAMPS
+    if (lane == 0 && g.stamps && st_c[5])
+    {
+        for (int k = 0; k < 6; ++k) atomicAdd(&g.stamps[k], st_c[k]);
+        atomicAdd(&g.stamps[6], st_r[0]); atomicAdd(&g.stamps[7], st_r[1]); atomicAdd(&g.stamps[14], st_r[2]);
+    }
+#endif
 }
 #undef PR
 
@@ -699,8 +747,8 @@ __global__ void __launch_bounds__(64) k_fric(FricArgs g) {
         for (int k = 0; k < 6; ++k) sum[k] = 0.0;
         int item = 0;
         bool contributed = false;
-        if (active) {
-            const unsigned pk = (unsigned)g.poly_item[idx];
+        const unsigned pk = active ? (unsigned)g.poly_item[idx] : 0u;
+        if ((pk >> 28) >= 3u) {     // 0: a reserved slot whose pair had a polygon but no pressure point
             item = (int)(pk & 0x0FFFFFFFu);
             const int n = (int)(pk >> 28);
             const ItemRec *it = g.items + item;

@@ -17,9 +17,10 @@ print("rounds", v[5], "cycles/round", tot / max(v[5], 1))
 for k, nm in enumerate(names):
     print(f"  {nm:10s} {v[k] / max(v[5], 1):10.0f} cycles/round  {100.0 * v[k] / max(tot, 1):5.1f} %")
 
+print("  reduce sub-phases (cycles/round): slot atomic + polygon store %.0f, ten sums %.0f, moments + record %.0f, counters %.0f" % (
+    v[6] / max(v[5], 1), v[7] / max(v[5], 1), v[14] / max(v[5], 1), (v[4] - v[6] - v[7] - v[14]) / max(v[5], 1)))
 it = max(v[11], 1)
-print("broadphase iterations", v[11], "lanes/iteration %.1f" % (v[12] / it))
-for k, nm in ((8, "pop+load"), (9, "SAT"), (10, "push+flush")):
-    print(f"  {nm:10s} {v[k] / it:10.0f} cycles/iteration  {100.0 * v[k] / max(v[8] + v[9] + v[10], 1):5.1f} %")
-print("undecided by the FP32 filter: %d pairs (%.4f %% of tests) in %d iterations (%.2f %%); general-path iterations %.1f %%" % (
-    v[13], 100.0 * v[13] / max(v[12], 1), v[14], 100.0 * v[14] / it, 100.0 * v[15] / it))
+print("broadphase workgroup iterations", v[11], "pairs/iteration %.1f" % (v[12] / it))
+tb = v[8] + v[9] + v[10] + v[13]
+for k, nm in ((8, "pop + node loads"), (9, "single-precision test"), (10, "ballots + barrier"), (13, "prefix + push + barrier")):
+    print(f"  {nm:24s} {v[k] / it:10.0f} cycles/iteration  {100.0 * v[k] / max(tb, 1):5.1f} %")
