@@ -690,9 +690,11 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
 #endif
             if (single) {   // one item: a popcount and one integer wave sum instead of two segmented scans
                 const int n_ne = __popcll(__ballot(has_poly));
-                int nt = contributed ? n_trac_lane : 0;
+                // traction points of the wave: a lane has at most 8 x 3 = 24, i.e. five bits -> five ballots
+                const int ntl = contributed ? n_trac_lane : 0;
+                int nt = 0;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) nt += __shfl_xor(nt, o, 64);
+                for (int b = 0; b < 5; ++b) nt += __popcll(__ballot((ntl >> b) & 1)) << b;
                 if (lane == 0 && am) {
                     if (n_ne) atomicAdd(&g.icnt[4 * (size_t)item_first + 2], n_ne);
                     if (nt) atomicAdd(&g.icnt[4 * (size_t)item_first + 3], nt);
