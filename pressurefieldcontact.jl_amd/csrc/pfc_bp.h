@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
     __shared__ int2 und_l[kDfsBlock];     // node pairs the Float32 test left undecided in the last iteration
     __shared__ int und_v[kDfsBlock];      // their exact verdicts
     __shared__ double xs[(kDfsBlock / 16) * 33];
-    __shared__ int s_seed, s_base, s_def;
+    __shared__ int s_seed, s_base, s_def[2];   // s_def: parked-pair counters, alternating by iteration parity
     __shared__ double s_pose[12];         // R_a_b (9, column-major), t_a_b (3) of the current seed's item
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n_seed = *g.n_seed;
@@ -358,14 +358,15 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
             const int sa = (it->nodes1[s.a].leaf != kInternal) ? ~s.a : s.a;
             const int sb = (it->nodes2[s.b].leaf != kInternal) ? ~s.b : s.b;
             stk[0] = make_int2(sa, sb);
-            s_def = 0;
+            s_def[0] = s_def[1] = 0;
         }
         __syncthreads();
 #ifdef PFC_STAMPS
         unsigned long long c_a = 0, c_b = 0, c_c = 0, c_d = 0, c_it = 0, c_p = 0;
 #endif
         // every workgroup must reach its exit: the iteration guard stops a corrupt (cyclic) tree from spinning forever
-        for (int guard = 0; (sp > 0 || n_def > 0) && guard < (1 << 22); ++guard) {
+        int par = 0;   // parity of the iteration: selects the parking counter
+        for (int guard = 0; (sp > 0 || n_def > 0) && guard < (1 << 22); ++guard, par ^= 1) {
             // Either settle the pairs the previous iteration left undecided (exact Float64 test; their children still
             // have the room that iteration reserved for them), or pop up to 256 pairs, but never more than the stack can
             // take back as children (4 per pair).  n_def is uniform over the workgroup.
@@ -383,7 +384,8 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
             const bool act = tid < p;
             int2 e = make_int2(0, 0);
             if (act) e = settle ? und_l[tid] : stk[sp - 1 - tid];
-            __syncthreads();
+            // no barrier here: the stack and the parking list are only written after the barrier below the test, by
+            // which every thread has done this read
             if (!settle) { sp -= p; n_test += p; } else { n_und += p; }
             int verdict = 0, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
             if (settle && act) verdict = und_v[tid];
@@ -408,7 +410,7 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
             }
             STAMP(u2);
             // an undecided pair is parked for the next iteration (verdict 2 only comes from the Float32 test)
-            if (verdict == 2) und_l[atomicAdd(&s_def, 1)] = e;
+            if (verdict == 2) und_l[atomicAdd(&s_def[par], 1)] = e;
             const bool hit = verdict == 1;
             const bool is_cand = hit && la && lb;
             const bool two = hit && (la != lb);
@@ -420,7 +422,8 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
             }
             __syncthreads();
             STAMP(u3);
-            n_def = s_def;   // read by everyone between this barrier and the next; reset after the next
+            n_def = s_def[par];                     // read by everyone between this barrier and the next
+            if (tid == 0) s_def[par ^ 1] = 0;       // the next iteration's counter: its last readers passed a barrier ago
             int c_off = 0, p_off = 0, c_tot = 0, p_tot = 0;
 #pragma unroll
             for (int w = 0; w < kDfsWaves; ++w) {
@@ -445,7 +448,6 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
             n_out += c_tot;
             sp += p_tot;
             __syncthreads();
-            if (tid == 0) s_def = 0;   // ordered before the next iteration's parking by its first barrier
             if (n_out > kDfsOut32 - kDfsBlock || (sp == 0 && n_def == 0 && n_out > 0)) {
                 flush_candidates(g, ob, n_out, item, tid, &s_base);
                 n_cand += n_out;
