@@ -236,7 +236,6 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
 // Dual polygon of every contributing bristle lane is kept for passes B and C (k_dual_poly).  TT as in k_narrow.
 template <bool TT>
 __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
-    constexpr int MODE = 0;
     __shared__ double pv[8 * 4 * 64];
     __shared__ double pd[8 * 4 * 64];
     const int lane = threadIdx.x;

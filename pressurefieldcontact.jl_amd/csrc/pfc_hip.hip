@@ -151,7 +151,7 @@ struct DevBuf {
 };
 
 struct HostMesh {
-    int n_pt = 0, n_tri = 0, n_tet = 0, n_node = 0, depth = 0;
+    int n_pt = 0, n_tri = 0, n_tet = 0, n_node = 0, n_leaf = 0, depth = 0;
     double Ebar = 0.0;
     std::vector<double> xyz, eps;
     std::vector<int> tri, tet;
@@ -697,6 +697,7 @@ int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int
             ++n_leaf;
         }
     }
+    m.n_leaf = n_leaf;
     m.depth = tree_depth(m.nodes);
     if (m.depth < 0) return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: the node array is not a tree");
     // Device encoding: a child link to a LEAF is stored as ~index (negative), so the broadphase knows from the link
@@ -828,7 +829,7 @@ int pfc_finalize(pfc_handle h) {
     for (const InsDev &in : h->ins) {
         int lv = h->meshes[in.m1].depth + h->meshes[in.m2].depth + 1;
         if (lv > h->max_levels) h->max_levels = lv;
-        const int lf = (h->meshes[in.m1].n_node + 1) / 2 + (h->meshes[in.m2].n_node + 1) / 2;
+        const int lf = h->meshes[in.m1].n_leaf + h->meshes[in.m2].n_leaf;
         if (lf > h->max_leaves) h->max_leaves = lf;
         if (in.model == PFC_BRISTLE) h->any_bristle = true;
         if (h->meshes[in.m1].n_tri == 0) h->any_tet_tet = true;
