@@ -242,6 +242,9 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pfc, w, args.cpu_seconds, 1)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            import shutil
+            # the Julia reference itself can only be timed where a Julia toolchain exists
+            out["cpu_baseline"]["julia_on_box"] = shutil.which("julia")
             # second leg: the same port over the box's CPU share for one GPU (16 cores)
             nt = max(1, min(16, os.cpu_count() or 1))
             if nt > 1:
