@@ -22,15 +22,18 @@ for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
 json.dump(raw, open(os.path.join(root, "profiles", f"{rnd}_pmc_raw.json"), "w"), indent=1)
 
 def per_launch(name):
-    return 1024.0 * (raw["FETCH_SIZE"].get(name, {}).get("per_call_KB", 0.0) + raw["WRITE_SIZE"].get(name, {}).get("per_call_KB", 0.0))
+    # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B while the L2 fills 128-byte lines, i.e. it
+    # reports half of the bytes read -> doubled; WRITE_SIZE is exact.  Both are KB.
+    return 1024.0 * (2.0 * raw["FETCH_SIZE"].get(name, {}).get("per_call_KB", 0.0) +
+                     raw["WRITE_SIZE"].get(name, {}).get("per_call_KB", 0.0))
 
 out = {"k_bp_dfs32_bytes_per_launch": per_launch("pfc::k_bp_dfs32") + per_launch("pfc::k_bp_dfs") + per_launch("pfc::k_bp_expand"),
        "k_narrow0_bytes_per_launch": per_launch("void pfc::k_narrow<false>"),
        "k_fric_bytes_per_launch": per_launch("pfc::k_fric"),
-       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB x 1024, per launch, bench.py default "
-               "workload (2048 poses); FETCH_SIZE is NOT doubled: MI355X_MICROARCH.md says it under-reports wide coalesced "
-               "streaming reads by 2x and is uncalibrated for other widths; these kernels gather 16-byte pieces of "
-               "64..256-byte records"}
+       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch of bench.py's default workload "
+               "(2048 poses as two concurrent 1024-pose halves: a launch covers one half); bytes = 1024 x (2 x FETCH_SIZE "
+               "+ WRITE_SIZE): the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies 128-byte line fills at "
+               "64 B); Infinity-Cache hits are counted, so this is memory-side traffic of the L2, an upper bound of HBM bytes"}
 json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(root, "gpurun_out", f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(root, "profiles", f"{rnd}_kernel_stats.csv"))
