@@ -219,6 +219,8 @@ struct pfc_context {
     DevBuf<double> dual_in, dual_acc, dual_res, dual_out, dual_poly;   // pfc_eval_dual
     DevBuf<int2> dual_pkey;
     DevBuf<int> dual_cnt;
+    DevBuf<double> scat_d;                                  // pfc_scatter_generalized
+    DevBuf<int> scat_i;
     DevBuf<int> surv;                                       // candidate indices of contributing pairs
     DevBuf<int> poly_item;                                  // kept polygons of bristle pairs (k_narrow -> k_fric)
     DevBuf<double> poly;
@@ -631,7 +633,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     h->tail.release();
-    h->poly_item.release(); h->poly.release(); h->surv.release();
+    h->poly_item.release(); h->poly.release(); h->surv.release(); h->scat_d.release(); h->scat_i.release();
     h->dual_poly.release(); h->dual_pkey.release(); h->dual_cnt.release();
     h->dual_in.release(); h->dual_acc.release(); h->dual_res.release(); h->dual_out.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1142,35 +1144,29 @@ int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, con
     }
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t n = (size_t)n_items, nf = (size_t)n_scene * nv, nj = (size_t)n_body * 6 * nv;
-    double *dw = nullptr, *dx = nullptr, *dj = nullptr, *df = nullptr;
-    int *db = nullptr;
-    HIP_TRY(h, hipMalloc((void **)&df, sizeof(double) * nf));
-    HIP_TRY(h, hipMemsetAsync(df, 0, sizeof(double) * nf, h->stream));
+    // work buffers of the handle (grown on demand, reused by later calls): [f | wrench | x_w_r2 | jac] and the ids
+    HIP_TRY(h, h->scat_d.ensure(nf + n * 18 + nj + 1));
+    HIP_TRY(h, h->scat_i.ensure(n * 3 + 1));
+    double *df = h->scat_d.p, *dw = df + nf, *dx = dw + n * 6, *dj = dx + n * 12;
+    int *db = h->scat_i.p;
+    hipStream_t st = h->stream;
+    HIP_TRY(h, hipMemsetAsync(df, 0, sizeof(double) * nf, st));
     if (n) {
-        HIP_TRY(h, hipMalloc((void **)&dw, sizeof(double) * n * 6));
-        HIP_TRY(h, hipMalloc((void **)&dx, sizeof(double) * n * 12));
-        HIP_TRY(h, hipMalloc((void **)&dj, sizeof(double) * (nj ? nj : 1)));
-        HIP_TRY(h, hipMalloc((void **)&db, sizeof(int) * n * 3));
-        HIP_TRY(h, hipMemcpyAsync(dw, wrench, sizeof(double) * n * 6, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(dx, x_w_r2, sizeof(double) * n * 12, hipMemcpyHostToDevice, h->stream));
-        if (nj) HIP_TRY(h, hipMemcpyAsync(dj, jac, sizeof(double) * nj, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(db, body_1, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(db + n, body_2, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
-        if (scene) HIP_TRY(h, hipMemcpyAsync(db + 2 * n, scene, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(dw, wrench, sizeof(double) * n * 6, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(dx, x_w_r2, sizeof(double) * n * 12, hipMemcpyHostToDevice, st));
+        if (nj) HIP_TRY(h, hipMemcpyAsync(dj, jac, sizeof(double) * nj, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(db, body_1, sizeof(int) * n, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(db + n, body_2, sizeof(int) * n, hipMemcpyHostToDevice, st));
+        if (scene) HIP_TRY(h, hipMemcpyAsync(db + 2 * n, scene, sizeof(int) * n, hipMemcpyHostToDevice, st));
         ScatterArgs a;
         a.n_items = n_items; a.nv = nv; a.wrench = dw; a.x_w_r2 = dx; a.body_1 = db; a.body_2 = db + n;
         a.scene = scene ? db + 2 * n : nullptr; a.jac = dj; a.f = df;
         const long long tot = (long long)n_items * nv;
-        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a);
         HIP_TRY(h, hipGetLastError());
     }
-    HIP_TRY(h, hipMemcpyAsync(f_out, df, sizeof(double) * nf, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(df);
-    if (dw) (void)hipFree(dw);
-    if (dx) (void)hipFree(dx);
-    if (dj) (void)hipFree(dj);
-    if (db) (void)hipFree(db);
+    HIP_TRY(h, hipMemcpyAsync(f_out, df, sizeof(double) * nf, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
     return PFC_OK;
 }
 
