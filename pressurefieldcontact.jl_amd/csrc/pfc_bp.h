@@ -24,6 +24,15 @@ __device__ __forceinline__ void count_per_item(int *icnt, int item, int slot, bo
     if (sg.tail && sg.valid && t != 0) atomicAdd(&icnt[4 * (size_t)item + slot], t);
 }
 
+// a whole NodeRec through the global address space (nine 16-byte global_load instead of flat_load)
+__device__ __forceinline__ NodeRec load_node(const NodeRec *n) {
+    union U { vec4i v[9]; NodeRec r; __device__ U() {} } u;
+    const gvec4i *p = (const gvec4i *)n;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) u.v[k] = p[k];
+    return u.r;
+}
+
 __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
     int n_in = g.fcount[g.level];
     if (n_in > g.fcap) n_in = g.fcap;  // the previous level overflowed (flagged there); never read past the buffer
@@ -41,8 +50,8 @@ __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
         if (active) {
             w = g.fin[idx];
             const ItemRec *it = g.items + w.item;
-            const NodeRec a = it->nodes1[w.a];
-            const NodeRec b = it->nodes2[w.b];
+            const NodeRec a = load_node(it->nodes1 + w.a);
+            const NodeRec b = load_node(it->nodes2 + w.b);
             hit = bb_bb_intersect(a, b, it->R12, it->t12);
             la = a.leaf != kInternal; lb = b.leaf != kInternal;
             ca0 = node_index(a.child0); ca1 = node_index(a.child1); cb0 = node_index(b.child0); cb1 = node_index(b.child1);
@@ -184,8 +193,8 @@ struct Dfs32Args {
 
 __device__ __forceinline__ NodeF load_nodef(const NodeF *n) {
     // four 16-byte loads of one 64-byte line
-    const int4 *p = reinterpret_cast<const int4 *>(n);
-    union { int4 v[4]; NodeF f; } u;
+    const gvec4i *p = (const gvec4i *)n;
+    union { vec4i v[4]; NodeF f; } u;
     u.v[0] = p[0]; u.v[1] = p[1]; u.v[2] = p[2]; u.v[3] = p[3];
     return u.f;
 }
@@ -244,7 +253,7 @@ __device__ __forceinline__ void exact_pairs_coop(const ItemRec *it, const double
         const bool valid = j < n_def;
         int2 e = make_int2(0, 0);
         if (valid) e = und_l[j];
-        const NodeRec *na = it->nodes1 + node_index(e.x), *nb = it->nodes2 + node_index(e.y);
+        const GNodeRec *na = (const GNodeRec *)(it->nodes1 + node_index(e.x)), *nb = (const GNodeRec *)(it->nodes2 + node_index(e.y));
         if (valid && sub < 9) {
             const int i = sub % 3, jj = sub / 3;
             const double r0 = na->R[3 * i], r1 = na->R[3 * i + 1], r2 = na->R[3 * i + 2];
@@ -355,8 +364,8 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
         int sp = 1, n_out = 0, n_test = 0, n_cand = 0, n_def = 0, n_und = 0;
         if (tid == 0) {
             // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
-            const int sa = (it->nodes1[s.a].leaf != kInternal) ? ~s.a : s.a;
-            const int sb = (it->nodes2[s.b].leaf != kInternal) ? ~s.b : s.b;
+            const int sa = (((const GNodeRec *)it->nodes1)[s.a].leaf != kInternal) ? ~s.a : s.a;
+            const int sb = (((const GNodeRec *)it->nodes2)[s.b].leaf != kInternal) ? ~s.b : s.b;
             stk[0] = make_int2(sa, sb);
             s_def[0] = s_def[1] = 0;
         }
@@ -481,13 +490,10 @@ struct NodeHead {
     int child0, child1, leaf, aabb;
 };
 __device__ __forceinline__ NodeHead load_head(const NodeRec *n) {
-    NodeHead h;
-    const double2 *p = reinterpret_cast<const double2 *>(n);
-    const double2 a = p[0], b = p[1], c = p[2];
-    const int4 l = reinterpret_cast<const int4 *>(n)[3];
-    h.c[0] = a.x; h.c[1] = a.y; h.c[2] = b.x; h.e[0] = b.y; h.e[1] = c.x; h.e[2] = c.y;
-    h.child0 = l.x; h.child1 = l.y; h.leaf = l.z; h.aabb = l.w;
-    return h;
+    union { vec4i v[4]; NodeHead h; } u;
+    const gvec4i *p = (const gvec4i *)n;
+    u.v[0] = p[0]; u.v[1] = p[1]; u.v[2] = p[2]; u.v[3] = p[3];
+    return u.h;
 }
 
 __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
@@ -510,8 +516,8 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
         int sp = 1, n_out = 0, n_test = 0, n_cand = 0;
         // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
         if (lane == 0) {
-            const int sa = (n1[s.a].leaf != kInternal) ? ~s.a : s.a;
-            const int sb = (n2[s.b].leaf != kInternal) ? ~s.b : s.b;
+            const int sa = (((const GNodeRec *)n1)[s.a].leaf != kInternal) ? ~s.a : s.a;
+            const int sb = (((const GNodeRec *)n2)[s.b].leaf != kInternal) ? ~s.b : s.b;
             stk[0] = make_int2(sa, sb);
         }
         __syncthreads();
@@ -552,11 +558,11 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
                 if (general) {
                     if (la) {
 #pragma unroll
-                        for (int k = 0; k < 9; ++k) Ra[k] = n1[ia].R[k];
+                        for (int k = 0; k < 9; ++k) Ra[k] = ((const GNodeRec *)n1)[ia].R[k];
                     }
                     if (lb) {
 #pragma unroll
-                        for (int k = 0; k < 9; ++k) Rb[k] = n2[ib].R[k];
+                        for (int k = 0; k < 9; ++k) Rb[k] = ((const GNodeRec *)n2)[ib].R[k];
                     }
                 }
             }

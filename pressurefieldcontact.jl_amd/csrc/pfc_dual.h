@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
         if (active) ci = g.surv[idx];   // -1: the pair had a polygon but did not contribute in the value pass
         if (ci >= 0) cw = g.cand[ci];
         const ItemRec *it = g.items + cw.item;
-        const TetRec *tp = it->tet + cw.b;
+        const GTetRec *tp = (const GTetRec *)(it->tet + cw.b);
         const bool reg = it->model == PFC_REGULARIZED;
         const bool live = active && ci >= 0;
         const int key = live ? cw.item * n_dir + dir : -1;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
             for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
             if (!TT || it->tet1 == nullptr) {
                 // tri-tet op (non_friction.jl:196-215)
-                const TriRec tr = it->tri[cw.a];
+                const GTriRec *tr = (const GTriRec *)(it->tri + cw.a);
                 Du X[16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -289,16 +289,16 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        z[k][i] = ((X[i] * tr.v[3 * k] + X[i + 4] * tr.v[3 * k + 1]) + X[i + 8] * tr.v[3 * k + 2]) + X[i + 12];
+                        z[k][i] = ((X[i] * tr->v[3 * k] + X[i + 4] * tr->v[3 * k + 1]) + X[i + 8] * tr->v[3 * k + 2]) + X[i + 12];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) z[3][i] = du(0.0);
                 n_in = 3;
-                nh_in = dmk((R21[0] * tr.n[0] + R21[3] * tr.n[1]) + R21[6] * tr.n[2],
-                            (R21[1] * tr.n[0] + R21[4] * tr.n[1]) + R21[7] * tr.n[2],
-                            (R21[2] * tr.n[0] + R21[5] * tr.n[1]) + R21[8] * tr.n[2]);
+                nh_in = dmk((R21[0] * tr->n[0] + R21[3] * tr->n[1]) + R21[6] * tr->n[2],
+                            (R21[1] * tr->n[0] + R21[4] * tr->n[1]) + R21[7] * tr->n[2],
+                            (R21[2] * tr->n[0] + R21[5] * tr->n[1]) + R21[8] * tr->n[2]);
             } else {
                 // tet-tet op (non_friction.jl:166-194)
-                const TetRec *t1 = it->tet1 + cw.a;
+                const GTetRec *t1 = (const GTetRec *)(it->tet1 + cw.a);
                 Du plane[4];
                 {
                     Du R12[9], t12[3], X1[16];
@@ -319,8 +319,8 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
                     double Ee1[4], Ee2[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        Ee1[j] = it->Ebar1 * it->eps1[4 * (size_t)cw.a + j];
-                        Ee2[j] = it->Ebar * it->eps2[4 * (size_t)cw.b + j];
+                        Ee1[j] = it->Ebar1 * ((const gdouble *)it->eps1)[4 * (size_t)cw.a + j];
+                        Ee2[j] = it->Ebar * ((const gdouble *)it->eps2)[4 * (size_t)cw.b + j];
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {

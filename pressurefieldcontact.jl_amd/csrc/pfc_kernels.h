@@ -72,6 +72,15 @@ struct alignas(128) TetRec {  // tetrahedron_vertices_ϵ + calc_ζ_transforms (n
 };
 static_assert(sizeof(TetRec) == 256, "TetRec layout");
 
+// A pointer read out of an ItemRec is "generic" to the compiler: it emits flat_load (counted on vmcnt AND lgkmcnt, aperture
+// check in the address path).  Hot gathers go through pointers cast to the global address space instead (global_load).
+typedef int vec4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) vec4i gvec4i;
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) TriRec GTriRec;
+typedef __attribute__((address_space(1))) TetRec GTetRec;
+typedef __attribute__((address_space(1))) NodeRec GNodeRec;
+
 struct MeshDev {
     const NodeRec *nodes;
     const NodeF *nodesf;

@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         cw.item = 0; cw.a = 0; cw.b = 0; cw.pad = 0;
         if (active) cw = g.cand[idx];
         const ItemRec *it = g.items + cw.item;
-        const TetRec *tp = it->tet + cw.b;
+        const GTetRec *tp = (const GTetRec *)(it->tet + cw.b);
         const int nq = it->nq;
         const bool reg = it->model == PFC_REGULARIZED;
         const bool materialise = active && g.debug;
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
             if (!TT || it->tet1 == nullptr) {
                 // ---- tri-tet op (non_friction.jl:196-215) -----------------------------------------------------------
-                const TriRec tr = it->tri[cw.a];
+                const GTriRec *tr = (const GTriRec *)(it->tri + cw.a);
                 // x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (:204); last row of x_r2_r1.mat is (0 0 0 1)
                 double X[16];
 #pragma unroll
@@ -175,17 +175,17 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        z[k][i] = ((X[i] * tr.v[3 * k] + X[i + 4] * tr.v[3 * k + 1]) + X[i + 8] * tr.v[3 * k + 2]) + X[i + 12];
+                        z[k][i] = ((X[i] * tr->v[3 * k] + X[i + 4] * tr->v[3 * k + 1]) + X[i + 8] * tr->v[3 * k + 2]) + X[i + 12];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) z[3][i] = 0.0;
                 n_in = 3;
                 // n̂2 = R(x_r2_r1) * n̂_r1 (:211-212)
-                nh_in = mk3((R21[0] * tr.n[0] + R21[3] * tr.n[1]) + R21[6] * tr.n[2],
-                            (R21[1] * tr.n[0] + R21[4] * tr.n[1]) + R21[7] * tr.n[2],
-                            (R21[2] * tr.n[0] + R21[5] * tr.n[1]) + R21[8] * tr.n[2]);
+                nh_in = mk3((R21[0] * tr->n[0] + R21[3] * tr->n[1]) + R21[6] * tr->n[2],
+                            (R21[1] * tr->n[0] + R21[4] * tr->n[1]) + R21[7] * tr->n[2],
+                            (R21[2] * tr->n[0] + R21[5] * tr->n[1]) + R21[8] * tr->n[2]);
             } else {
                 // ---- tet-tet op (non_friction.jl:166-194) -----------------------------------------------------------
-                const TetRec *t1 = it->tet1 + cw.a;
+                const GTetRec *t1 = (const GTetRec *)(it->tet1 + cw.a);
                 double plane[4];
                 {
                     // ϵ_plane_r2 = (Ē2 ϵ2) x_ζ2_r2 - (Ē1 ϵ1) (x_ζ1_r1 x_r1_r2)   (find_plane_tet :164, :174-177)
@@ -206,8 +206,8 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                     double Ee1[4], Ee2[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        Ee1[j] = it->Ebar1 * it->eps1[4 * (size_t)cw.a + j];
-                        Ee2[j] = it->Ebar * it->eps2[4 * (size_t)cw.b + j];
+                        Ee1[j] = it->Ebar1 * ((const gdouble *)it->eps1)[4 * (size_t)cw.a + j];
+                        Ee2[j] = it->Ebar * ((const gdouble *)it->eps2)[4 * (size_t)cw.b + j];
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
