@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpfc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 
 OK, ERR_NONFINITE, ERR_OVERFLOW, ERR_BAD_ARG, ERR_NOMEM, ERR_HIP, ERR_STATE, ERR_INVERTED_TET = range(8)
 STATUS_NAMES = {0: "PFC_OK", 1: "PFC_ERR_NONFINITE", 2: "PFC_ERR_OVERFLOW", 3: "PFC_ERR_BAD_ARG", 4: "PFC_ERR_NOMEM",
@@ -62,6 +62,7 @@ def build(force: bool = False) -> str:
     """Compile csrc/pfc_hip.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in ("pfc_hip.hip", "pfc_tree.cpp", "pfc_kernels.h", "pfc_bp.h", "pfc_np.h", "pfc_br.h", "pfc_dual.h")]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "pfc.h"))
+    srcs.append(os.path.abspath(__file__))      # the compiler flags live here
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
         cmd = [HIPCC] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0], srcs[1]]

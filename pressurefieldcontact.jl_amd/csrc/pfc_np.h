@@ -78,8 +78,9 @@ __device__ __forceinline__ void accumulate_items(double *acc, int item, bool lis
     }
 }
 
-// Sums of N per-lane values over a whole wave through LDS: lane `lane` writes column `lane` of N rows (row stride 65
-// doubles: conflict-free both ways), lanes lane0 .. lane0+N-1 then add up one row each.  N + ~130 instructions per wave
+// Sums of N per-lane values over a whole wave through LDS: lane `lane` writes column `lane` of N rows, then L
+// lanes per row add up 64/L entries each (interleaved columns) and the L partials meet in a butterfly; the row totals are
+// returned on lanes lane0 .. lane0+N-1.  N + ~130 instructions per wave
 // instead of ~30 N for N segmented DPP scans; used when all work items of the wave belong to one item (97 % of the
 // waves of the C3 batch).
 // LDS ordering inside ONE wave (the block is a single wave): the LDS unit serves a wave's instructions in order, so a
@@ -90,22 +91,34 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <int N>
+template <int N, int L>
 __device__ __forceinline__ double lds_row_sums(double *buf, const double *v, bool any, int lane, int lane0) {
+    constexpr int RS = 64 + L;   // row stride: the 32 lanes of a half-wave read 32 different banks
+    static_assert(N * L <= 64 && N * RS <= 2048 && (L == 1 || L == 2 || L == 4), "rows x lanes per row must fit the wave");
 #pragma unroll
-    for (int k = 0; k < N; ++k) buf[k * 65 + lane] = any ? v[k] : 0.0;
+    for (int k = 0; k < N; ++k) buf[k * RS + lane] = any ? v[k] : 0.0;
     wave_lds_sync();
     double t = 0.0;
-    const int row = lane - lane0;
-    if (row >= 0 && row < N) {
-        const double *r = buf + row * 65;
+    const int row = lane / L, part = lane % L;
+    if (row < N) {
+        const double *r = buf + row * RS + part;
         double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-#pragma unroll 4
-        for (int j = 0; j < 64; j += 4) { t0 += r[j]; t1 += r[j + 1]; t2 += r[j + 2]; t3 += r[j + 3]; }
+#pragma unroll
+        for (int j = 0; j < 64 / L; j += 8) {
+            const double a0 = r[L * j], a1 = r[L * (j + 1)], a2 = r[L * (j + 2)], a3 = r[L * (j + 3)];
+            const double a4 = r[L * (j + 4)], a5 = r[L * (j + 5)], a6 = r[L * (j + 6)], a7 = r[L * (j + 7)];
+            t0 += a0; t1 += a1; t2 += a2; t3 += a3;
+            t0 += a4; t1 += a5; t2 += a6; t3 += a7;
+        }
         t = (t0 + t1) + (t2 + t3);
     }
     wave_lds_sync();
-    return t;
+#pragma unroll
+    for (int m = 1; m < L; m <<= 1) t += __shfl_xor(t, m, 64);
+    // row r's total sits on lanes r L .. r L + L - 1; hand it to lane lane0 + r
+    const int dst_row = lane - lane0;
+    const double out = __shfl(t, (dst_row >= 0 && dst_row < N) ? dst_row * L : 0, 64);
+    return (dst_row >= 0 && dst_row < N) ? out : 0.0;
 }
 
 // Everything up to the per-item sums (regularized friction fused; bristle: normal wrench + patch moments).  For bristle
@@ -569,7 +582,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             double t10 = 0.0;   // single: lane k < 10 holds total k
             if (single) {
                 if (__any(contributed)) {
-                    t10 = lds_row_sums<10>(poly, sum, contributed, lane, 0);
+                    t10 = lds_row_sums<10, 4>(poly, sum, contributed, lane, 0);
                     if (lane < 10 && t10 != 0.0) unsafeAtomicAdd(&g.acc[(size_t)item_first * kAccStride + lane], t10);
                 }
             } else {
@@ -628,7 +641,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 for (int k = 0; k < 6; ++k) v[21 + k] = q[k];
                 if (single) {
                     // rows on lanes 5..31: the record is item, W, c_w, 27 moments
-                    double mine = lds_row_sums<27>(poly, v, cb, lane, 5);
+                    double mine = lds_row_sums<27, 2>(poly, v, cb, lane, 5);
                     if (Wt > 0.0) {
                         if (lane == 0) mine = (double)item_first;
                         if (lane == 1) mine = Wt;
