@@ -348,6 +348,7 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
     __shared__ double xs[(kDfsBlock / 16) * 33];
     __shared__ int s_seed, s_base, s_def[2];   // s_def: parked-pair counters, alternating by iteration parity
     __shared__ double s_pose[12];         // R_a_b (9, column-major), t_a_b (3) of the current seed's item
+    __shared__ float s_posef[12];         // R_a_b rounded to Float32 once per seed
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n_seed = *g.n_seed;
     if (n_seed > g.seed_cap) n_seed = g.seed_cap;
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
         const ItemRec *it = g.items + item;
         // the item's pose lives in LDS (broadcast reads inside the iteration) rather than in 33 registers that would
         // stay live across the call of the exact test
-        if (tid < 9) s_pose[tid] = it->R12[tid];
+        if (tid < 9) { const double r = it->R12[tid]; s_pose[tid] = r; s_posef[tid] = (float)r; }
         else if (tid < 12) s_pose[tid] = it->t12[tid - 9];
         const NodeF *n1 = it->nf1, *n2 = it->nf2;
         int sp = 1, n_out = 0, n_test = 0, n_cand = 0, n_def = 0, n_und = 0;
@@ -411,7 +412,7 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
                     double R12[9], t12[3];
                     float R12f[9];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) { R12[k] = s_pose[k]; R12f[k] = (float)R12[k]; }
+                    for (int k = 0; k < 9; ++k) { R12[k] = s_pose[k]; R12f[k] = s_posef[k]; }
 #pragma unroll
                     for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
                     verdict = test_pair_f32(a, b, la || lb, R12, R12f, t12);
