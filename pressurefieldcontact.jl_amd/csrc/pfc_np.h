@@ -503,12 +503,14 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         V3 vt = vec_sub_vec_proj(rdot, nh);
                         double m2 = dot(vt, vt);
                         V3 T;
+                        // one division per point where the reference divides the three components (friction.jl:64-68):
+                        // last-bit differences only
                         if (m2 < v_c * v_c) {
-                            T = (vt * (-mu_s)) / v_c;
+                            T = vt * (-(mu_s / v_c));
                         } else {
-                            double mg = __builtin_sqrt(m2);
-                            double mu = clamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
-                            T = (vt * (-mu)) / mg;
+                            const double mg = __builtin_sqrt(m2);
+                            const double mu = clamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
+                            T = vt * (-(mu / mg));
                         }
                         const V3 tk = nh * p_dA + T * p_dA;
                         const V3 ta = cross(r, tk);
@@ -775,6 +777,7 @@ __global__ void __launch_bounds__(64) k_fric(FricArgs g) {
             const V3 w = ld3(it->w), vl = ld3(it->v);
             const double chi = it->chi, Ebar = it->Ebar, mu_s = it->mu_s, mu_d = it->mu_d;
             const double tau = it->tau, k_bar = it->k_bar;
+            const double mu_slope = (mu_d - mu_s) / (3 * mu_s - 2 * mu_s);   // clamped_piecewise(x, 2 mu_s, 3 mu_s, mu_s, mu_d)
             const double *res = g.res + (size_t)item * kResStride;
             const V3 cop = ld3(res + kResCop), Da = ld3(res + kResDelta), Dl = ld3(res + kResDelta + 3);
             V3 v2 = mk3(o[(10 + 3 * (n - 1)) * P], o[(11 + 3 * (n - 1)) * P], o[(12 + 3 * (n - 1)) * P]);
@@ -814,9 +817,12 @@ __global__ void __launch_bounds__(64) k_fric(FricArgs g) {
                     if (m2 < mu_s * mu_s) {
                         T = Ts;
                     } else {
+                        // mu / |T| as ONE division (the reference divides the three components: friction.jl:44-46; this
+                        // differs in the last bit only), the slope of the clamp once per item
                         const double mg = __builtin_sqrt(m2);
-                        const double mu = clamped_piecewise(mg, 2 * mu_s, 3 * mu_s, mu_s, mu_d);
-                        T = (Ts * mu) / mg;
+                        const double y = mu_s + (mg - 2 * mu_s) * mu_slope;
+                        const double mu = (y > mu_s) ? mu_s : ((y < mu_d) ? mu_d : y);
+                        T = Ts * (mu / mg);
                     }
                     const V3 Tc = T * p_dA;
                     const V3 ta = cross(x, Tc);
