@@ -6,6 +6,8 @@
 // =================================================================================================================
 struct BrArgs {
     int *ctr;            // counter block, packed into tail and zeroed by k_final
+    int *rgn;            // region counters of the polygon / record lists: summed into tail[12 + i_pcount], tail[12 + 3], zeroed
+    int i_pcount;
     int n_ctr;
     unsigned *status;
     int *tail;
@@ -28,20 +30,21 @@ struct BrArgs {
 // One lane computes one record, the block transposes through LDS so that each record leaves as ONE 27-lane atomic.
 struct ShiftArgs {
     const double *rec;
-    const int *rcount;
-    int rcap;
+    const int *rgn;      // region counters (word 1: moment records)
+    int rr_cap;          // record slots per region
     double *acc;
 };
 __global__ void __launch_bounds__(64) k_shift(ShiftArgs g) {
     __shared__ double out[64 * 28];
     __shared__ int items[64];
-    int n_r = *g.rcount;
-    if (n_r > g.rcap) n_r = g.rcap;
     const int lane = threadIdx.x;
-    for (int base = blockIdx.x * 64; base < n_r; base += gridDim.x * 64) {
-        const int i = base + lane;
+    const RgnScan rs = rgn_scan(g.rgn, 1, g.rr_cap, lane);
+    for (int w = blockIdx.x; w < rs.total; w += gridDim.x) {
+        int slot0, n_here;
+        rgn_locate(rs, w, g.rr_cap, slot0, n_here);
+        const int i = slot0 + lane;
         items[lane] = -1;
-        if (i < n_r && g.rec[(size_t)i * kRecStride + 1] > 0.0) {   // W = 0: a reserved slot that was not needed
+        if (lane < n_here && g.rec[(size_t)i * kRecStride + 1] > 0.0) {   // W = 0: a reserved slot that was not needed
             const double *r = g.rec + (size_t)i * kRecStride;
             const int item = (int)r[0];
             const double W = r[1];
@@ -89,7 +92,6 @@ __global__ void __launch_bounds__(64) k_shift(ShiftArgs g) {
             items[lane] = item;
         }
         __syncthreads();
-        const int n_here = (n_r - base < 64) ? (n_r - base) : 64;
         for (int q = 0; q < n_here; ++q) {
             if (lane < 27 && items[q] >= 0) {
                 const double x = out[q * 28 + lane];
@@ -296,6 +298,17 @@ __global__ void __launch_bounds__(128) k_final(BrArgs g) {
     if (threadIdx.x < 3) reinterpret_cast<unsigned long long *>(tail + 4)[threadIdx.x] = tot[threadIdx.x];
     if (threadIdx.x == 3) reinterpret_cast<unsigned long long *>(tail + 4)[3] = 0ull;
     for (int k = threadIdx.x; k < g.n_ctr; k += blockDim.x) { tail[12 + k] = g.ctr[k]; g.ctr[k] = 0; }
+    // region counters -> totals (the host sizes the record list by them)
+    __shared__ int rtot[2];
+    if (threadIdx.x < 2) rtot[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x < kRgn) {
+        int *c = g.rgn + threadIdx.x * kRgnStride;
+        atomicAdd(&rtot[0], c[0]); atomicAdd(&rtot[1], c[1]);
+        c[0] = 0; c[1] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { tail[12 + g.i_pcount] = rtot[0]; tail[12 + 3] = rtot[1]; }
 }
 
 // addGeneralizedForcesThirdLaw! (non_friction.jl:267-286): per item, the wrench on body 2 (frame r2) goes to the

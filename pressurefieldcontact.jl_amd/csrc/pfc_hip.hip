@@ -222,6 +222,7 @@ struct pfc_context {
     DevBuf<double> scat_d;                                  // pfc_scatter_generalized
     DevBuf<int> scat_i;
     DevBuf<int> surv;                                       // candidate indices of contributing pairs
+    DevBuf<int> rgn;                                        // region counters of the polygon / record lists
     DevBuf<int> poly_item;                                  // kept polygons of bristle pairs (k_narrow -> k_fric)
     DevBuf<double> poly;
     long long last_undecided = 0;      // node pairs the Float32 broadphase settled with the exact Float64 test
@@ -284,6 +285,11 @@ int grid_for(size_t n, int block, int max_blocks) {
     return (int)b;
 }
 
+// Kept-polygon slots: kRgn regions, each able to hold every candidate its workgroups can see (workgroup b of the
+// narrowphase appends to region b % kRgn and reads candidates b*64 + round*stride): (ccap + stride) / kRgn per region.
+constexpr int kNpMaxBlocks = 256 * 16;
+size_t poly_cap(size_t ccap) { return ccap + (size_t)grid_for(ccap, 64, kNpMaxBlocks) * 64; }
+
 hipError_t ensure_work(pfc_context *h, int n_items) {
     hipError_t e;
     const size_t caps0[] = {h->items.cap, h->acc.cap, h->res.cap, h->icnt.cap, h->ctr.cap, h->frontier[0].cap,
@@ -299,6 +305,9 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
         if ((e = h->status.ensure(4)) != hipSuccess) return e;
         if (h->ctr.cap != c0 && (e = hipMemset(h->ctr.p, 0, sizeof(int) * h->ctr.cap)) != hipSuccess) return e;
         if (h->status.cap != s0 && (e = hipMemset(h->status.p, 0, sizeof(unsigned) * h->status.cap)) != hipSuccess) return e;
+        const size_t r0 = h->rgn.cap;
+        if ((e = h->rgn.ensure((size_t)kRgn * kRgnStride)) != hipSuccess) return e;
+        if (h->rgn.cap != r0 && (e = hipMemset(h->rgn.p, 0, sizeof(int) * h->rgn.cap)) != hipSuccess) return e;
     }
     if ((e = h->stamps.ensure(16)) != hipSuccess) return e;
     size_t f = h->fcap ? h->fcap : 1u << 16;
@@ -316,8 +325,9 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     if ((e = h->clip_n.ensure(c)) != hipSuccess) return e;
     if ((e = h->surv.ensure(c)) != hipSuccess) return e;
     if (h->any_bristle) {
-        if ((e = h->poly_item.ensure(c)) != hipSuccess) return e;
-        if ((e = h->poly.ensure(c * 34)) != hipSuccess) return e;
+        const size_t pc = poly_cap(c);
+        if ((e = h->poly_item.ensure(pc)) != hipSuccess) return e;
+        if ((e = h->poly.ensure(pc * 34)) != hipSuccess) return e;
     }
     if ((e = h->trac_item.ensure(t)) != hipSuccess) return e;
     if ((e = h->trac_d.ensure(t * 8)) != hipSuccess) return e;
@@ -370,7 +380,7 @@ int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
 int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
                 const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st, bool prof) {
     const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
-    int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2, *rcount = h->ctr.p + 3;
+    int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2;   // ctr[3]: total records, filled by k_final
     int *ucount = h->ctr.p + 4, *fcount = h->ctr.p + 6;
     int *pcount = h->ctr.p + ((levels + 9) & ~1);   // after the per-level frontier counts; 8-byte aligned pair
     // counters and status are zero here: k_final of the previous evaluation (or ensure_work after an allocation) left them so
@@ -427,10 +437,10 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     np.icnt = h->icnt.p; np.clip_n = h->opt_debug ? h->clip_n.p : nullptr; np.trac = trac_view(h);
     np.tcount = tcount; np.tcap = (int)h->tcap; np.status = h->status.p; np.debug = h->opt_debug;
     np.stamps = h->stamps.p;
-    np.rec = h->rec.p; np.rcount = rcount; np.rcap = (int)h->rcap;
-    np.poly_item = h->poly_item.p; np.poly = h->poly.p; np.pcount = pcount; np.pcap = (int)h->ccap;
+    np.rec = h->rec.p; np.rgn = h->rgn.p; np.rr_cap = (int)(h->rcap / kRgn);
+    np.poly_item = h->poly_item.p; np.poly = h->poly.p; np.pcap = (int)poly_cap(h->ccap); np.rp_cap = np.pcap / kRgn;
     np.surv = h->want_surv ? h->surv.p : nullptr; np.scount = pcount + 1;
-    const int np_grid = grid_for(h->ccap, kNpBlock, 256 * 16);
+    const int np_grid = grid_for(h->ccap, kNpBlock, kNpMaxBlocks);
     if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
     else hipLaunchKernelGGL((k_narrow<false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_NP], st));
@@ -440,14 +450,15 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     br.trac = trac_view(h); br.tcount = tcount; br.tcap = (int)h->tcap; br.wrench = d_wrench; br.sdot = d_sdot;
     br.counts = d_counts;
     br.ctr = h->ctr.p; br.n_ctr = levels + 12; br.status = h->status.p; br.tail = h->tail.p;
+    br.rgn = h->rgn.p; br.i_pcount = (levels + 9) & ~1;
     if (h->any_bristle) {
         ShiftArgs sh;
-        sh.rec = h->rec.p; sh.rcount = rcount; sh.rcap = (int)h->rcap; sh.acc = h->acc.p;
+        sh.rec = h->rec.p; sh.rgn = h->rgn.p; sh.rr_cap = (int)(h->rcap / kRgn); sh.acc = h->acc.p;
         hipLaunchKernelGGL(k_shift, dim3(grid_for(h->rcap, 64, 2048)), dim3(64), 0, st, sh);
         hipLaunchKernelGGL(k_eig, dim3(n_items), dim3(64), 0, st, br);   // one wave per item
         FricArgs fr;
-        fr.items = h->items.p; fr.poly_item = h->poly_item.p; fr.poly = h->poly.p; fr.pcount = pcount;
-        fr.pcap = (int)h->ccap; fr.res = h->res.p; fr.acc = h->acc.p;
+        fr.items = h->items.p; fr.poly_item = h->poly_item.p; fr.poly = h->poly.p; fr.rgn = h->rgn.p;
+        fr.pcap = np.pcap; fr.rp_cap = np.rp_cap; fr.res = h->res.p; fr.acc = h->acc.p;
         hipLaunchKernelGGL(k_fric, dim3(grid_for(h->ccap, 64, 256 * 16)), dim3(64), 0, st, fr);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BR], st));
@@ -538,6 +549,7 @@ int check_one(pfc_context *h) {
                     status, h->fcap, h->ccap, h->tcap, h->rcap);
     }
     if (status & kStAbort) return fail(h, PFC_ERR_STATE, "broadphase aborted: iteration guard hit (corrupt tree?)");
+    if (status & kStPolyOvf) return fail(h, PFC_ERR_STATE, "internal error: a kept-polygon region overflowed");
     if (status & kStNonFinite) return fail(h, PFC_ERR_NONFINITE, "Non-finite vertex likely");
     h->stats[0] = (long long)tot[0]; h->stats[2] = (long long)tot[1]; h->stats[3] = (long long)tot[2];
     return PFC_OK;
@@ -633,7 +645,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     h->tail.release();
-    h->poly_item.release(); h->poly.release(); h->surv.release(); h->scat_d.release(); h->scat_i.release();
+    h->rgn.release(); h->poly_item.release(); h->poly.release(); h->surv.release(); h->scat_d.release(); h->scat_i.release();
     h->dual_poly.release(); h->dual_pkey.release(); h->dual_cnt.release();
     h->dual_in.release(); h->dual_acc.release(); h->dual_res.release(); h->dual_out.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);

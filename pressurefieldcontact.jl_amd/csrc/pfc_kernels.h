@@ -21,6 +21,7 @@ enum : unsigned {
     kStBadIns = 16u,
     kStAbort = 32u,
     kStRecOvf = 64u,
+    kStPolyOvf = 128u,   // a kept-polygon region ran full (sized so that it cannot: an internal error)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -536,6 +537,39 @@ __device__ __forceinline__ int seg_incl_scan(int v) {
     t = dpp_move<0x142, 0xA>(v); v += (lane & 16) ? t : 0;
     t = dpp_move<0x143, 0xC>(v); v += (lane >= 32) ? t : 0;
     return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Region-partitioned append lists.  k_narrow appends kept polygons and moment records once per wave round; with ONE
+// counter that is 60 k returning atomics on a single address per C3 batch, which the L2 serves serially (~11 ns each):
+// 0.21 ms of a 0.85 ms kernel.  The lists are therefore cut into kRgn regions with a counter each, on separate 128-byte
+// lines (word 0: polygons, word 1: records, reserved together by one 64-bit atomic); workgroup b appends to region
+// b % kRgn, region c owns slots [c cap, (c + 1) cap).  A consumer maps its flat wave index onto (region, offset) with
+// a scan of the per-region wave counts held one region per lane.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kRgn = 64;
+constexpr int kRgnStride = 32;   // ints between two regions' counters
+struct RgnScan { int cnt, excl, total; };   // lane c: live slots of region c, waves before region c; total waves (uniform)
+__device__ __forceinline__ RgnScan rgn_scan(const int *rgn, int word, int cap, int lane) {
+    RgnScan r;
+    r.cnt = rgn[lane * kRgnStride + word];
+    if (r.cnt > cap) r.cnt = cap;
+    const int nw = (r.cnt + 63) >> 6;
+    int incl = nw;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    r.excl = incl - nw;
+    r.total = __builtin_amdgcn_readlane(incl, 63);
+    return r;
+}
+// wave w (uniform, < total) of the pass: first slot and number of live slots (1..64)
+__device__ __forceinline__ void rgn_locate(const RgnScan &r, int w, int cap, int &slot0, int &n_live) {
+    const unsigned long long m = __ballot(r.excl <= w);          // lane 0 always qualifies
+    const int c = 63 - __builtin_clzll(m);                       // the last region that starts at or before w
+    const int start = __shfl(r.excl, c, 64), cnt = __shfl(r.cnt, c, 64);
+    const int off = (w - start) * 64;
+    slot0 = c * cap + off;
+    n_live = cnt - off < 64 ? cnt - off : 64;
 }
 template <class T>
 __device__ __forceinline__ T seg_sum(T v, const Seg &s) {

@@ -16,15 +16,15 @@ struct NpArgs {
     int ccap;
     double *acc;
     double *rec;       // moment records (bristle)
-    int *rcount;
-    int rcap;
+    int *rgn;        // region counters of the kept-polygon and record lists (kRgn x kRgnStride ints)
+    int rr_cap;      // record slots per region
     int *icnt;
     int *clip_n;     // per candidate, or null
     // clipped polygons of bristle items, kept for the friction pass (k_fric): SoA [field][slot], slot < pcap
     int *poly_item;  // item | n_poly << 28
     double *poly;    // 34 fields: n̂ 3, centroid 3, ϵ_r² 4, vertices 8 x 3 (frame r²)
-    int *pcount;
-    int pcap;
+    int rp_cap;      // polygon slots per region
+    int pcap;        // kRgn * rp_cap: the SoA stride of the polygon fields
     int *surv;       // candidate indices of the pairs that contributed traction points (work list of the Dual passes)
     int *scount;
     TracSoA trac;
@@ -403,17 +403,15 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         const int item_prev = __shfl_up(cw.item, 1, 64);
         const unsigned long long am = __ballot(active);
         const unsigned long long heads = __ballot(active && (lane == 0 || item_prev != cw.item || !((am >> (lane - 1)) & 1ull)));
-        unsigned long long base2_raw = 0;
-        int rbase_raw = 0;
+        unsigned long long base2_raw = 0;   // low word: polygon offset in the region, high word: record offset
+        int sbase_raw = 0;
+        const int rgn_c = blockIdx.x & (kRgn - 1);
         if (lane == 0) {
-            if (km | sm) {
-                if (g.surv == nullptr)
-                    base2_raw = (unsigned)atomicAdd(g.pcount, __popcll(km));
-                else   // ONE 64-bit atomic: pcount in the low word, scount in the high word
-                    base2_raw = atomicAdd(reinterpret_cast<unsigned long long *>(g.pcount),
-                                          ((unsigned long long)__popcll(sm) << 32) | (unsigned long long)__popcll(km));
-            }
-            if (km) rbase_raw = atomicAdd(g.rcount, __popcll(heads));
+            // ONE 64-bit atomic on the region's own cache line reserves the polygon slots and the record slots
+            if (km)
+                base2_raw = atomicAdd(reinterpret_cast<unsigned long long *>(g.rgn + rgn_c * kRgnStride),
+                                      ((unsigned long long)__popcll(heads) << 32) | (unsigned long long)__popcll(km));
+            if (sm) sbase_raw = atomicAdd(g.scount, __popcll(sm));   // Dual evaluations only
         }
         STAMP(t3);
         // ==== phase 3 (divergent): integrate_over_polygon_patch! (non_friction.jl:217-234) ============================
@@ -551,11 +549,14 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             const bool keep = contributed && !reg;
             if (km | sm) {
                 const int base = __builtin_amdgcn_readfirstlane((int)(base2_raw & 0xFFFFFFFFull));
-                const int sbase = __builtin_amdgcn_readfirstlane((int)(base2_raw >> 32));
+                const int sbase = __builtin_amdgcn_readfirstlane(sbase_raw);
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (polys) g.surv[sbase + __popcll(sm & below)] = contributed ? idx : -1;   // <= ccap entries
-                const int slot = base + __popcll(km & below);
-                if (polyb && slot < g.pcap) {      // pcap >= ccap: cannot overflow
+                // a region holds every candidate its workgroups can see (rp_cap = (ccap + grid stride) / kRgn)
+                const bool fits = base + __popcll(km) <= g.rp_cap;
+                if (!fits && lane == 0) atomicOr(g.status, kStPolyOvf);
+                const int slot = rgn_c * g.rp_cap + base + __popcll(km & below);
+                if (polyb && fits) {
                     const size_t P = (size_t)g.pcap;
                     double *o = g.poly + slot;
                     // streaming stores: 0.5 GB per C3 batch must not evict the mesh records from the XCD's 4 MiB L2
@@ -593,7 +594,8 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             STAMP(r2);
             // ---- patch-stiffness moments of the bristle model, one record per run of an item in this wave, in the slots
             // reserved before the integration (run r of the wave -> slot rbase + r; a run without a record gets W = 0)
-            const int rbase = __builtin_amdgcn_readfirstlane(rbase_raw);
+            const int rbase = __builtin_amdgcn_readfirstlane((int)(base2_raw >> 32));   // offset in the region
+            const int rslot0 = rgn_c * g.rr_cap;
             unsigned long long rec_done = 0;   // bit r: run r has its record
             if (__any(contributed && !reg)) {
                 const bool cb = contributed && !reg;
@@ -650,9 +652,8 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         if (lane == 2) mine = cwv.x;
                         if (lane == 3) mine = cwv.y;
                         if (lane == 4) mine = cwv.z;
-                        const int slot = rbase;   // the wave's single run
-                        if (slot < g.rcap) {
-                            if (lane < kRecStride) g.rec[(size_t)slot * kRecStride + lane] = mine;
+                        if (rbase < g.rr_cap) {   // the wave's single run
+                            if (lane < kRecStride) g.rec[(size_t)(rslot0 + rbase) * kRecStride + lane] = mine;
                         } else if (lane == 0) {
                             atomicOr(g.status, kStRecOvf);
                         }
@@ -685,9 +686,8 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         if (lane == 5 + k) mine = x;
                     }
                     const int run = __popcll(heads & ((2ull << t) - 1ull)) - 1;   // heads at or before the tail lane
-                    const int slot = rbase + run;
-                    if (slot < g.rcap) {
-                        if (lane < kRecStride) g.rec[(size_t)slot * kRecStride + lane] = mine;
+                    if (rbase + run < g.rr_cap) {
+                        if (lane < kRecStride) g.rec[(size_t)(rslot0 + rbase + run) * kRecStride + lane] = mine;
                     } else if (lane == 0) {
                         atomicOr(g.status, kStRecOvf);
                     }
@@ -696,8 +696,8 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             }
             if (km) {   // reserved but unused record slots: W = 0
                 const int n_run = __popcll(heads);
-                if (lane < n_run && !((rec_done >> lane) & 1ull) && rbase + lane < g.rcap)
-                    g.rec[(size_t)(rbase + lane) * kRecStride + 1] = 0.0;
+                if (lane < n_run && !((rec_done >> lane) & 1ull) && rbase + lane < g.rr_cap)
+                    g.rec[(size_t)(rslot0 + rbase + lane) * kRecStride + 1] = 0.0;
             }
             STAMP(r3);
 #ifdef PFC_STAMPS
@@ -744,21 +744,20 @@ struct FricArgs {
     const ItemRec *items;
     const int *poly_item;
     const double *poly;
-    const int *pcount;
-    int pcap;
+    const int *rgn;      // region counters (word 0: kept polygons)
+    int rp_cap, pcap;    // slots per region, kRgn * rp_cap
     const double *res;
     double *acc;
 };
 __global__ void __launch_bounds__(64) k_fric(FricArgs g) {
     const int lane = threadIdx.x;
-    int n_p = *g.pcount;
-    if (n_p > g.pcap) n_p = g.pcap;
     const size_t P = (size_t)g.pcap;
-    const int stride = gridDim.x * 64;
-    const int n_round = (n_p + stride - 1) / stride;
-    for (int rd = 0; rd < n_round; ++rd) {
-        const int idx = rd * stride + blockIdx.x * 64 + lane;
-        const bool active = idx < n_p;
+    const RgnScan rs = rgn_scan(g.rgn, 0, g.rp_cap, lane);
+    for (int w = blockIdx.x; w < rs.total; w += gridDim.x) {
+        int slot0, n_live;
+        rgn_locate(rs, w, g.rp_cap, slot0, n_live);
+        const int idx = slot0 + lane;
+        const bool active = lane < n_live;
         double sum[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) sum[k] = 0.0;
