@@ -35,6 +35,13 @@ struct NpArgs {
     unsigned long long *stamps;  // diagnostic builds: [0..5] cycles in gather / clip / reserve / integrate / reduce, rounds
 };
 
+// Elimination builds (diagnostic, scripts/elimination.sh): -DPFC_EXP=n compiles one phase of k_narrow out behind a
+// condition the compiler cannot fold, so that timing the variants against each other gives the phase costs including
+// their overlap (results are wrong in these builds).  3: every candidate rejected after the gather; 4: polygons dropped
+// after the clip; 9: slots reserved, no polygon set-up; 7: no quadrature points; 5: nothing after the integration.
+#ifndef PFC_EXP
+#define PFC_EXP 0
+#endif
 constexpr int kNpBlock = 64;  // one wave per block: 16 KiB of LDS polygon staging per wave
 
 // weightPoly (src/math_kernel/utility.jl:21-26) on 4-vectors held in LDS slots
@@ -299,6 +306,9 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0) && (n_in < 4 || z[3][i] <= 0.0);
+#if PFC_EXP == 3
+            reject |= z[0][0] > -1e300;
+#endif
             if (!reject) {
                 STAMP(t1);
                 // ---- clip_in_tet_coordinates (static_clip.jl:7-23,34-201), polygon ring in LDS, clipped in place ---
@@ -369,6 +379,9 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 }
                 if (err) atomicOr(g.status, kStNonFinite);
                 n_poly = n;
+#if PFC_EXP == 4
+                if (nh_in.x > -1e300) n_poly = 0;
+#endif
                 if (n >= 3) nh = nh_in;
             }
         }
@@ -423,7 +436,11 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         wr1[0] = wr1[1] = wr1[2] = 0.0;
         V3 cen = mk3(0.0, 0.0, 0.0);
         int n_trac_lane = 0;
+#if PFC_EXP == 9
+        if (n_poly >= 3 && nh.x > 1e300) {
+#else
         if (n_poly >= 3) {
+#endif
             const int n = n_poly;
             // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98), converted in place (x, y, z)
             {
@@ -464,7 +481,11 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 V3 v1 = v2;
                 v2 = mk3(PR(k, 0), PR(k, 1), PR(k, 2));
                 double area = triangle_area(v1, v2, cen, nh);
+#if PFC_EXP == 7
+                if (!(0.0 < area) || area < 1e300) continue;
+#else
                 if (!(0.0 < area)) continue;  // :232
+#endif
                 for (int q = 0; q < nq; ++q) {
                     // TriTetQuadRule rules 1 and 2, literal decimals of src/clip/quadrature.jl:24-39
                     double q0, q1, q2, qw;
@@ -541,7 +562,11 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         }
         STAMP(t4);
         // ==== phase 4 (wave-uniform): per-item reductions =============================================================
+#if PFC_EXP == 5
+        const bool contributed = work && n_trac_lane > 0 && sum[6] > 1e300;
+#else
         const bool contributed = work && n_trac_lane > 0;
+#endif
         {
             // ---- (a) the polygons of contributing bristle pairs, kept for k_fric, and (b) when pfc_eval_dual asked for it,
             // the candidate indices of the contributing pairs, in the slots reserved before the integration (lanes that

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Elimination builds of k_narrow (see the PFC_EXP note in csrc/pfc_np.h): build the variants HERE (no GPU needed),
+# then time them on the GPU box; the product library is restored at the end.
+#   bash scripts/elimination.sh build                      -> csrc/exp/e{0,3,4,9,7,5}.so
+#   gpurun -- 'bash scripts/elimination.sh run'            -> gpurun_out/elim.txt (unsplit narrowphase ms per variant)
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+C=$R/pressurefieldcontact.jl_amd/csrc
+V="0 3 4 9 7 5"
+if [ "$1" = build ]; then
+  mkdir -p $C/exp
+  for e in $V; do
+    (cd $C && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DPFC_EXP=$e -o exp/e$e.so pfc_hip.hip pfc_tree.cpp) &
+  done
+  wait; ls -la $C/exp
+else
+  mkdir -p $R/gpurun_out; : > $R/gpurun_out/elim.txt
+  cp $C/libpfc_hip.so $C/exp/product.so
+  for e in $V; do
+    cp $C/exp/e$e.so $C/libpfc_hip.so
+    (cd $R && timeout -k 10 120 python bench.py --cpu-seconds 0 --split-min 0 --steps 5 > gpurun_out/elim_$e.json) || { cp $C/exp/product.so $C/libpfc_hip.so; exit 1; }
+    python3 -c "import json; j=json.load(open('$R/gpurun_out/elim_$e.json')); print('PFC_EXP=$e  step %.3f ms  narrowphase %.3f ms' % (j['ms_per_step'], j['stage_ms_per_step']['narrowphase']))" >> $R/gpurun_out/elim.txt
+  done
+  cp $C/exp/product.so $C/libpfc_hip.so
+  cat $R/gpurun_out/elim.txt
+fi
