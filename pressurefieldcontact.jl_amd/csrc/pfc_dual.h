@@ -98,7 +98,6 @@ struct DualArgs {
     // SoA [field][slot], 64 fields: n̂ (3 values, 3 partials), centroid (3, 3), ϵ_r² (4), 8 vertices x (3, 3)
     double *dpoly;
     int2 *dpoly_key;         // (item * n_dir + dir, n_poly)
-    int *dpcount;
     long long dpcap;
 };
 constexpr int kDpFields = 64;
@@ -505,16 +504,15 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
             cen_keep = cen;
 #undef PVT
         }
-        // ---- keep the Dual polygon of contributing bristle lanes (compacted slots, coalesced SoA stores) -------------
+        // ---- keep the Dual polygon of contributing bristle lanes.  The work list of this pass holds contributing pairs
+        // only, so nearly every lane keeps its polygon: a wave owns the 64 slots grp * 64 + lane (coalesced SoA stores)
+        // and lanes without a polygon leave a marker -- no slot counter, hence no returning atomic per wave.
         {
             const bool keep = work && n_trac_lane > 0 && !reg;
-            const unsigned long long km = __ballot(keep);
-            if (km) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(g.dpcount, __popcll(km));
-                base = __builtin_amdgcn_readfirstlane(base);
-                const long long slot = (long long)base + __popcll(km & ((1ull << lane) - 1ull));
-                if (keep && slot < g.dpcap) {     // dpcap >= non-empty pairs x n_dir: cannot overflow
+            const long long slot = (long long)grp * 64 + lane;
+            if (slot < g.dpcap) {
+                if (!keep) g.dpoly_key[slot] = make_int2(-1, 0);
+                if (keep) {     // dpcap >= 64 x groups of the contributing pairs: cannot overflow
                     const size_t P = (size_t)g.dpcap;
                     double *o = g.dpoly + slot;
                     g.dpoly_key[slot] = make_int2(key, n_poly);
@@ -545,7 +543,11 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
 template <int MODE>
 __global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
     const int lane = threadIdx.x;
-    long long n_p = *g.dpcount;
+    // the slots k_narrow_dual owns: 64 per group of 64 / n_dir contributing pairs (markers where no polygon was kept)
+    int n_c = *g.scount;
+    if (n_c > g.ccap) n_c = g.ccap;
+    const int cpw = 64 / g.n_dir;
+    long long n_p = (long long)((n_c + cpw - 1) / cpw) * 64;
     if (n_p > g.dpcap) n_p = g.dpcap;
     const size_t P = (size_t)g.dpcap;
     const long long stride = (long long)gridDim.x * 64;
@@ -557,8 +559,9 @@ __global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) sum[k] = du(0.0);
         int key = -1, n_trac = 0;
-        if (active) {
-            const int2 kn = g.dpoly_key[idx];
+        int2 kn = make_int2(-1, 0);
+        if (active) kn = g.dpoly_key[idx];
+        if (kn.x >= 0) {
             key = kn.x;
             const int n = kn.y;
             const ItemRec *it = g.items + key / g.n_dir;
@@ -587,7 +590,7 @@ __global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
         double flat[2 * NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) { flat[k] = sum[k].v; flat[NS + k] = sum[k].d; }
-        accumulate_items<2 * NS>(g.dacc, key, active, n_trac > 0, flat, MODE == 1 ? kDaB : kDaC, kDaStride);
+        accumulate_items<2 * NS>(g.dacc, key, key >= 0, n_trac > 0, flat, MODE == 1 ? kDaB : kDaC, kDaStride);
     }
 }
 

@@ -218,7 +218,6 @@ struct pfc_context {
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     DevBuf<double> dual_in, dual_acc, dual_res, dual_out, dual_poly;   // pfc_eval_dual
     DevBuf<int2> dual_pkey;
-    DevBuf<int> dual_cnt;
     DevBuf<double> scat_d;                                  // pfc_scatter_generalized
     DevBuf<int> scat_i;
     DevBuf<int> surv;                                       // candidate indices of contributing pairs
@@ -646,7 +645,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     h->tail.release();
     h->rgn.release(); h->poly_item.release(); h->poly.release(); h->surv.release(); h->scat_d.release(); h->scat_i.release();
-    h->dual_poly.release(); h->dual_pkey.release(); h->dual_cnt.release();
+    h->dual_poly.release(); h->dual_pkey.release();
     h->dual_in.release(); h->dual_acc.release(); h->dual_res.release(); h->dual_out.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1011,13 +1010,11 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     const int grid = grid_for((n_cand + cpw - 1) / cpw, 1, 256 * 16);
     const int kgrid = grid_for(nk, 64, 1 << 20);
     const bool tt = h->any_tet_tet;
-    // Dual polygons kept between the passes: at most (pairs with a non-empty polygon) x n_dir slots
-    const size_t dpcap = h->any_bristle ? (size_t)h->stats[2] * n_dir + 64 : 64;
+    // Dual polygons kept between the passes: a wave of k_narrow_dual owns 64 consecutive slots (no slot counter)
+    const size_t dpcap = h->any_bristle ? ((n_cand + cpw - 1) / cpw) * 64 + 64 : 64;   // 64 slots per group of cpw pairs
     HIP_TRY(h, h->dual_poly.ensure(dpcap * kDpFields));
     HIP_TRY(h, h->dual_pkey.ensure(dpcap));
-    HIP_TRY(h, h->dual_cnt.ensure(4));
-    HIP_TRY(h, hipMemsetAsync(h->dual_cnt.p, 0, sizeof(int) * 4, st));
-    a.dpoly = h->dual_poly.p; a.dpoly_key = h->dual_pkey.p; a.dpcount = h->dual_cnt.p; a.dpcap = (long long)dpcap;
+    a.dpoly = h->dual_poly.p; a.dpoly_key = h->dual_pkey.p; a.dpcap = (long long)dpcap;
     if (tt) hipLaunchKernelGGL((k_narrow_dual<true>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_narrow_dual<false>), dim3(grid), dim3(64), 0, st, a);
     if (h->any_bristle) {
