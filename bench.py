@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--poses", type=int, default=2048, help="Monte-Carlo poses (items) per GPU per step")
+    ap.add_argument("--poses", type=int, default=8192, help="Monte-Carlo poses (items) per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--friction", choices=["bristle", "regularized"], default="bristle",
                     help="friction model of the C3 instruction (BASELINE: bristle; regularized is an experiment knob)")

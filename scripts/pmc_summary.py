@@ -14,10 +14,14 @@ for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
             if row["Counter_Name"] != ctr:
                 continue
             name = re.sub(r"\(.*", "", row["Kernel_Name"])
-            a = acc.setdefault(name, {"calls": 0, "sum_KB": 0.0})
-            a["calls"] += 1; a["sum_KB"] += float(row["Counter_Value"])
+            a = acc.setdefault(name, {"calls": 0, "sum_KB": 0.0, "values_KB": []})
+            a["calls"] += 1; a["sum_KB"] += float(row["Counter_Value"]); a["values_KB"].append(float(row["Counter_Value"]))
     for a in acc.values():
-        a["per_call_KB"] = a["sum_KB"] / a["calls"]
+        # steady-state launches only: while the work lists are still growing (first step of a run) an overflowing
+        # candidate list truncates what the later kernels process; launches below half of the maximum are dropped
+        keep = [x for x in a["values_KB"] if x >= 0.5 * max(a["values_KB"])]
+        a["per_call_KB"] = sum(keep) / len(keep); a["steady_calls"] = len(keep)
+        del a["values_KB"]
     raw[ctr] = acc
 json.dump(raw, open(os.path.join(root, "profiles", f"{rnd}_pmc_raw.json"), "w"), indent=1)
 
@@ -31,7 +35,7 @@ out = {"k_bp_dfs32_bytes_per_launch": per_launch("pfc::k_bp_dfs32") + per_launch
        "k_narrow0_bytes_per_launch": per_launch("void pfc::k_narrow<false>"),
        "k_fric_bytes_per_launch": per_launch("pfc::k_fric"),
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch of bench.py's default workload "
-               "(2048 poses as two concurrent 1024-pose halves: a launch covers one half); bytes = 1024 x (2 x FETCH_SIZE "
+               "(8192 poses as two concurrent 4096-pose halves: a launch covers one half); bytes = 1024 x (2 x FETCH_SIZE "
                "+ WRITE_SIZE): the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies 128-byte line fills at "
                "64 B); Infinity-Cache hits are counted, so this is memory-side traffic of the L2, an upper bound of HBM bytes"}
 json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)

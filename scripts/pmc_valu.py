@@ -1,0 +1,34 @@
+"""profiles/pmc_valu.json from the counter groups of scripts/pmc_probe.sh (SQ_INSTS_VALU, wait and L2 counters) and the
+unit counts of a bench line.  usage: python scripts/pmc_valu.py <tag> <bench.json>
+Values are PER STEP: parts x the per-launch averages (a split step launches every kernel once per half)."""
+import csv, glob, json, os, re, sys, collections
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, bench = sys.argv[1], json.load(open(sys.argv[2]))
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(root, "gpurun_out", tag + "_g*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        vals[re.sub(r"\(.*", "", row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+
+
+def steady(v):
+    """Mean over the steady-state launches: the first launches of a run see work lists that are still growing (an
+    overflowing candidate list truncates what the later kernels process), so launches below half of the maximum are
+    dropped."""
+    if not v:
+        return None
+    keep = [x for x in v if x >= 0.5 * max(v)]
+    return sum(keep) / len(keep)
+
+
+parts = int(bench.get("concurrent_parts", 1))
+out = {"source": "rocprofv3 --pmc (scripts/pmc_probe.sh, one counter group per pass), bench.py default workload "
+                 f"({bench['config']['poses_per_gpu']} poses as {parts} concurrent part(s)); PER STEP = {parts} x the per-launch averages",
+       "node_tests": int(bench["config"]["node_tests_per_step"]), "candidates": int(bench["config"]["ops_per_step"])}
+for kern, name in (("pfc::k_bp_dfs32", "k_bp_dfs32"), ("void pfc::k_narrow<false>", "k_narrow"), ("pfc::k_fric", "k_fric")):
+    for ctr, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAIT_ANY", "wait_any_cycles"),
+                     ("SQ_WAIT_INST_ANY", "wait_inst_any_cycles"), ("TCC_HIT_sum", "tcc_hit"), ("TCC_MISS_sum", "tcc_miss")):
+        m = steady(vals[kern][ctr])
+        if m is not None:
+            out[f"{name}_{key}"] = round(parts * m)
+json.dump(out, open(os.path.join(root, "profiles", "pmc_valu.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
