@@ -442,28 +442,28 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         if (n_poly >= 3) {
 #endif
             const int n = n_poly;
-            // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98), converted in place (x, y, z)
+            // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98), converted in place (x, y, z), fused with
+            // centroid(poly_r2, n̂2) (poly_eight.jl:35-52): vertex k is converted when the centroid fan first needs it
             {
                 double V[12];
 #pragma unroll
                 for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
-                for (int k = 0; k < n; ++k) {
+                auto conv = [&](int k) {
                     const double z0 = PR(k, 0), z1 = PR(k, 1), z2 = PR(k, 2), z3 = PR(k, 3);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        PR(k, c) = ((V[c] * z0 + V[c + 3] * z1) + V[c + 6] * z2) + V[c + 9] * z3;
-                }
-            }
-            // centroid(poly_r2, n̂2) (poly_eight.jl:35-52)
-            {
-                V3 a = mk3(PR(0, 0), PR(0, 1), PR(0, 2));
-                V3 cc = mk3(PR(1, 0), PR(1, 1), PR(1, 2));
+                    const V3 x = mk3(((V[0] * z0 + V[3] * z1) + V[6] * z2) + V[9] * z3,
+                                     ((V[1] * z0 + V[4] * z1) + V[7] * z2) + V[10] * z3,
+                                     ((V[2] * z0 + V[5] * z1) + V[8] * z2) + V[11] * z3);
+                    PR(k, 0) = x.x; PR(k, 1) = x.y; PR(k, 2) = x.z;
+                    return x;
+                };
+                const V3 a = conv(0);
+                V3 cc = conv(1);
                 double cum_sum = 0.0;
                 V3 cum_prod = mk3(0.0, 0.0, 0.0);
                 for (int k = 2; k < n; ++k) {
-                    V3 b = cc;
-                    cc = mk3(PR(k, 0), PR(k, 1), PR(k, 2));
-                    double ar = triangle_area(a, b, cc, nh);
+                    const V3 b = cc;
+                    cc = conv(k);
+                    const double ar = triangle_area(a, b, cc, nh);
                     cum_prod = cum_prod + ((a + b) + cc) * (1.0 / 3.0) * ar;
                     cum_sum += ar;
                 }
