@@ -217,3 +217,24 @@ def test_split_evaluation_equals_unsplit(pfc):
     for key in ("node_tests", "candidates", "nonempty", "tractions", "n_items"):
         assert a[3][key] == b[3][key], key
     assert np.all(a[2][:, 3] > 0)
+
+
+def test_alternating_batch_shapes_on_one_handle(pfc):
+    """One handle, evaluations of very different sizes back to back (1, 700, 3, 1500 split, 64 items): the append lists
+    (candidates, kept polygons and moment records in their 64 regions, contributing pairs) and their counters must
+    start every evaluation empty whatever the previous one left behind, on the graph path and across the growth of
+    the buffers.  Every evaluation is checked against a fresh handle that only ever saw that one batch."""
+    w = pfc.configs.c3_blob_tool(1500, seed=77, n_div_blob=8, n_div_tool=6)
+    w.s[:] = np.random.default_rng(9).standard_normal((w.n_items, 6)) * 1e-3
+    m = pfc.configs.build_scenario(w)
+    for rep in range(2):
+        for lo, hi in ((0, 1), (100, 800), (5, 8), (0, 1500), (900, 964)):
+            sl = slice(lo, hi)
+            wr, sd, ct = m.force_all_elastic_intersections(w.pose[sl], w.twist[sl], w.s[sl], w.ins_ids[sl])
+            f = pfc.configs.build_scenario(w)
+            wr0, sd0, ct0 = f.force_all_elastic_intersections(w.pose[sl], w.twist[sl], w.s[sl], w.ins_ids[sl])
+            f.close()
+            assert np.array_equal(ct, ct0), (rep, lo, hi)
+            np.testing.assert_allclose(wr, wr0, rtol=1e-11, atol=1e-11 * max(np.abs(wr0).max(), 1e-300))
+            np.testing.assert_allclose(sd, sd0, rtol=1e-7, atol=1e-7 * max(np.abs(sd0).max(), 1e-300))
+    m.close()
