@@ -228,15 +228,22 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
     }
 }
 
-#define PV(k, c) pv[((((rbase) + (k)) & 7) * 4 + (c)) * 64 + lane]
+// Polygon rings of pass A in LDS.  The VALUE ring is shared by the n_dir lanes of a candidate: they hold the same
+// values and take the same branches (Dual comparisons look at values only), so every ring write is the same number to
+// the same address from each of them, and a read is an LDS broadcast.  With at most 16 candidates per wave (n_dir >= 4)
+// the value ring is 4 KiB instead of 16 (column stride 16: the 4 s + c part of an address is a multiple of 16 doubles,
+// so distinct candidates sit in distinct banks); 20 KiB per wave let eight waves share a CU instead of five.
+#define PV(k, c) pv[((((rbase) + (k)) & 7) * 4 + (c)) * pvs + pvi]
 #define PD(k, c) pd[((((rbase) + (k)) & 7) * 4 + (c)) * 64 + lane]
+__host__ __device__ inline int dual_pv_stride(int n_dir) { return 64 / n_dir <= 16 ? 16 : 64; }
+__host__ inline size_t dual_lds_bytes(int n_dir) { return sizeof(double) * (size_t)(8 * 4 * 64 + 8 * 4 * dual_pv_stride(n_dir)); }
 
 // Pass A: gather, clip and integrate in Dual arithmetic (normal wrench, regularized friction fused, cop sums); the
 // Dual polygon of every contributing bristle lane is kept for passes B and C (k_dual_poly).  TT as in k_narrow.
 template <bool TT>
 __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
-    __shared__ double pv[8 * 4 * 64];
-    __shared__ double pd[8 * 4 * 64];
+    extern __shared__ double dual_lds[];     // dual_lds_bytes(n_dir): partial ring (16 KiB), then the value ring
+    double *pd = dual_lds, *pv = dual_lds + 8 * 4 * 64;
     const int lane = threadIdx.x;
     int n_c = *g.scount;     // contributing pairs only: no lane gathers for a pair that will be rejected
     if (n_c > g.ccap) n_c = g.ccap;
@@ -244,6 +251,7 @@ __global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
     const int cpw = 64 / n_dir;
     const int n_group = (n_c + cpw - 1) / cpw;
     const int dir = lane / cpw, cl = lane - dir * cpw;
+    const int pvs = dual_pv_stride(n_dir), pvi = pvs == 16 ? cl : lane;
     for (int grp = blockIdx.x; grp < n_group; grp += gridDim.x) {
         const int idx = grp * cpw + cl;
         const bool active = dir < n_dir && idx < n_c;

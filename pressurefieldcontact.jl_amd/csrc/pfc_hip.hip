@@ -1015,8 +1015,8 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     HIP_TRY(h, h->dual_poly.ensure(dpcap * kDpFields));
     HIP_TRY(h, h->dual_pkey.ensure(dpcap));
     a.dpoly = h->dual_poly.p; a.dpoly_key = h->dual_pkey.p; a.dpcap = (long long)dpcap;
-    if (tt) hipLaunchKernelGGL((k_narrow_dual<true>), dim3(grid), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_narrow_dual<false>), dim3(grid), dim3(64), 0, st, a);
+    if (tt) hipLaunchKernelGGL((k_narrow_dual<true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+    else hipLaunchKernelGGL((k_narrow_dual<false>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
     if (h->any_bristle) {
         const int pgrid = grid_for(dpcap, 64, 256 * 16);
         hipLaunchKernelGGL((k_dual_poly<1>), dim3(pgrid), dim3(64), 0, st, a);
