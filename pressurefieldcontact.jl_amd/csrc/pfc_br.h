@@ -247,15 +247,22 @@ __device__ __forceinline__ void final_item(const BrArgs &g, int i) {
     const double *a = g.acc + (size_t)i * kAccStride;
     const double *r = g.res + (size_t)i * kResStride;
     double *w = g.wrench + 6 * (size_t)i, *sd = g.sdot + 6 * (size_t)i;
-    const bool contact = g.icnt[4 * (size_t)i + 3] > 0;
-    if (g.counts)
-        for (int k = 0; k < 4; ++k) g.counts[4 * (size_t)i + k] = g.icnt[4 * (size_t)i + k];
-    for (int k = 0; k < 6; ++k) { w[k] = 0.0; sd[k] = 0.0; }
-    if (it->model == PFC_REGULARIZED) {
-        if (contact)
-            for (int k = 0; k < 6; ++k) w[k] = a[kAccWrench + k];
+    // everything the common paths need is loaded before the first branch (one round trip to memory instead of three)
+    const int4 cnt = *reinterpret_cast<const int4 *>(g.icnt + 4 * (size_t)i);
+    const int model = it->model;
+    double aw[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) aw[k] = a[kAccWrench + k];
+    const bool contact = cnt.w > 0;
+    if (g.counts) {   // the caller's buffer: only int alignment may be assumed
+        int *co = g.counts + 4 * (size_t)i;
+        co[0] = cnt.x; co[1] = cnt.y; co[2] = cnt.z; co[3] = cnt.w;
+    }
+    if (model == PFC_REGULARIZED) {
+        for (int k = 0; k < 6; ++k) { w[k] = contact ? aw[k] : 0.0; sd[k] = 0.0; }
         return;
     }
+    for (int k = 0; k < 6; ++k) { w[k] = 0.0; sd[k] = 0.0; }
     const double tau_inv = 1.0 / it->tau;
     if (!contact) {
         for (int k = 0; k < 6; ++k) sd[k] = -tau_inv * it->s[k];
@@ -263,8 +270,8 @@ __device__ __forceinline__ void final_item(const BrArgs &g, int i) {
     }
     V3 fang = ld3(a + kAccFric), flin = ld3(a + kAccFric + 3), cop = ld3(r + kResCop);
     V3 fang2 = fang + cross(cop, flin);
-    w[0] = a[kAccWrench] + fang2.x; w[1] = a[kAccWrench + 1] + fang2.y; w[2] = a[kAccWrench + 2] + fang2.z;
-    w[3] = a[kAccWrench + 3] + flin.x; w[4] = a[kAccWrench + 4] + flin.y; w[5] = a[kAccWrench + 5] + flin.z;
+    w[0] = aw[0] + fang2.x; w[1] = aw[1] + fang2.y; w[2] = aw[2] + fang2.z;
+    w[3] = aw[3] + flin.x; w[4] = aw[4] + flin.y; w[5] = aw[5] + flin.z;
     double sw[6];
     for (int k = 0; k < 6; ++k) sw[k] = r[kResSinv + k] * a[kAccFric + k];
     for (int ii = 0; ii < 6; ++ii) {
@@ -282,33 +289,48 @@ __device__ __forceinline__ void final_item(const BrArgs &g, int i) {
 // small scene pays is launches, not kernels: this used to be a kernel of its own plus two memset nodes.)
 __global__ void __launch_bounds__(128) k_final(BrArgs g) {
     __shared__ unsigned long long tot[3];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < g.n_items) final_item(g, i);
-    if (blockIdx.x != 0) return;
-    if (threadIdx.x < 3) tot[threadIdx.x] = 0ull;
-    __syncthreads();
-    unsigned long long a = 0, b = 0, c = 0;
-    for (int k = threadIdx.x; k < g.n_items; k += blockDim.x) {
-        a += (unsigned)g.icnt[4 * (size_t)k]; b += (unsigned)g.icnt[4 * (size_t)k + 2]; c += (unsigned)g.icnt[4 * (size_t)k + 3];
-    }
-    atomicAdd(&tot[0], a); atomicAdd(&tot[1], b); atomicAdd(&tot[2], c);
-    __syncthreads();
-    int *tail = g.tail;
-    if (threadIdx.x < 4) { tail[threadIdx.x] = (int)g.status[threadIdx.x]; g.status[threadIdx.x] = 0u; }
-    if (threadIdx.x < 3) reinterpret_cast<unsigned long long *>(tail + 4)[threadIdx.x] = tot[threadIdx.x];
-    if (threadIdx.x == 3) reinterpret_cast<unsigned long long *>(tail + 4)[3] = 0ull;
-    for (int k = threadIdx.x; k < g.n_ctr; k += blockDim.x) { tail[12 + k] = g.ctr[k]; g.ctr[k] = 0; }
-    // region counters -> totals (the host sizes the record list by them)
     __shared__ int rtot[2];
-    if (threadIdx.x < 2) rtot[threadIdx.x] = 0;
-    __syncthreads();
-    if (threadIdx.x < kRgn) {
-        int *c = g.rgn + threadIdx.x * kRgnStride;
-        atomicAdd(&rtot[0], c[0]); atomicAdd(&rtot[1], c[1]);
-        c[0] = 0; c[1] = 0;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + tid;
+    const bool b0 = blockIdx.x == 0;
+    // Block 0 issues every load of the packing FIRST: they depend on nothing this kernel computes, and a small scene
+    // pays each dependent round trip to memory in full (this kernel was 14.6 us of a 68 us C1 evaluation when the
+    // packing loaded after the epilogue and between barriers).
+    unsigned stw = 0;
+    int c0 = 0, c1 = 0, r0 = 0, r1 = 0;
+    unsigned long long a = 0, b = 0, c = 0;
+    if (b0) {
+        if (tid < 4) stw = g.status[tid];
+        if (tid < g.n_ctr) c0 = g.ctr[tid];
+        if (tid + 128 < g.n_ctr) c1 = g.ctr[tid + 128];
+        if (tid < kRgn) { r0 = g.rgn[tid * kRgnStride]; r1 = g.rgn[tid * kRgnStride + 1]; }
+        for (int k = tid; k < g.n_items; k += blockDim.x) {
+            a += (unsigned)g.icnt[4 * (size_t)k]; b += (unsigned)g.icnt[4 * (size_t)k + 2]; c += (unsigned)g.icnt[4 * (size_t)k + 3];
+        }
+        if (tid < 3) tot[tid] = 0ull;
+        if (tid < 2) rtot[tid] = 0;
     }
+    if (i < g.n_items) final_item(g, i);
+    if (!b0) return;
     __syncthreads();
-    if (threadIdx.x == 0) { tail[12 + g.i_pcount] = rtot[0]; tail[12 + 3] = rtot[1]; }
+    if (a) atomicAdd(&tot[0], a);
+    if (b) atomicAdd(&tot[1], b);
+    if (c) atomicAdd(&tot[2], c);
+    if (r0) atomicAdd(&rtot[0], r0);
+    if (r1) atomicAdd(&rtot[1], r1);
+    int *tail = g.tail;
+    if (tid < 4) { tail[tid] = (int)stw; g.status[tid] = 0u; }
+    if (tid < g.n_ctr && tid != g.i_pcount && tid != 3) tail[12 + tid] = c0;
+    if (tid + 128 < g.n_ctr) tail[12 + tid + 128] = c1;     // i_pcount, 3 < 128
+    if (tid < g.n_ctr) g.ctr[tid] = 0;
+    if (tid + 128 < g.n_ctr) g.ctr[tid + 128] = 0;
+    for (int k = tid + 256; k < g.n_ctr; k += blockDim.x) { tail[12 + k] = g.ctr[k]; g.ctr[k] = 0; }   // very deep trees
+    if (tid < kRgn) { g.rgn[tid * kRgnStride] = 0; g.rgn[tid * kRgnStride + 1] = 0; }
+    __syncthreads();
+    if (tid < 3) reinterpret_cast<unsigned long long *>(tail + 4)[tid] = tot[tid];
+    if (tid == 3) reinterpret_cast<unsigned long long *>(tail + 4)[3] = 0ull;
+    // region counters -> totals (the host sizes the record list by them)
+    if (tid == 0) { tail[12 + g.i_pcount] = rtot[0]; tail[12 + 3] = rtot[1]; }
 }
 
 // addGeneralizedForcesThirdLaw! (non_friction.jl:267-286): per item, the wrench on body 2 (frame r2) goes to the
