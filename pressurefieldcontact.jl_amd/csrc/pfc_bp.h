@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
         w.item = 0; w.a = 0; w.b = 0; w.pad = 0;
         bool hit = false, la = false, lb = false;
         int ca0 = 0, ca1 = 0, cb0 = 0, cb1 = 0, leaf_a = 0, leaf_b = 0;
+        int fa0 = 0, fa1 = 0, fb0 = 0, fb1 = 0;   // WorkRec.pad flags of the children: bit 0 / 1 = a / b is a leaf (negative link)
         if (active) {
             w = g.fin[idx];
             const ItemRec *it = g.items + w.item;
@@ -55,6 +56,7 @@ __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
             hit = bb_bb_intersect(a, b, it->R12, it->t12);
             la = a.leaf != kInternal; lb = b.leaf != kInternal;
             ca0 = node_index(a.child0); ca1 = node_index(a.child1); cb0 = node_index(b.child0); cb1 = node_index(b.child1);
+            fa0 = a.child0 < 0 ? 1 : 0; fa1 = a.child1 < 0 ? 1 : 0; fb0 = b.child0 < 0 ? 2 : 0; fb1 = b.child1 < 0 ? 2 : 0;
             leaf_a = a.leaf; leaf_b = b.leaf;
         }
         count_per_item(g.icnt, w.item, 0, active, active);
@@ -90,20 +92,20 @@ __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
             if (nout) {
                 if (pos + nout <= g.fcap) {
                     WorkRec c;
-                    c.item = w.item; c.pad = 0;
+                    c.item = w.item;
                     if (two) {
                         if (la) {  // leaf_1: descend tree_2 (:97-98)
-                            c.a = w.a; c.b = cb0; g.fout[pos] = c;
-                            c.b = cb1; g.fout[pos + 1] = c;
+                            c.a = w.a; c.b = cb0; c.pad = 1 | fb0; g.fout[pos] = c;
+                            c.b = cb1; c.pad = 1 | fb1; g.fout[pos + 1] = c;
                         } else {   // leaf_2: descend tree_1 (:101-103)
-                            c.b = w.b; c.a = ca0; g.fout[pos] = c;
-                            c.a = ca1; g.fout[pos + 1] = c;
+                            c.b = w.b; c.a = ca0; c.pad = fa0 | 2; g.fout[pos] = c;
+                            c.a = ca1; c.pad = fa1 | 2; g.fout[pos + 1] = c;
                         }
                     } else {       // (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107)
-                        c.a = ca0; c.b = cb0; g.fout[pos] = c;
-                        c.a = ca1; c.b = cb0; g.fout[pos + 1] = c;
-                        c.a = ca0; c.b = cb1; g.fout[pos + 2] = c;
-                        c.a = ca1; c.b = cb1; g.fout[pos + 3] = c;
+                        c.a = ca0; c.b = cb0; c.pad = fa0 | fb0; g.fout[pos] = c;
+                        c.a = ca1; c.b = cb0; c.pad = fa1 | fb0; g.fout[pos + 1] = c;
+                        c.a = ca0; c.b = cb1; c.pad = fa0 | fb1; g.fout[pos + 2] = c;
+                        c.a = ca1; c.b = cb1; c.pad = fa1 | fb1; g.fout[pos + 3] = c;
                     }
                 } else {
                     atomicOr(g.status, kStFrontierOvf);
@@ -312,9 +314,13 @@ __device__ __forceinline__ void exact_pairs_coop(const ItemRec *it, const double
 // ~700 dependent iterations for a single wave -- that serial chain, not ALU or memory, bounded the one-wave-per-seed
 // version (every variant of its inner loop ran 2.0 ms).  Four waves pop 256 pairs per iteration from the same stack.
 
-// one ticket per workgroup: thread 0 takes it, LDS broadcast between two barriers
-__device__ __forceinline__ int next_ticket_block(int *ctr, int *slot) {
-    if (threadIdx.x == 0) *slot = atomicAdd(ctr, 1);
+// Seed tickets of the workgroup kernel: workgroup b starts with seed b (no atomic), further seeds are handed out by
+// the counter, offset by the grid size -- and not asked for at all when the grid already covers every seed (a small
+// scene: each returning atomic is ~2 us of a ~19 us kernel).  One ticket per workgroup: thread 0 takes it, LDS
+// broadcast between two barriers; the early return is uniform over the workgroup.
+__device__ __forceinline__ int next_ticket_block(int *ctr, int *slot, int n_seed) {
+    if ((int)gridDim.x >= n_seed) return n_seed;
+    if (threadIdx.x == 0) *slot = (int)gridDim.x + atomicAdd(ctr, 1);
     __syncthreads();
     const int t = *slot;
     __syncthreads();
@@ -352,9 +358,11 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n_seed = *g.n_seed;
     if (n_seed > g.seed_cap) n_seed = g.seed_cap;
+    // the first seed record is fetched together with the seed count (blockIdx.x < grid <= seed_cap: in bounds)
+    const WorkRec s_first = g.seeds[blockIdx.x];
     // one ticket per workgroup (same loop shape as k_bp_dfs: condition in the for header, no break)
-    for (int sd = next_ticket_block(g.next_seed, &s_seed); sd < n_seed; sd = next_ticket_block(g.next_seed, &s_seed)) {
-        const WorkRec s = g.seeds[__builtin_amdgcn_readfirstlane(sd)];
+    for (int sd = blockIdx.x; sd < n_seed; sd = next_ticket_block(g.next_seed, &s_seed, n_seed)) {
+        const WorkRec s = (sd == (int)blockIdx.x) ? s_first : g.seeds[__builtin_amdgcn_readfirstlane(sd)];
         const int item = __builtin_amdgcn_readfirstlane(s.item);   // uniform: scalar loads of the pose below
         const ItemRec *it = g.items + item;
         // the item's pose lives in LDS (broadcast reads inside the iteration) rather than in 33 registers that would
@@ -365,8 +373,8 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
         int sp = 1, n_out = 0, n_test = 0, n_cand = 0, n_def = 0, n_und = 0;
         if (tid == 0) {
             // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
-            const int sa = (((const GNodeRec *)it->nodes1)[s.a].leaf != kInternal) ? ~s.a : s.a;
-            const int sb = (((const GNodeRec *)it->nodes2)[s.b].leaf != kInternal) ? ~s.b : s.b;
+            const int sa = (s.pad & 1) ? ~s.a : s.a;     // leaf flags travel with the seed (k_setup_items, k_bp_expand)
+            const int sb = (s.pad & 2) ? ~s.b : s.b;
             stk[0] = make_int2(sa, sb);
             s_def[0] = s_def[1] = 0;
         }

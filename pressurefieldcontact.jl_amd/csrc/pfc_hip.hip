@@ -113,7 +113,9 @@ __global__ void k_setup_items(EvalArgs g) {
     if (!finite) atomicOr(g.status, kStNonFinite);
     g.items[i] = r;
     WorkRec w;
-    w.item = i; w.a = 0; w.b = 0; w.pad = 0;
+    // pad: bit 0 / bit 1 = node a / node b is a leaf (a one-element mesh: the root is the leaf), so that the
+    // depth-first kernel can start a seed without reading the two nodes first
+    w.item = i; w.a = 0; w.b = 0; w.pad = (m1.n_node == 1 ? 1 : 0) | (m2.n_node == 1 ? 2 : 0);
     g.frontier0[i] = w;
     for (int k = 0; k < kAccStride; ++k) g.acc[(size_t)i * kAccStride + k] = 0.0;
 #pragma unroll
