@@ -194,6 +194,7 @@ struct pfc_context {
     DevBuf<unsigned long long> stamps;   // diagnostic builds
     DevBuf<int> tail;                    // packed status, totals, counters (block 0 of k_final)
     int *h_tail = nullptr;               // pinned host mirror of tail
+    const int *tail_host = nullptr;      // set by pfc_eval: the tail is already on its way to this pinned block (with the outputs)
     size_t h_tail_cap = 0;
     void *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-buffer path
     size_t pin_in_cap = 0, pin_out_cap = 0;
@@ -523,10 +524,14 @@ int check_one(pfc_context *h) {
     if (!h->pending) return PFC_OK;
     const int levels = h->last_levels;
     const size_t n_tail = (size_t)levels + 12 + 12;
-    HIP_TRY(h, hipMemcpyAsync(h->h_tail, h->tail.p, sizeof(int) * n_tail, hipMemcpyDeviceToHost, h->last_stream));
+    const int *tail = h->h_tail;
+    if (h->tail_host) {     // pfc_eval: one D2H copy carries the tail and the outputs
+        tail = h->tail_host; h->tail_host = nullptr;
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->h_tail, h->tail.p, sizeof(int) * n_tail, hipMemcpyDeviceToHost, h->last_stream));
+    }
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     h->pending = false;
-    const int *tail = h->h_tail;
     const unsigned status = (unsigned)tail[0];
     const unsigned long long *tot = reinterpret_cast<const unsigned long long *>(tail + 4);
     const int *ctr = tail + 12;
@@ -914,43 +919,52 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     if (!pose || !twist || !wrench || !sdot) return fail(h, PFC_ERR_BAD_ARG, "null buffer");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t n = (size_t)n_items;
-    // one pinned block in (pose | twist | s | ins_ids), one pinned block out (wrench | sdot | counts): two async
-    // copies around the launch sequence and a single synchronisation
+    // one pinned block in (pose | twist | s | ins_ids), one pinned block out (tail | wrench | sdot | counts): two async
+    // copies around the launch sequence and a single synchronisation.  The device side of the output block lives
+    // behind the packed tail in the same buffer, so that the status / counters and the results come back together.
     const size_t in_d = n * 36, in_bytes = in_d * sizeof(double) + n * sizeof(int);
     const size_t out_d = n * 12, out_bytes = out_d * sizeof(double) + n * 4 * sizeof(int);
+    const size_t t0 = (((size_t)h->max_levels + 40) + 3) & ~(size_t)3;      // ints in front of the outputs (16-byte multiple)
+    const size_t back_bytes = t0 * sizeof(int) + out_bytes;
     if (h->pin_in_cap < in_bytes) {
         if (h->pin_in) (void)hipHostFree(h->pin_in);
         h->pin_in = nullptr; h->pin_in_cap = 0;
         HIP_TRY(h, hipHostMalloc(&h->pin_in, in_bytes * 2));
         h->pin_in_cap = in_bytes * 2;
     }
-    if (h->pin_out_cap < out_bytes) {
+    if (h->pin_out_cap < back_bytes) {
         if (h->pin_out) (void)hipHostFree(h->pin_out);
         h->pin_out = nullptr; h->pin_out_cap = 0;
-        HIP_TRY(h, hipHostMalloc(&h->pin_out, out_bytes * 2));
-        h->pin_out_cap = out_bytes * 2;
+        HIP_TRY(h, hipHostMalloc(&h->pin_out, back_bytes * 2));
+        h->pin_out_cap = back_bytes * 2;
     }
     HIP_TRY(h, h->h_pose.ensure(in_d + (n + 1) / 2 + 1));      // device mirror of the input block (doubles)
-    HIP_TRY(h, h->h_wrench.ensure(out_d + 2 * n + 1));         // device mirror of the output block
+    {
+        const size_t cap0 = h->tail.cap;
+        HIP_TRY(h, h->tail.ensure(t0 + out_bytes / sizeof(int) + 4));   // only ever grows; ensure_work asks for less
+        if (h->tail.cap != cap0) ++h->epoch;                   // captured graphs hold the old address
+    }
     double *pi = (double *)h->pin_in;
     std::memcpy(pi, pose, sizeof(double) * n * 24);
     std::memcpy(pi + n * 24, twist, sizeof(double) * n * 6);
     if (s) std::memcpy(pi + n * 30, s, sizeof(double) * n * 6); else std::memset(pi + n * 30, 0, sizeof(double) * n * 6);
     if (ins_ids) std::memcpy(pi + in_d, ins_ids, sizeof(int) * n);
     hipStream_t st = h->stream;
-    double *di = h->h_pose.p, *dout = h->h_wrench.p;
+    double *di = h->h_pose.p, *dout = reinterpret_cast<double *>(h->tail.p + t0);
     HIP_TRY(h, hipMemcpyAsync(di, pi, ins_ids ? in_bytes : in_d * sizeof(double), hipMemcpyHostToDevice, st));
     int rc = PFC_OK;
     for (int attempt = 0; attempt < 40; ++attempt) {
         rc = pfc_eval_device(h, n_items, ins_ids ? (const int *)(di + in_d) : nullptr, di, di + n * 24,
                              s ? di + n * 30 : nullptr, dout, dout + n * 6, (int *)(dout + out_d), st);
         if (rc != PFC_OK) return rc;
-        HIP_TRY(h, hipMemcpyAsync(h->pin_out, dout, out_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(h->pin_out, h->tail.p, back_bytes, hipMemcpyDeviceToHost, st));
+        h->tail_host = (const int *)h->pin_out;
         rc = check_eval(h);
+        h->tail_host = nullptr;
         if (rc != PFC_ERR_OVERFLOW) break;
     }
     if (rc != PFC_OK) return rc;
-    const double *po = (const double *)h->pin_out;
+    const double *po = reinterpret_cast<const double *>((const int *)h->pin_out + t0);
     std::memcpy(wrench, po, sizeof(double) * n * 6);
     std::memcpy(sdot, po + n * 6, sizeof(double) * n * 6);
     if (counts) std::memcpy(counts, po + out_d, sizeof(int) * n * 4);
