@@ -195,6 +195,7 @@ struct pfc_context {
     DevBuf<int> tail;                    // packed status, totals, counters (block 0 of k_final)
     int *h_tail = nullptr;               // pinned host mirror of tail
     const int *tail_host = nullptr;      // set by pfc_eval: the tail is already on its way to this pinned block (with the outputs)
+    int *tail_dev = nullptr;             // set by pfc_eval for a small scene: k_final packs straight into pinned host memory
     size_t h_tail_cap = 0;
     void *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-buffer path
     size_t pin_in_cap = 0, pin_out_cap = 0;
@@ -203,7 +204,7 @@ struct pfc_context {
     hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [0] plain evaluation, [1] with the contributing-pair list (Dual)
     struct GraphKey {
         int n_items, levels, L, debug, bristle, surv;
-        const void *p[7];
+        const void *p[8];
         void *stream;
         unsigned long long epoch;
     } gkey[2] = {};
@@ -451,7 +452,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     br.items = h->items.p; br.n_items = n_items; br.acc = h->acc.p; br.res = h->res.p; br.icnt = h->icnt.p;
     br.trac = trac_view(h); br.tcount = tcount; br.tcap = (int)h->tcap; br.wrench = d_wrench; br.sdot = d_sdot;
     br.counts = d_counts;
-    br.ctr = h->ctr.p; br.n_ctr = levels + 12; br.status = h->status.p; br.tail = h->tail.p;
+    br.ctr = h->ctr.p; br.n_ctr = levels + 12; br.status = h->status.p; br.tail = h->tail_dev ? h->tail_dev : h->tail.p;
     br.rgn = h->rgn.p; br.i_pcount = (levels + 9) & ~1;
     if (h->any_bristle) {
         ShiftArgs sh;
@@ -492,7 +493,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
         key.bristle = (h->any_bristle ? 1 : 0) | (h->any_tet_tet ? 2 : 0);
         key.surv = h->want_surv ? 1 : 0;
         key.p[0] = d_ins_ids; key.p[1] = d_pose; key.p[2] = d_twist; key.p[3] = d_s; key.p[4] = d_wrench;
-        key.p[5] = d_sdot; key.p[6] = d_counts; key.stream = (void *)st; key.epoch = h->epoch;
+        key.p[5] = d_sdot; key.p[6] = d_counts; key.p[7] = h->tail_dev; key.stream = (void *)st; key.epoch = h->epoch;
         const int gi = key.surv;   // Radau alternates value and Dual evaluations: both graphs stay instantiated
         if (!h->ghave[gi] || std::memcmp(&key, &h->gkey[gi], sizeof key) != 0) {
             if (h->gexec[gi]) { (void)hipGraphExecDestroy(h->gexec[gi]); h->gexec[gi] = nullptr; }
@@ -950,14 +951,27 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     if (s) std::memcpy(pi + n * 30, s, sizeof(double) * n * 6); else std::memset(pi + n * 30, 0, sizeof(double) * n * 6);
     if (ins_ids) std::memcpy(pi + in_d, ins_ids, sizeof(int) * n);
     hipStream_t st = h->stream;
+    // A small scene (what a Radau stage evaluates) pays ~5 us per staging copy, more than the kernels spend on the data:
+    // there the kernels read the inputs from, and write the results and the tail to, the pinned blocks directly.
+    const bool zero_copy = n_items <= 512 && !h->want_surv;
     double *di = h->h_pose.p, *dout = reinterpret_cast<double *>(h->tail.p + t0);
-    HIP_TRY(h, hipMemcpyAsync(di, pi, ins_ids ? in_bytes : in_d * sizeof(double), hipMemcpyHostToDevice, st));
+    if (zero_copy) {
+        void *dpi = nullptr, *dpo = nullptr;
+        HIP_TRY(h, hipHostGetDevicePointer(&dpi, h->pin_in, 0));
+        HIP_TRY(h, hipHostGetDevicePointer(&dpo, h->pin_out, 0));
+        di = (double *)dpi;
+        dout = reinterpret_cast<double *>((int *)dpo + t0);
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(di, pi, ins_ids ? in_bytes : in_d * sizeof(double), hipMemcpyHostToDevice, st));
+    }
     int rc = PFC_OK;
     for (int attempt = 0; attempt < 40; ++attempt) {
+        h->tail_dev = zero_copy ? reinterpret_cast<int *>(dout) - t0 : nullptr;
         rc = pfc_eval_device(h, n_items, ins_ids ? (const int *)(di + in_d) : nullptr, di, di + n * 24,
                              s ? di + n * 30 : nullptr, dout, dout + n * 6, (int *)(dout + out_d), st);
+        h->tail_dev = nullptr;
         if (rc != PFC_OK) return rc;
-        HIP_TRY(h, hipMemcpyAsync(h->pin_out, h->tail.p, back_bytes, hipMemcpyDeviceToHost, st));
+        if (!zero_copy) HIP_TRY(h, hipMemcpyAsync(h->pin_out, h->tail.p, back_bytes, hipMemcpyDeviceToHost, st));
         h->tail_host = (const int *)h->pin_out;
         rc = check_eval(h);
         h->tail_host = nullptr;
