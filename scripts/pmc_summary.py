@@ -41,4 +41,17 @@ out = {"k_bp_dfs32_bytes_per_launch": per_launch("pfc::k_bp_dfs32") + per_launch
 json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(root, "gpurun_out", f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(root, "profiles", f"{rnd}_kernel_stats.csv"))
+# rocprofv3's own summary averages over ALL launches, including the few of the first step that ran on truncated work
+# lists (buffers still growing); the steady-state averages below are the ones bench.py's HIP-event times agree with
+steady = {}
+for f in glob.glob(os.path.join(root, "gpurun_out", f"{tag}_stats", "**", "*kernel_trace.csv"), recursive=True):
+    dur = {}
+    for row in csv.DictReader(open(f)):
+        dur.setdefault(re.sub(r"\(.*", "", row["Kernel_Name"]), []).append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    for name, v in dur.items():
+        if name.startswith(("pfc::", "void pfc::")):
+            keep = [x for x in v if x >= 0.5 * max(v)]
+            steady[name] = {"launches": len(v), "steady_launches": len(keep), "all_avg_ns": sum(v) / len(v),
+                            "steady_avg_ns": sum(keep) / len(keep)}
+json.dump(steady, open(os.path.join(root, "profiles", f"{rnd}_kernel_steady.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
