@@ -213,8 +213,7 @@ struct pfc_context {
     int opt_graph = 1;
     size_t fcap = 0, ccap = 0, tcap = 0, rcap = 0;
     // host-pointer path staging
-    DevBuf<double> h_pose, h_twist, h_s, h_wrench, h_sdot;
-    DevBuf<int> h_ins, h_counts;
+    DevBuf<double> h_pose;               // device mirror of pfc_eval's pinned input block (pose | twist | s | ins_ids)
     // last evaluation
     int last_n_items = 0, last_levels = 0, last_bfs_levels = 0;
     bool pending = false;
@@ -642,8 +641,7 @@ void pfc_destroy(pfc_handle h) {
     h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
     h->clip_n.release(); h->icnt.release(); h->trac_item.release(); h->acc.release(); h->res.release();
     h->trac_d.release(); h->rec.release(); h->ctr.release(); h->status.release(); h->stamps.release();
-    h->h_pose.release(); h->h_twist.release(); h->h_s.release(); h->h_wrench.release(); h->h_sdot.release();
-    h->h_ins.release(); h->h_counts.release();
+    h->h_pose.release();
     for (int k = 0; k < EV_COUNT; ++k)
         if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (int gi = 0; gi < 2; ++gi)
