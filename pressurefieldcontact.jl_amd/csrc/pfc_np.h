@@ -774,7 +774,7 @@ struct FricArgs {
     const double *res;
     double *acc;
 };
-__global__ void __launch_bounds__(64) k_fric(FricArgs g) {
+__global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
     const int lane = threadIdx.x;
     const size_t P = (size_t)g.pcap;
     const RgnScan rs = rgn_scan(g.rgn, 0, g.rp_cap, lane);
@@ -805,9 +805,12 @@ __global__ void __launch_bounds__(64) k_fric(FricArgs g) {
             const double *res = g.res + (size_t)item * kResStride;
             const V3 cop = ld3(res + kResCop), Da = ld3(res + kResDelta), Dl = ld3(res + kResDelta + 3);
             V3 v2 = mk3(o[(10 + 3 * (n - 1)) * P], o[(11 + 3 * (n - 1)) * P], o[(12 + 3 * (n - 1)) * P]);
+            V3 vn = mk3(o[10 * P], o[11 * P], o[12 * P]);
             for (int k = 0; k < n; ++k) {
                 const V3 v1 = v2;
-                v2 = mk3(o[(10 + 3 * k) * P], o[(11 + 3 * k) * P], o[(12 + 3 * k) * P]);
+                v2 = vn;
+                // the next vertex is fetched while this triangle's points are evaluated (slot k + 1 <= 7 always exists)
+                if (k + 1 < n) vn = mk3(o[(13 + 3 * k) * P], o[(14 + 3 * k) * P], o[(15 + 3 * k) * P]);
                 const double area = triangle_area(v1, v2, cen, nh);
                 if (!(0.0 < area)) continue;
                 for (int q = 0; q < nq; ++q) {
