@@ -804,6 +804,7 @@ __global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
             const double mu_slope = (mu_d - mu_s) / (3 * mu_s - 2 * mu_s);   // clamped_piecewise(x, 2 mu_s, 3 mu_s, mu_s, mu_d)
             const double *res = g.res + (size_t)item * kResStride;
             const V3 cop = ld3(res + kResCop), Da = ld3(res + kResDelta), Dl = ld3(res + kResDelta + 3);
+            const V3 ts_c0 = ((Dl - cross(Da, cop)) + vl * tau) * (-k_bar), ts_e = (Da + w * tau) * (-k_bar);
             V3 v2 = mk3(o[(10 + 3 * (n - 1)) * P], o[(11 + 3 * (n - 1)) * P], o[(12 + 3 * (n - 1)) * P]);
             V3 vn = mk3(o[10 * P], o[11 * P], o[12 * P]);
             for (int k = 0; k < n; ++k) {
@@ -836,8 +837,10 @@ __global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
                     contributed = true;
                     const double p_dA = p * dA;
                     const V3 x = r - cop;
-                    const V3 del = Dl + cross(Da, x);
-                    V3 Ts = (del + rdot * tau) * (-k_bar);
+                    // T̄s = -k̄ (Δ_lin + Δ_ang x (r - cop) + τ (v + ω x r)) (friction.jl:186-190) = c0 + e x r with the
+                    // per-item constants c0 = -k̄ (Δ_lin - Δ_ang x cop + τ v), e = -k̄ (Δ_ang + τ ω): one cross product
+                    // per point instead of two (rounding differs in the last bits; T̄s only feeds the friction force)
+                    V3 Ts = ts_c0 + cross(ts_e, r);
                     Ts = vec_sub_vec_proj(Ts, nh);
                     const double m2 = dot(Ts, Ts);
                     V3 T;
