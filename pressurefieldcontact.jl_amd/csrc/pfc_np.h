@@ -527,9 +527,14 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         if (m2 < v_c * v_c) {
                             T = vt * (-(mu_s / v_c));
                         } else {
-                            const double mg = __builtin_sqrt(m2);
+                            // as in k_fric: 1/|v_t| from the hardware rsqrt and two Newton steps
+                            double ri = __builtin_amdgcn_rsq(m2);
+                            const double hm = 0.5 * m2;
+                            ri = ri * __builtin_fma(-hm * ri, ri, 1.5);
+                            ri = ri * __builtin_fma(-hm * ri, ri, 1.5);
+                            const double mg = m2 * ri;
                             const double mu = clamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
-                            T = vt * (-(mu / mg));
+                            T = vt * (-(mu * ri));
                         }
                         const V3 tk = nh * p_dA + T * p_dA;
                         const V3 ta = cross(r, tk);
