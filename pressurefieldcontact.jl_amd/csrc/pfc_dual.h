@@ -63,6 +63,21 @@ __device__ __forceinline__ Du3 dvec_sub_vec_proj(Du3 v, Du3 n) {
     const Du t = -ddot(v, n);
     return Du3{dfma(t, n.x, v.x), dfma(t, n.y, v.y), dfma(t, n.z, v.z)};
 }
+// mu(|T|) / |T| for a sliding point, |T|^2 = m2 given: the friction coefficient ramp of calc_clamped_piecewise
+// (friction.jl:2-10) over the norm, with 1/|T| from the hardware reciprocal square root and two Newton steps (as in
+// k_fric) -- no IEEE sqrt and no division; the partials follow from d|T| = dm2 / (2 |T|).
+__device__ __forceinline__ Du dmu_over_norm(Du m2, double x1, double x2, double y1, double y2) {
+    double ri = __builtin_amdgcn_rsq(m2.v);
+    const double hm = 0.5 * m2.v;
+    ri = ri * __builtin_fma(-hm * ri, ri, 1.5);
+    ri = ri * __builtin_fma(-hm * ri, ri, 1.5);
+    const Du mg = Du{m2.v * ri, (0.5 * m2.d) * ri};
+    const double k = (y2 - y1) / (x2 - x1);
+    const Du y = du(y1) + (mg - du(x1)) * k;
+    const Du mu = (y.v > y1) ? du(y1) : ((y.v < y2) ? du(y2) : y);
+    const double q = mu.v * ri;
+    return Du{q, (mu.d - q * mg.d) * ri};
+}
 __device__ __forceinline__ Du dclamped_piecewise(Du x, double x1, double x2, double y1, double y2) {
     const double k = (y2 - y1) / (x2 - x1);
     const Du y = du(y1) + (x - du(x1)) * k;
@@ -156,9 +171,7 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
                 if (m2.v < mu_s * mu_s) {
                     T = Ts;
                 } else {
-                    const Du mg = dsqrt(m2);
-                    const Du mu = dclamped_piecewise(mg, 2 * mu_s, 3 * mu_s, mu_s, mu_d);
-                    T = (Ts * mu) / mg;
+                    T = Ts * dmu_over_norm(m2, 2 * mu_s, 3 * mu_s, mu_s, mu_d);
                 }
                 const Du3 Tc = T * p_dA;
                 const Du3 ta = dcross(x, Tc);
@@ -183,6 +196,7 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
                 if (m2.v < v_c * v_c) {
                     T = (vt * (-mu_s)) / v_c;
                 } else {
+                    // (pass A sits at the 256-register limit: the division-free form of pass C costs it a wave per SIMD)
                     const Du mg = dsqrt(m2);
                     const Du mu = dclamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
                     T = (vt * (-mu)) / mg;
@@ -241,7 +255,7 @@ __host__ inline size_t dual_lds_bytes(int n_dir) { return sizeof(double) * (size
 // Pass A: gather, clip and integrate in Dual arithmetic (normal wrench, regularized friction fused, cop sums); the
 // Dual polygon of every contributing bristle lane is kept for passes B and C (k_dual_poly).  TT as in k_narrow.
 template <bool TT>
-__global__ void __launch_bounds__(64) k_narrow_dual(DualArgs g) {
+__global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
     extern __shared__ double dual_lds[];     // dual_lds_bytes(n_dir): partial ring (16 KiB), then the value ring
     double *pd = dual_lds, *pv = dual_lds + 8 * 4 * 64;
     const int lane = threadIdx.x;
