@@ -770,6 +770,17 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
 // Bristle friction pass (after k_eig): calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48)
 // over the polygons k_narrow kept.  One lane per kept polygon, every load is a coalesced read of consecutive slots;
 // the fan / quadrature arithmetic is the one of k_narrow, so the traction points are bit-identical.
+// Fused-multiply-add forms of the vector helpers for the friction force, which is compared with the oracle by
+// tolerance (the library is built with -ffp-contract=off because the traction points and every predicate upstream are
+// bit-exact restatements; here an a*b + c*d costs two instructions instead of three).
+__device__ __forceinline__ V3 cross_fma(V3 a, V3 b) {
+    return V3{__builtin_fma(a.y, b.z, -(a.z * b.y)), __builtin_fma(a.z, b.x, -(a.x * b.z)), __builtin_fma(a.x, b.y, -(a.y * b.x))};
+}
+__device__ __forceinline__ double dot_fma(V3 a, V3 b) { return __builtin_fma(a.z, b.z, __builtin_fma(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ V3 axpy_fma(double a, V3 x, V3 y) {
+    return V3{__builtin_fma(a, x.x, y.x), __builtin_fma(a, x.y, y.y), __builtin_fma(a, x.z, y.z)};
+}
+
 struct FricArgs {
     const ItemRec *items;
     const int *poly_item;
@@ -845,9 +856,9 @@ __global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
                     // T̄s = -k̄ (Δ_lin + Δ_ang x (r - cop) + τ (v + ω x r)) (friction.jl:186-190) = c0 + e x r with the
                     // per-item constants c0 = -k̄ (Δ_lin - Δ_ang x cop + τ v), e = -k̄ (Δ_ang + τ ω): one cross product
                     // per point instead of two (rounding differs in the last bits; T̄s only feeds the friction force)
-                    V3 Ts = ts_c0 + cross(ts_e, r);
-                    Ts = vec_sub_vec_proj(Ts, nh);
-                    const double m2 = dot(Ts, Ts);
+                    V3 Ts = ts_c0 + cross_fma(ts_e, r);
+                    Ts = axpy_fma(-dot_fma(Ts, nh), nh, Ts);      // vec_sub_vec_proj
+                    const double m2 = dot_fma(Ts, Ts);
                     V3 T;
                     if (m2 < mu_s * mu_s) {
                         T = Ts;
@@ -867,7 +878,7 @@ __global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
                         T = Ts * (mu * ri);
                     }
                     const V3 Tc = T * p_dA;
-                    const V3 ta = cross(x, Tc);
+                    const V3 ta = cross_fma(x, Tc);
                     sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
                     sum[3] += Tc.x; sum[4] += Tc.y; sum[5] += Tc.z;
                 }
