@@ -35,6 +35,17 @@ struct NpArgs {
     unsigned long long *stamps;  // diagnostic builds: [0..5] cycles in gather / clip / reserve / integrate / reduce, rounds
 };
 
+// Fused-multiply-add forms of the vector helpers for quantities that are compared with the oracle by
+// tolerance (friction force, patch moments) (the library is built with -ffp-contract=off because the traction points and every predicate upstream are
+// bit-exact restatements; here an a*b + c*d costs two instructions instead of three).
+__device__ __forceinline__ V3 cross_fma(V3 a, V3 b) {
+    return V3{__builtin_fma(a.y, b.z, -(a.z * b.y)), __builtin_fma(a.z, b.x, -(a.x * b.z)), __builtin_fma(a.x, b.y, -(a.y * b.x))};
+}
+__device__ __forceinline__ double dot_fma(V3 a, V3 b) { return __builtin_fma(a.z, b.z, __builtin_fma(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ V3 axpy_fma(double a, V3 x, V3 y) {
+    return V3{__builtin_fma(a, x.x, y.x), __builtin_fma(a, x.y, y.y), __builtin_fma(a, x.z, y.z)};
+}
+
 // Elimination builds (diagnostic, scripts/elimination.sh): -DPFC_EXP=n compiles one phase of k_narrow out behind a
 // condition the compiler cannot fold, so that timing the variants against each other gives the phase costs including
 // their overlap (results are wrong in these builds).  3: every candidate rejected after the gather; 4: polygons dropped
@@ -520,7 +531,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                     if (reg) {
                         // yes_contact!(::Regularized) (friction.jl:50-72) fused
                         V3 vt = vec_sub_vec_proj(rdot, nh);
-                        double m2 = dot(vt, vt);
+                        double m2 = dot_fma(vt, vt);
                         V3 T;
                         // one division per point where the reference divides the three components (friction.jl:64-68):
                         // last-bit differences only
@@ -536,8 +547,8 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                             const double mu = clamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
                             T = vt * (-(mu * ri));
                         }
-                        const V3 tk = nh * p_dA + T * p_dA;
-                        const V3 ta = cross(r, tk);
+                        const V3 tk = (nh + T) * p_dA;
+                        const V3 ta = cross_fma(r, tk);
                         sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
                         sum[3] += tk.x; sum[4] += tk.y; sum[5] += tk.z;
                     } else {
@@ -549,8 +560,9 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         const V3 rc = r - cen;
                         const double wx = p_dA * rc.x, wy = p_dA * rc.y, wz = p_dA * rc.z;
                         wr1[0] += wx; wr1[1] += wy; wr1[2] += wz;
-                        wrr[0] += wx * rc.x; wrr[1] += wx * rc.y; wrr[2] += wx * rc.z;
-                        wrr[3] += wy * rc.y; wrr[4] += wy * rc.z; wrr[5] += wz * rc.z;
+                        wrr[0] = __builtin_fma(wx, rc.x, wrr[0]); wrr[1] = __builtin_fma(wx, rc.y, wrr[1]);
+                        wrr[2] = __builtin_fma(wx, rc.z, wrr[2]); wrr[3] = __builtin_fma(wy, rc.y, wrr[3]);
+                        wrr[4] = __builtin_fma(wy, rc.z, wrr[4]); wrr[5] = __builtin_fma(wz, rc.z, wrr[5]);
                     }
                 }
             }
@@ -770,17 +782,6 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
 // Bristle friction pass (after k_eig): calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48)
 // over the polygons k_narrow kept.  One lane per kept polygon, every load is a coalesced read of consecutive slots;
 // the fan / quadrature arithmetic is the one of k_narrow, so the traction points are bit-identical.
-// Fused-multiply-add forms of the vector helpers for the friction force, which is compared with the oracle by
-// tolerance (the library is built with -ffp-contract=off because the traction points and every predicate upstream are
-// bit-exact restatements; here an a*b + c*d costs two instructions instead of three).
-__device__ __forceinline__ V3 cross_fma(V3 a, V3 b) {
-    return V3{__builtin_fma(a.y, b.z, -(a.z * b.y)), __builtin_fma(a.z, b.x, -(a.x * b.z)), __builtin_fma(a.x, b.y, -(a.y * b.x))};
-}
-__device__ __forceinline__ double dot_fma(V3 a, V3 b) { return __builtin_fma(a.z, b.z, __builtin_fma(a.y, b.y, a.x * b.x)); }
-__device__ __forceinline__ V3 axpy_fma(double a, V3 x, V3 y) {
-    return V3{__builtin_fma(a, x.x, y.x), __builtin_fma(a, x.y, y.y), __builtin_fma(a, x.z, y.z)};
-}
-
 struct FricArgs {
     const ItemRec *items;
     const int *poly_item;
