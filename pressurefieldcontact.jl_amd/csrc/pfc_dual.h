@@ -25,12 +25,14 @@ __device__ __forceinline__ Du du(double v, double d) { return Du{v, d}; }
 __device__ __forceinline__ Du operator+(Du a, Du b) { return Du{a.v + b.v, a.d + b.d}; }
 __device__ __forceinline__ Du operator-(Du a, Du b) { return Du{a.v - b.v, a.d - b.d}; }
 __device__ __forceinline__ Du operator-(Du a) { return Du{-a.v, -a.d}; }
-__device__ __forceinline__ Du operator*(Du a, Du b) { return Du{a.v * b.v, a.v * b.d + a.d * b.v}; }
+// values: the reference's operations, unfused (they take the same branches as the value pass); partials: fused
+// multiply-adds (compared with the Dual oracle by tolerance; these kernels are bound by Dual arithmetic)
+__device__ __forceinline__ Du operator*(Du a, Du b) { return Du{a.v * b.v, __builtin_fma(a.v, b.d, a.d * b.v)}; }
 __device__ __forceinline__ Du operator*(double a, Du b) { return Du{a * b.v, a * b.d}; }
 __device__ __forceinline__ Du operator*(Du a, double b) { return Du{a.v * b, a.d * b}; }
 __device__ __forceinline__ Du operator/(Du a, Du b) {
     const double q = a.v / b.v;
-    return Du{q, (a.d - q * b.d) / b.v};
+    return Du{q, __builtin_fma(-q, b.d, a.d) / b.v};
 }
 __device__ __forceinline__ Du operator/(Du a, double b) { return Du{a.v / b, a.d / b}; }
 __device__ __forceinline__ Du dsqrt(Du a) {
@@ -38,8 +40,10 @@ __device__ __forceinline__ Du dsqrt(Du a) {
     return Du{s, a.d / (2.0 * s)};
 }
 // muladd(a, x, c) with a constant a
-__device__ __forceinline__ Du dfma(double a, Du x, Du c) { return Du{__builtin_fma(a, x.v, c.v), a * x.d + c.d}; }
-__device__ __forceinline__ Du dfma(Du a, Du x, Du c) { return Du{__builtin_fma(a.v, x.v, c.v), a.v * x.d + a.d * x.v + c.d}; }
+__device__ __forceinline__ Du dfma(double a, Du x, Du c) { return Du{__builtin_fma(a, x.v, c.v), __builtin_fma(a, x.d, c.d)}; }
+__device__ __forceinline__ Du dfma(Du a, Du x, Du c) {
+    return Du{__builtin_fma(a.v, x.v, c.v), __builtin_fma(a.v, x.d, __builtin_fma(a.d, x.v, c.d))};
+}
 __device__ __forceinline__ void operator+=(Du &a, Du b) { a.v += b.v; a.d += b.d; }
 
 struct Du3 { Du x, y, z; };
