@@ -1,0 +1,27 @@
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import helpers as H
+import test_gpu_parity as T
+import pfc_pkg
+pfc = pfc_pkg.load()
+bad = 0
+for seed in range(200, 212):
+    for degenerate in (False, True):
+        for tet_tet in (False, True):
+            rng = np.random.default_rng(seed)
+            w = T._fuzz_workload(pfc, rng, 400, degenerate, tet_tet)
+            m, wrench, sdot, counts = T._eval(pfc, w)
+            ref = H.oracle_run(pfc, w)
+            for k in range(w.n_items):
+                ok = np.array_equal(counts[k], ref[k].counts)
+                if np.linalg.norm(ref[k].wrench) > 0:
+                    ok = ok and H.rel_err(wrench[k], ref[k].wrench) < T.TOL_TIGHT
+                else:
+                    ok = ok and np.linalg.norm(wrench[k]) == 0.0
+                if not ok:
+                    bad += 1
+                    print("MISMATCH", seed, degenerate, tet_tet, k, counts[k], ref[k].counts)
+            m.close()
+    print("seed", seed, "done, mismatches so far", bad, flush=True)
+print("total mismatches", bad)
