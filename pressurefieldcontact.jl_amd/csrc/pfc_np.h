@@ -414,11 +414,14 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             }
             tbase = base + incl - slots;
         }
-        // Slots of the lists this wave will append to at the END of the round are reserved HERE, before the integration:
-        // the returning atomics (~1-2 us each under load) then complete behind ~17 000 cycles of quadrature instead of
-        // stalling the reductions.  What a lane will contribute is not known yet, so the reservation is for every lane
-        // that has a polygon (bristle lanes: a kept-polygon slot; with the Dual list on: a contributing-pair slot) and
-        // for one moment record per run of an item; slots that turn out unused get an empty marker.
+        // Slots of the lists this wave will append to at the END of the round are reserved HERE, before the integration,
+        // with one returning atomic on the counters of this workgroup's list region (pfc_kernels.h, "Region-partitioned
+        // append lists": on a single counter the 60 k atomics of a C3 batch were serialised by the L2 and cost a quarter
+        // of the kernel).  The compiler waits for the result right away, so what is left of its latency (~3 % of the
+        // kernel) is not hidden by the placement; reordering the integration's loads in front of it needs more than
+        // 256 VGPRs.  What a lane will contribute is not known yet, so the reservation is for every lane that has a
+        // polygon (bristle lanes: a kept-polygon slot; with the Dual list on: a contributing-pair slot) and for one
+        // moment record per run of an item; slots that turn out unused get an empty marker.
         const bool has_poly = work && n_poly >= 3;
         const bool polyb = has_poly && !reg;
         const bool polys = has_poly && g.surv != nullptr;
