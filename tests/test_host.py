@@ -299,5 +299,6 @@ def test_c_example_builds_and_refuses_without_gpu(pfc, tmp_path):
 def test_c_example_matches_analytic_normal_wrench(pfc, tmp_path):
     """test/test_normal.jl:2-49 through the C ABI from a C program: exact normal wrench of a box on the half-plane."""
     import subprocess
-    r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([_build_c_example(tmp_path), "200"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "us per pfc_eval" in r.stdout          # the timing loop ran its 200 repeated evaluations without an error
