@@ -93,11 +93,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    # PFC_BENCH_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs than ranks (ranks share the visible GPUs and
+    # the exchange goes through host memory); the measured configuration is nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("PFC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import pfc_pkg
     pfc = pfc_pkg.load()
@@ -137,7 +145,12 @@ def main():
         if world > 1:
             d_out[:, :6] = d_wrench
             d_out[:, 6:] = d_sdot
-            dist.all_gather_into_tensor(gathered, d_out)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, d_out)
+            else:
+                parts_cpu = [torch.empty((n, 12), dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(parts_cpu, d_out.cpu())
+                gathered.copy_(torch.cat(parts_cpu).to(dev))
 
     def fence():
         if world > 1:
@@ -163,6 +176,8 @@ def main():
     tot = torch.tensor([float(st["candidates"]), float(n), float(st["node_tests"]), float(st["tractions"])],
                        dtype=torch.float64, device=dev)
     if world > 1:
+        if backend != "nccl":
+            t, tot = t.cpu(), tot.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt = float(t.item())
@@ -231,7 +246,8 @@ def main():
                                    f"{args.poses} Monte-Carlo poses per GPU per step",
                        "poses_per_gpu": args.poses, "ops_per_step": ops_step, "node_tests_per_step": nodes_step,
                        "traction_points_per_step": trac_step,
-                       "exchange": "RCCL all-gather of [wrench, sdot] per item" if world > 1 else "none"},
+                       "exchange": ("none" if world == 1 else "RCCL all-gather of [wrench, sdot] per item" if backend == "nccl"
+                                    else f"REHEARSAL ({backend}, ranks share GPUs): all-gather through host memory")},
             "contact_pairs_per_s": items_step * K / dt,
             "node_tests_per_s": nodes_step * K / dt,
             "stage_ms_per_step": {k: v / K for k, v in stage.items()},
