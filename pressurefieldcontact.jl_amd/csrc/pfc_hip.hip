@@ -199,6 +199,9 @@ struct pfc_context {
     size_t h_tail_cap = 0;
     void *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-buffer path
     size_t pin_in_cap = 0, pin_out_cap = 0;
+    void *pin_din = nullptr, *pin_dout = nullptr; // pinned blocks of the small-scene Dual path (partials in / out)
+    size_t pin_din_cap = 0, pin_dout_cap = 0;
+    long long dual_hint = -1;                     // contributing pairs of the last Dual evaluation (-1: none yet)
     unsigned long long epoch = 0;        // bumped whenever a device work buffer is reallocated
     // captured launch sequence (hipGraph) of the last evaluation shape
     hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [0] plain evaluation, [1] with the contributing-pair list (Dual)
@@ -649,6 +652,8 @@ void pfc_destroy(pfc_handle h) {
     if (h->h_tail) (void)hipHostFree(h->h_tail);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->pin_din) (void)hipHostFree(h->pin_din);
+    if (h->pin_dout) (void)hipHostFree(h->pin_dout);
     h->tail.release();
     h->rgn.release(); h->poly_item.release(); h->poly.release(); h->surv.release(); h->scat_d.release(); h->scat_i.release();
     h->dual_poly.release(); h->dual_pkey.release();
@@ -983,6 +988,118 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     return PFC_OK;
 }
 
+namespace {
+hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes) {
+    if (*cap >= bytes) return hipSuccess;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr; *cap = 0;
+    hipError_t e = hipHostMalloc(p, bytes * 2);
+    if (e == hipSuccess) *cap = bytes * 2;
+    return e;
+}
+
+// The Dual passes of one evaluation on stream st.  tail: the packed tail of the value pass (device-visible), dp/dt/dsd
+// and dw/dsdot: seeds and results (device-visible), n_pairs_bound: upper bound of the contributing pairs used to size
+// the kept Dual polygons (the kernels take the actual count from the tail and guard against the capacity).
+int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const double *dp, const double *dt,
+                const double *dsd, double *dw, double *dsdot, size_t n_pairs_bound, hipStream_t st, size_t *dpcap_out) {
+    const size_t nk = (size_t)n_items * n_dir;
+    HIP_TRY(h, h->dual_acc.ensure(nk * kDaStride));
+    HIP_TRY(h, h->dual_res.ensure(nk * kDrStride));
+    HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
+    DualArgs a;
+    a.items = h->items.p; a.cand = h->cand.p; a.ccount = tail + 12; a.ccap = (int)h->ccap;   // packed copy of the counters
+    a.surv = h->surv.p; a.scount = tail + 12 + (((h->last_levels + 9) & ~1) + 1);
+    a.n_items = n_items; a.n_dir = n_dir; a.d_pose = dp; a.d_twist = dt; a.d_s = dsd; a.icnt = h->icnt.p;
+    a.dacc = h->dual_acc.p; a.dres = h->dual_res.p; a.d_wrench = dw; a.d_sdot = dsdot;
+    a.status = h->status.p;
+    const int cpw = 64 / n_dir;
+    const int grid = grid_for((n_pairs_bound + cpw - 1) / cpw, 1, 256 * 16);
+    const int kgrid = grid_for(nk, 64, 1 << 20);
+    const bool tt = h->any_tet_tet;
+    // Dual polygons kept between the passes: a wave of k_narrow_dual owns 64 consecutive slots (no slot counter)
+    const size_t dpcap = h->any_bristle ? ((n_pairs_bound + cpw - 1) / cpw) * 64 + 64 : 64;   // 64 slots per group of cpw pairs
+    HIP_TRY(h, h->dual_poly.ensure(dpcap * kDpFields));
+    HIP_TRY(h, h->dual_pkey.ensure(dpcap));
+    a.dpoly = h->dual_poly.p; a.dpoly_key = h->dual_pkey.p; a.dpcap = (long long)dpcap;
+    if (dpcap_out) *dpcap_out = dpcap;
+    if (tt) hipLaunchKernelGGL((k_narrow_dual<true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+    else hipLaunchKernelGGL((k_narrow_dual<false>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+    if (h->any_bristle) {
+        const int pgrid = grid_for(dpcap, 64, 256 * 16);
+        hipLaunchKernelGGL((k_dual_poly<1>), dim3(pgrid), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_dual_eig, dim3((unsigned)nk), dim3(64), 0, st, a);   // one wave per (item, direction)
+        hipLaunchKernelGGL((k_dual_poly<2>), dim3(pgrid), dim3(64), 0, st, a);
+    }
+    hipLaunchKernelGGL(k_dual_final, dim3(kgrid), dim3(64), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
+    return PFC_OK;
+}
+
+// Small scenes (what Radau evaluates): value pass and Dual passes enqueued back to back, ONE synchronisation, no
+// staging copies (the kernels read and write the pinned blocks), the kept Dual polygons sized from the previous Dual
+// evaluation's pair count.  Returns PFC_ERR_OVERFLOW when the speculation or a work list fell short: the caller then
+// takes the two-stage path, which sizes everything from the value pass.
+int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, const double *pose, const double *twist,
+                    const double *s, const double *d_pose, const double *d_twist, const double *d_s, double *wrench,
+                    double *sdot, double *d_wrench, double *d_sdot, int *counts) {
+    const size_t n = (size_t)n_items, nk = n * n_dir;
+    const size_t in_d = n * 36, in_bytes = in_d * sizeof(double) + n * sizeof(int);
+    const size_t out_d = n * 12, out_bytes = out_d * sizeof(double) + n * 4 * sizeof(int);
+    const size_t t0 = (((size_t)h->max_levels + 40) + 3) & ~(size_t)3;
+    const size_t back_bytes = t0 * sizeof(int) + out_bytes;
+    HIP_TRY(h, ensure_pinned(&h->pin_in, &h->pin_in_cap, in_bytes));
+    HIP_TRY(h, ensure_pinned(&h->pin_out, &h->pin_out_cap, back_bytes));
+    HIP_TRY(h, ensure_pinned(&h->pin_din, &h->pin_din_cap, sizeof(double) * nk * 36));
+    HIP_TRY(h, ensure_pinned(&h->pin_dout, &h->pin_dout_cap, sizeof(double) * nk * 12));
+    double *pi = (double *)h->pin_in;
+    std::memcpy(pi, pose, sizeof(double) * n * 24);
+    std::memcpy(pi + n * 24, twist, sizeof(double) * n * 6);
+    if (s) std::memcpy(pi + n * 30, s, sizeof(double) * n * 6); else std::memset(pi + n * 30, 0, sizeof(double) * n * 6);
+    if (ins_ids) std::memcpy(pi + in_d, ins_ids, sizeof(int) * n);
+    double *pdi = (double *)h->pin_din;
+    std::memcpy(pdi, d_pose, sizeof(double) * nk * 24);
+    std::memcpy(pdi + nk * 24, d_twist, sizeof(double) * nk * 6);
+    if (d_s) std::memcpy(pdi + nk * 30, d_s, sizeof(double) * nk * 6); else std::memset(pdi + nk * 30, 0, sizeof(double) * nk * 6);
+    void *v_in = nullptr, *v_out = nullptr, *v_din = nullptr, *v_dout = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer(&v_in, h->pin_in, 0));
+    HIP_TRY(h, hipHostGetDevicePointer(&v_out, h->pin_out, 0));
+    HIP_TRY(h, hipHostGetDevicePointer(&v_din, h->pin_din, 0));
+    HIP_TRY(h, hipHostGetDevicePointer(&v_dout, h->pin_dout, 0));
+    double *di = (double *)v_in, *dout = reinterpret_cast<double *>((int *)v_out + t0);
+    hipStream_t st = h->stream;
+    h->want_surv = true;
+    h->tail_dev = (int *)v_out;
+    int rc = pfc_eval_device(h, n_items, ins_ids ? (const int *)(di + in_d) : nullptr, di, di + n * 24,
+                             s ? di + n * 30 : nullptr, dout, dout + n * 6, (int *)(dout + out_d), st);
+    h->want_surv = false;
+    h->tail_dev = nullptr;
+    if (rc != PFC_OK) return rc;
+    size_t dpcap = 0;
+    const size_t bound = (size_t)h->dual_hint * 2 + 64;
+    double *ddi = (double *)v_din, *ddo = (double *)v_dout;
+    rc = launch_dual(h, n_items, n_dir, (const int *)v_out, ddi, ddi + nk * 24, ddi + nk * 30, ddo, ddo + nk * 6, bound, st, &dpcap);
+    if (rc != PFC_OK) { (void)hipStreamSynchronize(st); h->pending = false; return rc; }
+    h->tail_host = (const int *)h->pin_out;
+    rc = check_eval(h);                 // the one synchronisation; grows the work lists on overflow
+    h->tail_host = nullptr;
+    if (rc != PFC_OK) return rc;
+    // did the kept Dual polygons fit?  (contributing pairs: the counter next to the polygon total in the packed tail)
+    const int *tail = (const int *)h->pin_out;
+    const long long pairs = tail[12 + (((h->last_levels + 9) & ~1) + 1)];
+    const int cpw = 64 / n_dir;
+    h->dual_hint = pairs;
+    if (h->any_bristle && (size_t)((pairs + cpw - 1) / cpw) * 64 + 64 > dpcap) return PFC_ERR_OVERFLOW;
+    const double *po = reinterpret_cast<const double *>((const int *)h->pin_out + t0);
+    std::memcpy(wrench, po, sizeof(double) * n * 6);
+    std::memcpy(sdot, po + n * 6, sizeof(double) * n * 6);
+    if (counts) std::memcpy(counts, po + out_d, sizeof(int) * n * 4);
+    std::memcpy(d_wrench, h->pin_dout, sizeof(double) * nk * 6);
+    std::memcpy(d_sdot, (const double *)h->pin_dout + nk * 6, sizeof(double) * nk * 6);
+    return PFC_OK;
+}
+}  // namespace
+
 int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, const double *pose, const double *twist,
                   const double *s, const double *d_pose, const double *d_twist, const double *d_s, double *wrench,
                   double *sdot, double *d_wrench, double *d_sdot, int *counts) {
@@ -990,6 +1107,13 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     if (n_dir < 1 || n_dir > 16) return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: n_dir must be in 1..16");
     if (n_items > 0 && (!d_pose || !d_twist || !d_wrench || !d_sdot))
         return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: null buffer");
+    if (h->finalized && n_items > 0 && (size_t)n_items * n_dir <= 512 && h->dual_hint >= 0 && pose && twist &&
+        wrench && sdot && !h->opt_debug && !(h->opt_split_min > 0 && n_items >= h->opt_split_min)) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        const int rc_small = eval_dual_small(h, n_items, n_dir, ins_ids, pose, twist, s, d_pose, d_twist, d_s, wrench, sdot,
+                                             d_wrench, d_sdot, counts);
+        if (rc_small != PFC_ERR_OVERFLOW) return rc_small;    // else: lists grown / speculation short -> two-stage path
+    }
     // values, candidate list and per-item counters: the ordinary evaluation (the broadphase ignores partials,
     // src/contact_algorithms_non_friction.jl:95)
     h->want_surv = true;
@@ -1026,33 +1150,9 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
         else std::memset(pi + nk * 30, 0, sizeof(double) * nk * 6);
         HIP_TRY(h, hipMemcpyAsync(dp, pi, in_bytes, hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
-    DualArgs a;
-    a.items = h->items.p; a.cand = h->cand.p; a.ccount = h->tail.p + 12; a.ccap = (int)h->ccap;   // packed copy of the counters
-    a.surv = h->surv.p; a.scount = h->tail.p + 12 + (((h->last_levels + 9) & ~1) + 1);
-    a.n_items = n_items; a.n_dir = n_dir; a.d_pose = dp; a.d_twist = dt; a.d_s = dsd; a.icnt = h->icnt.p;
-    a.dacc = h->dual_acc.p; a.dres = h->dual_res.p; a.d_wrench = h->dual_out.p; a.d_sdot = h->dual_out.p + nk * 6;
-    a.status = h->status.p;
-    const int cpw = 64 / n_dir;
-    const size_t n_cand = (size_t)h->stats[2];   // contributing pairs <= pairs with a non-empty polygon
-    const int grid = grid_for((n_cand + cpw - 1) / cpw, 1, 256 * 16);
-    const int kgrid = grid_for(nk, 64, 1 << 20);
-    const bool tt = h->any_tet_tet;
-    // Dual polygons kept between the passes: a wave of k_narrow_dual owns 64 consecutive slots (no slot counter)
-    const size_t dpcap = h->any_bristle ? ((n_cand + cpw - 1) / cpw) * 64 + 64 : 64;   // 64 slots per group of cpw pairs
-    HIP_TRY(h, h->dual_poly.ensure(dpcap * kDpFields));
-    HIP_TRY(h, h->dual_pkey.ensure(dpcap));
-    a.dpoly = h->dual_poly.p; a.dpoly_key = h->dual_pkey.p; a.dpcap = (long long)dpcap;
-    if (tt) hipLaunchKernelGGL((k_narrow_dual<true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
-    else hipLaunchKernelGGL((k_narrow_dual<false>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
-    if (h->any_bristle) {
-        const int pgrid = grid_for(dpcap, 64, 256 * 16);
-        hipLaunchKernelGGL((k_dual_poly<1>), dim3(pgrid), dim3(64), 0, st, a);
-        hipLaunchKernelGGL(k_dual_eig, dim3((unsigned)nk), dim3(64), 0, st, a);   // one wave per (item, direction)
-        hipLaunchKernelGGL((k_dual_poly<2>), dim3(pgrid), dim3(64), 0, st, a);
-    }
-    hipLaunchKernelGGL(k_dual_final, dim3(kgrid), dim3(64), 0, st, a);
-    HIP_TRY(h, hipGetLastError());
+    rc = launch_dual(h, n_items, n_dir, h->tail.p, dp, dt, dsd, h->dual_out.p, h->dual_out.p + nk * 6, (size_t)h->stats[2], st, nullptr);
+    if (rc != PFC_OK) return rc;
+    h->dual_hint = h->stats[2];
     HIP_TRY(h, hipMemcpyAsync(h->pin_out, h->dual_out.p, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     std::memcpy(d_wrench, h->pin_out, sizeof(double) * nk * 6);
