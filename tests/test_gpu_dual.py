@@ -104,3 +104,45 @@ def test_dual_bad_arguments(pfc):
         m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, np.zeros((n, 17, 24)), np.zeros((n, 17, 6)), None,
                                                w.ins_ids)
     m.close()
+
+
+def test_dual_small_scene_path_and_its_fallback(pfc):
+    """Scenes of <= 512 (item, direction) pairs take a one-synchronisation path from the second Dual evaluation of a
+    handle on (value and Dual passes back to back, kept Dual polygons sized from the previous evaluation's pair count).
+    It must reproduce the two-stage path (what a fresh handle runs), also when the pair count jumps past the
+    speculative size (barely touching -> deep contact), and when it drops again."""
+    rng = np.random.default_rng(11)
+    w = pfc.configs.c3_blob_tool(8, seed=5, n_div_blob=6, n_div_tool=4)
+    n, nd = w.n_items, 6
+    w.s[:] = rng.standard_normal((n, 6)) * 1e-3
+    d_pose = rng.standard_normal((n, nd, 24)) * 1e-2
+    d_twist = rng.standard_normal((n, nd, 6)) * 0.1
+    d_s = rng.standard_normal((n, nd, 6)) * 1e-3
+
+    def shifted(scale):
+        # move the tool along the centre line: scale < 1 deepens the contact, > 1 leaves only a grazing one
+        p = w.pose.copy()
+        R21 = p[:, :9].reshape(n, 3, 3).transpose(0, 2, 1)        # column-major -> R
+        p[:, 9:12] *= scale
+        t12 = -np.einsum("nji,nj->ni", R21, p[:, 9:12])             # x_r1_r2 = inverse of x_r2_r1
+        p[:, 21:24] = t12
+        return p
+
+    def fresh(pose):
+        f = pfc.configs.build_scenario(w)
+        out = f.force_all_elastic_intersections_dual(pose, w.twist, w.s, d_pose, d_twist, d_s, w.ins_ids)
+        f.close()
+        return out
+
+    m = pfc.configs.build_scenario(w)
+    pairs = []
+    for scale in (1.045, 1.045, 0.97, 1.0, 1.045, 0.97):   # graze (two-stage), graze (fast), deep (miss -> fallback), ...
+        pose = shifted(scale)
+        got = m.force_all_elastic_intersections_dual(pose, w.twist, w.s, d_pose, d_twist, d_s, w.ins_ids)
+        ref = fresh(pose)
+        assert np.array_equal(got[4], ref[4]), scale
+        pairs.append(int(got[4][:, 2].sum()))
+        for a, b, tol in ((got[0], ref[0], 1e-11), (got[1], ref[1], 1e-7), (got[2], ref[2], 1e-9), (got[3], ref[3], 1e-6)):
+            np.testing.assert_allclose(a, b, rtol=tol, atol=tol * max(np.abs(b).max(), 1e-300), err_msg=str(scale))
+    m.close()
+    assert pairs[2] > 2 * pairs[1] + 64 > 64, pairs      # the deep contact really overshoots the speculative size
