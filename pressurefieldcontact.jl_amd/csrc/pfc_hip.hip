@@ -212,6 +212,10 @@ struct pfc_context {
         unsigned long long epoch;
     } gkey[2] = {};
     bool ghave[2] = {false, false};
+    // value pass + Dual passes of a small scene as ONE graph (eval_dual_small)
+    hipGraphExec_t dgexec = nullptr;
+    struct DualGraphKey { GraphKey v; int n_dir; size_t bound; const void *din, *dout; } dgkey = {};
+    bool dghave = false;
     bool want_surv = false;   // the narrowphase also lists the contributing candidates (pfc_eval_dual)
     int opt_graph = 1;
     size_t fcap = 0, ccap = 0, tcap = 0, rcap = 0;
@@ -649,6 +653,7 @@ void pfc_destroy(pfc_handle h) {
         if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (int gi = 0; gi < 2; ++gi)
         if (h->gexec[gi]) (void)hipGraphExecDestroy(h->gexec[gi]);
+    if (h->dgexec) (void)hipGraphExecDestroy(h->dgexec);
     if (h->h_tail) (void)hipHostFree(h->h_tail);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -1002,11 +1007,12 @@ hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes) {
 // and dw/dsdot: seeds and results (device-visible), n_pairs_bound: upper bound of the contributing pairs used to size
 // the kept Dual polygons (the kernels take the actual count from the tail and guard against the capacity).
 int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const double *dp, const double *dt,
-                const double *dsd, double *dw, double *dsdot, size_t n_pairs_bound, hipStream_t st, size_t *dpcap_out) {
+                const double *dsd, double *dw, double *dsdot, size_t n_pairs_bound, hipStream_t st, size_t *dpcap_out,
+                bool acc_cleared = false) {
     const size_t nk = (size_t)n_items * n_dir;
     HIP_TRY(h, h->dual_acc.ensure(nk * kDaStride));
     HIP_TRY(h, h->dual_res.ensure(nk * kDrStride));
-    HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
+    if (!acc_cleared) HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
     DualArgs a;
     a.items = h->items.p; a.cand = h->cand.p; a.ccount = tail + 12; a.ccap = (int)h->ccap;   // packed copy of the counters
     a.surv = h->surv.p; a.scount = tail + 12 + (((h->last_levels + 9) & ~1) + 1);
@@ -1068,18 +1074,58 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     HIP_TRY(h, hipHostGetDevicePointer(&v_dout, h->pin_dout, 0));
     double *di = (double *)v_in, *dout = reinterpret_cast<double *>((int *)v_out + t0);
     hipStream_t st = h->stream;
+    // One captured graph: accumulator fill, the value pass, the Dual passes.  (Launched eagerly behind the replayed value
+    // graph, the Dual kernels started 9 us late.)  The capacity of the kept Dual polygons is a power of two above twice
+    // the previous pair count, so that the graph survives the small changes from one evaluation to the next.
+    size_t bound = 64;
+    while (bound < (size_t)h->dual_hint * 2 + 64) bound *= 2;
+    const int cpw = 64 / n_dir;
+    HIP_TRY(h, ensure_work(h, n_items));
+    HIP_TRY(h, h->dual_acc.ensure(nk * kDaStride));
+    HIP_TRY(h, h->dual_res.ensure(nk * kDrStride));
+    const size_t dpcap = h->any_bristle ? ((bound + cpw - 1) / cpw) * 64 + 64 : 64;
+    HIP_TRY(h, h->dual_poly.ensure(dpcap * kDpFields));
+    HIP_TRY(h, h->dual_pkey.ensure(dpcap));
+    const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
+    const int L = bfs_levels_for(h, n_items, levels);
+    double *ddi = (double *)v_din, *ddo = (double *)v_dout;
+    const int *d_ins = ins_ids ? (const int *)(di + in_d) : nullptr;
+    const double *d_sv = s ? di + n * 30 : nullptr;
+    pfc_context::DualGraphKey key = {};
+    key.v.n_items = n_items; key.v.levels = levels; key.v.L = L; key.v.debug = 0;
+    key.v.bristle = (h->any_bristle ? 1 : 0) | (h->any_tet_tet ? 2 : 0); key.v.surv = 1;
+    key.v.p[0] = d_ins; key.v.p[1] = di; key.v.p[2] = di + n * 24; key.v.p[3] = d_sv; key.v.p[4] = dout;
+    key.v.p[5] = dout + n * 6; key.v.p[6] = dout + out_d; key.v.p[7] = v_out; key.v.stream = (void *)st; key.v.epoch = h->epoch;
+    key.n_dir = n_dir; key.bound = bound; key.din = v_din; key.dout = v_dout;
     h->want_surv = true;
     h->tail_dev = (int *)v_out;
-    int rc = pfc_eval_device(h, n_items, ins_ids ? (const int *)(di + in_d) : nullptr, di, di + n * 24,
-                             s ? di + n * 30 : nullptr, dout, dout + n * 6, (int *)(dout + out_d), st);
-    h->want_surv = false;
-    h->tail_dev = nullptr;
-    if (rc != PFC_OK) return rc;
-    size_t dpcap = 0;
-    const size_t bound = (size_t)h->dual_hint * 2 + 64;
-    double *ddi = (double *)v_din, *ddo = (double *)v_dout;
-    rc = launch_dual(h, n_items, n_dir, (const int *)v_out, ddi, ddi + nk * 24, ddi + nk * 30, ddo, ddo + nk * 6, bound, st, &dpcap);
-    if (rc != PFC_OK) { (void)hipStreamSynchronize(st); h->pending = false; return rc; }
+    h->last_levels = levels;      // launch_dual locates the pair counter in the tail by it
+    int rc = PFC_OK;
+    if (!h->dghave || std::memcmp(&key, &h->dgkey, sizeof key) != 0) {
+        if (h->dgexec) { (void)hipGraphExecDestroy(h->dgexec); h->dgexec = nullptr; }
+        h->dghave = false;
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            e = hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st);
+            rc = record_eval(h, n_items, d_ins, di, di + n * 24, d_sv, dout, dout + n * 6, (int *)(dout + out_d), st, false);
+            if (rc == PFC_OK)
+                rc = launch_dual(h, n_items, n_dir, (const int *)v_out, ddi, ddi + nk * 24, ddi + nk * 30, ddo, ddo + nk * 6, bound,
+                                 st, nullptr, true);
+            const hipError_t e2 = hipStreamEndCapture(st, &graph);
+            if (e == hipSuccess) e = e2;
+        }
+        if (rc == PFC_OK && e == hipSuccess) e = hipGraphInstantiate(&h->dgexec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        h->want_surv = false; h->tail_dev = nullptr;
+        if (rc != PFC_OK) return rc;
+        if (e != hipSuccess) return fail(h, PFC_ERR_HIP, "Dual graph capture failed: %s", hipGetErrorString(e));
+        h->dgkey = key; h->dghave = true;
+    }
+    h->want_surv = false; h->tail_dev = nullptr;
+    HIP_TRY(h, hipGraphLaunch(h->dgexec, st));
+    h->last_bfs_levels = L; h->last_n_items = n_items; h->pending = true; h->last_stream = st; h->ev_valid = false;
+    h->split_n0 = 0;
     h->tail_host = (const int *)h->pin_out;
     rc = check_eval(h);                 // the one synchronisation; grows the work lists on overflow
     h->tail_host = nullptr;
@@ -1087,7 +1133,6 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     // did the kept Dual polygons fit?  (contributing pairs: the counter next to the polygon total in the packed tail)
     const int *tail = (const int *)h->pin_out;
     const long long pairs = tail[12 + (((h->last_levels + 9) & ~1) + 1)];
-    const int cpw = 64 / n_dir;
     h->dual_hint = pairs;
     if (h->any_bristle && (size_t)((pairs + cpw - 1) / cpw) * 64 + 64 > dpcap) return PFC_ERR_OVERFLOW;
     const double *po = reinterpret_cast<const double *>((const int *)h->pin_out + t0);
@@ -1168,7 +1213,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "bfs_levels")) h->opt_bfs_levels = (int)value;
     else if (!std::strcmp(name, "graph")) h->opt_graph = value != 0;
     else if (!std::strcmp(name, "split_min")) h->opt_split_min = (int)value;
-    else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; }
+    else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;
 }
