@@ -1088,7 +1088,14 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     HIP_TRY(h, h->dual_pkey.ensure(dpcap));
     const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
     const int L = bfs_levels_for(h, n_items, levels);
-    double *ddi = (double *)v_din, *ddo = (double *)v_dout;
+    // seeds / results of up to 512 (item, direction) pairs are read / written in place by the kernels; larger ones are
+    // copied by memcpy nodes of the graph (reading 288 B per pair over PCIe from inside k_narrow_dual stops paying)
+    const bool zc_dual = nk <= 512;
+    if (!zc_dual) {
+        HIP_TRY(h, h->dual_in.ensure(nk * 36));
+        HIP_TRY(h, h->dual_out.ensure(nk * 12));
+    }
+    double *ddi = zc_dual ? (double *)v_din : h->dual_in.p, *ddo = zc_dual ? (double *)v_dout : h->dual_out.p;
     const int *d_ins = ins_ids ? (const int *)(di + in_d) : nullptr;
     const double *d_sv = s ? di + n * 30 : nullptr;
     pfc_context::DualGraphKey key = {};
@@ -1096,7 +1103,7 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     key.v.bristle = (h->any_bristle ? 1 : 0) | (h->any_tet_tet ? 2 : 0); key.v.surv = 1;
     key.v.p[0] = d_ins; key.v.p[1] = di; key.v.p[2] = di + n * 24; key.v.p[3] = d_sv; key.v.p[4] = dout;
     key.v.p[5] = dout + n * 6; key.v.p[6] = dout + out_d; key.v.p[7] = v_out; key.v.stream = (void *)st; key.v.epoch = h->epoch;
-    key.n_dir = n_dir; key.bound = bound; key.din = v_din; key.dout = v_dout;
+    key.n_dir = n_dir; key.bound = bound; key.din = ddi; key.dout = ddo;
     h->want_surv = true;
     h->tail_dev = (int *)v_out;
     h->last_levels = levels;      // launch_dual locates the pair counter in the tail by it
@@ -1108,10 +1115,13 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
             e = hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st);
+            if (!zc_dual && e == hipSuccess) e = hipMemcpyAsync(ddi, h->pin_din, sizeof(double) * nk * 36, hipMemcpyHostToDevice, st);
             rc = record_eval(h, n_items, d_ins, di, di + n * 24, d_sv, dout, dout + n * 6, (int *)(dout + out_d), st, false);
             if (rc == PFC_OK)
                 rc = launch_dual(h, n_items, n_dir, (const int *)v_out, ddi, ddi + nk * 24, ddi + nk * 30, ddo, ddo + nk * 6, bound,
                                  st, nullptr, true);
+            if (!zc_dual && rc == PFC_OK && e == hipSuccess)
+                e = hipMemcpyAsync(h->pin_dout, ddo, sizeof(double) * nk * 12, hipMemcpyDeviceToHost, st);
             const hipError_t e2 = hipStreamEndCapture(st, &graph);
             if (e == hipSuccess) e = e2;
         }
@@ -1152,7 +1162,7 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     if (n_dir < 1 || n_dir > 16) return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: n_dir must be in 1..16");
     if (n_items > 0 && (!d_pose || !d_twist || !d_wrench || !d_sdot))
         return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: null buffer");
-    if (h->finalized && n_items > 0 && (size_t)n_items * n_dir <= 512 && h->dual_hint >= 0 && pose && twist &&
+    if (h->finalized && n_items > 0 && n_items <= 512 && (size_t)n_items * n_dir <= 4096 && h->dual_hint >= 0 && pose && twist &&
         wrench && sdot && !h->opt_debug && !(h->opt_split_min > 0 && n_items >= h->opt_split_min)) {
         HIP_TRY(h, hipSetDevice(h->device));
         const int rc_small = eval_dual_small(h, n_items, n_dir, ins_ids, pose, twist, s, d_pose, d_twist, d_s, wrench, sdot,

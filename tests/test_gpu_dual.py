@@ -146,3 +146,28 @@ def test_dual_small_scene_path_and_its_fallback(pfc):
             np.testing.assert_allclose(a, b, rtol=tol, atol=tol * max(np.abs(b).max(), 1e-300), err_msg=str(scale))
     m.close()
     assert pairs[2] > 2 * pairs[1] + 64 > 64, pairs      # the deep contact really overshoots the speculative size
+
+
+def test_dual_one_graph_path_with_copied_seeds(pfc):
+    """Between 513 and 4096 (item, direction) pairs the one-graph Dual path copies seeds and results with memcpy nodes
+    instead of reading them in place: 120 scenes x 6 directions, second and third evaluation of a handle against a
+    fresh handle (which runs the two-stage path)."""
+    rng = np.random.default_rng(21)
+    w = pfc.configs.c2_box_on_plane(120, montecarlo=True)
+    n, nd = w.n_items, 6
+    d_pose = rng.standard_normal((n, nd, 24)) * 1e-2
+    d_twist = rng.standard_normal((n, nd, 6)) * 0.1
+    d_s = np.zeros((n, nd, 6))
+    f = pfc.configs.build_scenario(w)
+    ref = f.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, d_pose, d_twist, d_s, w.ins_ids)
+    f.close()
+    m = pfc.configs.build_scenario(w)
+    for rep in range(3):
+        got = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, d_pose * (1.0 if rep < 2 else 2.0), d_twist, d_s, w.ins_ids)
+        assert np.array_equal(got[4], ref[4])
+        np.testing.assert_allclose(got[0], ref[0], rtol=1e-11, atol=1e-11 * np.abs(ref[0]).max())
+        if rep < 2:
+            np.testing.assert_allclose(got[2], ref[2], rtol=1e-9, atol=1e-9 * np.abs(ref[2]).max())
+        else:   # linear in the seeds: doubling d_pose (with the same d_twist) changes the partials, not the values
+            assert np.abs(got[2] - ref[2]).max() > 1e-6 * np.abs(ref[2]).max()
+    m.close()
