@@ -90,26 +90,27 @@ __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
             int pos = base + 2 * prefix_count(m2) + 4 * prefix_count(m4);
             int nout = two ? 2 : (four ? 4 : 0);
             if (nout) {
-                if (pos + nout <= g.fcap) {
-                    WorkRec c;
-                    c.item = w.item;
-                    if (two) {
-                        if (la) {  // leaf_1: descend tree_2 (:97-98)
-                            c.a = w.a; c.b = cb0; c.pad = 1 | fb0; g.fout[pos] = c;
-                            c.b = cb1; c.pad = 1 | fb1; g.fout[pos + 1] = c;
-                        } else {   // leaf_2: descend tree_1 (:101-103)
-                            c.b = w.b; c.a = ca0; c.pad = fa0 | 2; g.fout[pos] = c;
-                            c.a = ca1; c.pad = fa1 | 2; g.fout[pos + 1] = c;
-                        }
-                    } else {       // (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107)
-                        c.a = ca0; c.b = cb0; c.pad = fa0 | fb0; g.fout[pos] = c;
-                        c.a = ca1; c.b = cb0; c.pad = fa1 | fb0; g.fout[pos + 1] = c;
-                        c.a = ca0; c.b = cb1; c.pad = fa0 | fb1; g.fout[pos + 2] = c;
-                        c.a = ca1; c.b = cb1; c.pad = fa1 | fb1; g.fout[pos + 3] = c;
+                // entries are stored one by one up to the capacity: a skipped slot below it would be read by the next
+                // level as whatever the buffer held before (wild item / node indices)
+                WorkRec c[4];
+                for (int k = 0; k < 4; ++k) { c[k].item = w.item; c[k].a = w.a; c[k].b = w.b; c[k].pad = 0; }
+                if (two) {
+                    if (la) {  // leaf_1: descend tree_2 (:97-98)
+                        c[0].b = cb0; c[0].pad = 1 | fb0;
+                        c[1].b = cb1; c[1].pad = 1 | fb1;
+                    } else {   // leaf_2: descend tree_1 (:101-103)
+                        c[0].a = ca0; c[0].pad = fa0 | 2;
+                        c[1].a = ca1; c[1].pad = fa1 | 2;
                     }
-                } else {
-                    atomicOr(g.status, kStFrontierOvf);
+                } else {       // (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107)
+                    c[0].a = ca0; c[0].b = cb0; c[0].pad = fa0 | fb0;
+                    c[1].a = ca1; c[1].b = cb0; c[1].pad = fa1 | fb0;
+                    c[2].a = ca0; c[2].b = cb1; c[2].pad = fa0 | fb1;
+                    c[3].a = ca1; c[3].b = cb1; c[3].pad = fa1 | fb1;
                 }
+                for (int k = 0; k < 4; ++k)
+                    if (k < nout && pos + k < g.fcap) g.fout[pos + k] = c[k];
+                if (pos + nout > g.fcap) atomicOr(g.status, kStFrontierOvf);
             }
         }
     }
@@ -333,15 +334,17 @@ __device__ __forceinline__ void flush_candidates(const Dfs32Args &g, const int2 
     if (tid == 0) *s_base = atomicAdd(g.ccount, n_out);
     __syncthreads();
     const int base = *s_base;
-    if (base + n_out <= g.ccap) {
-        for (int j = tid; j < n_out; j += kDfsBlock) {
+    // On overflow the part of the run that still fits IS written: the narrowphase of an overflowing evaluation runs
+    // over the first ccap slots (its results are discarded, the evaluation is re-issued with a longer list), and a
+    // slot skipped here would hand it whatever the freshly allocated buffer held -- wild item / element indices.
+    for (int j = tid; j < n_out; j += kDfsBlock) {
+        if (base + j < g.ccap) {
             WorkRec c;
             c.item = item; c.a = ob[j].x; c.b = ob[j].y; c.pad = 0;
             g.cand[base + j] = c;
         }
-    } else if (tid == 0) {
-        atomicOr(g.status, kStCandOvf);
     }
+    if (tid == 0 && base + n_out > g.ccap) atomicOr(g.status, kStCandOvf);
     __syncthreads();
 }
 
@@ -636,15 +639,14 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
                 int base = 0;
                 if (lane == 0) base = atomicAdd(g.ccount, n_out);
                 base = __shfl(base, 0, 64);
-                if (base + n_out <= g.ccap) {
-                    for (int j = lane; j < n_out; j += 64) {
+                for (int j = lane; j < n_out; j += 64) {      // partial runs are written on overflow (see flush_candidates)
+                    if (base + j < g.ccap) {
                         WorkRec c;
                         c.item = item; c.a = ob[j].x; c.b = ob[j].y; c.pad = 0;
                         g.cand[base + j] = c;
                     }
-                } else if (lane == 0) {
-                    atomicOr(g.status, kStCandOvf);
                 }
+                if (lane == 0 && base + n_out > g.ccap) atomicOr(g.status, kStCandOvf);
                 n_cand += n_out;
                 n_out = 0;
                 __syncthreads();

@@ -147,6 +147,9 @@ struct DevBuf {
         p = nullptr; cap = 0;
         hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
         if (e == hipSuccess) cap = n;
+        if (std::getenv("PFC_LOG_ALLOC"))      // diagnostic: match a faulting address with the buffer it lies behind
+            std::fprintf(stderr, "pfc alloc %p .. %p (%zu bytes, element %zu)\n", (void *)p, (void *)((char *)p + n * sizeof(T)),
+                         n * sizeof(T), sizeof(T));
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -610,6 +613,17 @@ int make_twin(pfc_context *h) {
 // =================================================================================================================
 // C ABI
 // =================================================================================================================
+// The one-graph Dual path replays kernels with the addresses of the dual_* buffers baked in: a reallocation anywhere
+// (also by the two-stage path, which sizes them from the value pass) must invalidate that graph, i.e. bump the epoch
+// that is part of its key.
+template <class T>
+hipError_t ensure_dual(pfc_context *h, DevBuf<T> &b, size_t n) {
+    const T *p0 = b.p;
+    const hipError_t e = b.ensure(n);
+    if (b.p != p0) ++h->epoch;
+    return e;
+}
+
 extern "C" {
 
 int pfc_version(void) { return PFC_VERSION; }
@@ -940,12 +954,14 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
         h->pin_in = nullptr; h->pin_in_cap = 0;
         HIP_TRY(h, hipHostMalloc(&h->pin_in, in_bytes * 2));
         h->pin_in_cap = in_bytes * 2;
+        if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned in %p .. %p\n", h->pin_in, (void *)((char *)h->pin_in + in_bytes * 2));
     }
     if (h->pin_out_cap < back_bytes) {
         if (h->pin_out) (void)hipHostFree(h->pin_out);
         h->pin_out = nullptr; h->pin_out_cap = 0;
         HIP_TRY(h, hipHostMalloc(&h->pin_out, back_bytes * 2));
         h->pin_out_cap = back_bytes * 2;
+        if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned out %p .. %p\n", h->pin_out, (void *)((char *)h->pin_out + back_bytes * 2));
     }
     HIP_TRY(h, h->h_pose.ensure(in_d + (n + 1) / 2 + 1));      // device mirror of the input block (doubles)
     {
@@ -1000,6 +1016,7 @@ hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes) {
     *p = nullptr; *cap = 0;
     hipError_t e = hipHostMalloc(p, bytes * 2);
     if (e == hipSuccess) *cap = bytes * 2;
+    if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned (ensure) %p .. %p\n", *p, (void *)((char *)*p + bytes * 2));
     return e;
 }
 
@@ -1010,8 +1027,8 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
                 const double *dsd, double *dw, double *dsdot, size_t n_pairs_bound, hipStream_t st, size_t *dpcap_out,
                 bool acc_cleared = false) {
     const size_t nk = (size_t)n_items * n_dir;
-    HIP_TRY(h, h->dual_acc.ensure(nk * kDaStride));
-    HIP_TRY(h, h->dual_res.ensure(nk * kDrStride));
+    HIP_TRY(h, ensure_dual(h, h->dual_acc, nk * kDaStride));
+    HIP_TRY(h, ensure_dual(h, h->dual_res, nk * kDrStride));
     if (!acc_cleared) HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
     DualArgs a;
     a.items = h->items.p; a.cand = h->cand.p; a.ccount = tail + 12; a.ccap = (int)h->ccap;   // packed copy of the counters
@@ -1025,8 +1042,8 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     const bool tt = h->any_tet_tet;
     // Dual polygons kept between the passes: a wave of k_narrow_dual owns 64 consecutive slots (no slot counter)
     const size_t dpcap = h->any_bristle ? ((n_pairs_bound + cpw - 1) / cpw) * 64 + 64 : 64;   // 64 slots per group of cpw pairs
-    HIP_TRY(h, h->dual_poly.ensure(dpcap * kDpFields));
-    HIP_TRY(h, h->dual_pkey.ensure(dpcap));
+    HIP_TRY(h, ensure_dual(h, h->dual_poly, dpcap * kDpFields));
+    HIP_TRY(h, ensure_dual(h, h->dual_pkey, dpcap));
     a.dpoly = h->dual_poly.p; a.dpoly_key = h->dual_pkey.p; a.dpcap = (long long)dpcap;
     if (dpcap_out) *dpcap_out = dpcap;
     if (tt) hipLaunchKernelGGL((k_narrow_dual<true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
@@ -1081,19 +1098,19 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     while (bound < (size_t)h->dual_hint * 2 + 64) bound *= 2;
     const int cpw = 64 / n_dir;
     HIP_TRY(h, ensure_work(h, n_items));
-    HIP_TRY(h, h->dual_acc.ensure(nk * kDaStride));
-    HIP_TRY(h, h->dual_res.ensure(nk * kDrStride));
+    HIP_TRY(h, ensure_dual(h, h->dual_acc, nk * kDaStride));
+    HIP_TRY(h, ensure_dual(h, h->dual_res, nk * kDrStride));
     const size_t dpcap = h->any_bristle ? ((bound + cpw - 1) / cpw) * 64 + 64 : 64;
-    HIP_TRY(h, h->dual_poly.ensure(dpcap * kDpFields));
-    HIP_TRY(h, h->dual_pkey.ensure(dpcap));
+    HIP_TRY(h, ensure_dual(h, h->dual_poly, dpcap * kDpFields));
+    HIP_TRY(h, ensure_dual(h, h->dual_pkey, dpcap));
     const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
     const int L = bfs_levels_for(h, n_items, levels);
     // seeds / results of up to 512 (item, direction) pairs are read / written in place by the kernels; larger ones are
     // copied by memcpy nodes of the graph (reading 288 B per pair over PCIe from inside k_narrow_dual stops paying)
     const bool zc_dual = nk <= 512;
     if (!zc_dual) {
-        HIP_TRY(h, h->dual_in.ensure(nk * 36));
-        HIP_TRY(h, h->dual_out.ensure(nk * 12));
+        HIP_TRY(h, ensure_dual(h, h->dual_in, nk * 36));
+        HIP_TRY(h, ensure_dual(h, h->dual_out, nk * 12));
     }
     double *ddi = zc_dual ? (double *)v_din : h->dual_in.p, *ddo = zc_dual ? (double *)v_dout : h->dual_out.p;
     const int *d_ins = ins_ids ? (const int *)(di + in_d) : nullptr;
@@ -1177,10 +1194,10 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     if (rc != PFC_OK || n_items == 0) return rc;
     const size_t nk = (size_t)n_items * n_dir;
     hipStream_t st = h->stream;
-    HIP_TRY(h, h->dual_in.ensure(nk * 36));
-    HIP_TRY(h, h->dual_acc.ensure(nk * kDaStride));
-    HIP_TRY(h, h->dual_res.ensure(nk * kDrStride));
-    HIP_TRY(h, h->dual_out.ensure(nk * 12));
+    HIP_TRY(h, ensure_dual(h, h->dual_in, nk * 36));
+    HIP_TRY(h, ensure_dual(h, h->dual_acc, nk * kDaStride));
+    HIP_TRY(h, ensure_dual(h, h->dual_res, nk * kDrStride));
+    HIP_TRY(h, ensure_dual(h, h->dual_out, nk * 12));
     double *dp = h->dual_in.p, *dt = dp + nk * 24, *dsd = dt + nk * 6;
     // one pinned block up (d_pose | d_twist | d_s), one down (d_wrench | d_sdot), as in pfc_eval (whose staging
     // buffers are free again at this point)
@@ -1190,12 +1207,14 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
         h->pin_in = nullptr; h->pin_in_cap = 0;
         HIP_TRY(h, hipHostMalloc(&h->pin_in, in_bytes * 2));
         h->pin_in_cap = in_bytes * 2;
+        if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned in %p .. %p\n", h->pin_in, (void *)((char *)h->pin_in + in_bytes * 2));
     }
     if (h->pin_out_cap < out_bytes) {
         if (h->pin_out) (void)hipHostFree(h->pin_out);
         h->pin_out = nullptr; h->pin_out_cap = 0;
         HIP_TRY(h, hipHostMalloc(&h->pin_out, out_bytes * 2));
         h->pin_out_cap = out_bytes * 2;
+        if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned out(dual) %p .. %p\n", h->pin_out, (void *)((char *)h->pin_out + out_bytes * 2));
     }
     {
         double *pi = (double *)h->pin_in;

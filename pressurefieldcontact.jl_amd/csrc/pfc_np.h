@@ -598,10 +598,11 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (polys) g.surv[sbase + __popcll(sm & below)] = contributed ? idx : -1;   // <= ccap entries
                 // a region holds every candidate its workgroups can see (rp_cap = (ccap + grid stride) / kRgn)
-                const bool fits = base + __popcll(km) <= g.rp_cap;
-                if (!fits && lane == 0) atomicOr(g.status, kStPolyOvf);
-                const int slot = rgn_c * g.rp_cap + base + __popcll(km & below);
-                if (polyb && fits) {
+                // (per slot, not per wave: a consumer reads every slot below min(count, capacity), none may be left unwritten)
+                const int off = base + __popcll(km & below);
+                if (lane == 0 && base + __popcll(km) > g.rp_cap) atomicOr(g.status, kStPolyOvf);
+                const int slot = rgn_c * g.rp_cap + off;
+                if (polyb && off < g.rp_cap) {
                     const size_t P = (size_t)g.pcap;
                     double *o = g.poly + slot;
                     // streaming stores: 0.5 GB per C3 batch must not evict the mesh records from the XCD's 4 MiB L2

@@ -1,0 +1,47 @@
+"""Soak run of the host paths: one long-lived handle, hundreds of evaluations of random sizes (1 .. 700 items), value
+and Dual mixed at random -- zero-copy and staged paths, one-graph and two-stage Dual paths, graph re-captures, list
+growth -- each compared with a fresh handle that only ever sees that one call.  usage: python scripts/soak.py [n_evals]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, pfc_pkg
+pfc = pfc_pkg.load()
+n_evals = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(2026)
+w = pfc.configs.c3_blob_tool(700, seed=9, n_div_blob=6, n_div_tool=4)
+w.s[:] = rng.standard_normal((w.n_items, 6)) * 1e-3
+nd = 6
+d_pose = rng.standard_normal((w.n_items, nd, 24)) * 1e-2
+d_twist = rng.standard_normal((w.n_items, nd, 6)) * 0.1
+d_s = rng.standard_normal((w.n_items, nd, 6)) * 1e-3
+m = pfc.configs.build_scenario(w)
+bad = 0
+kinds = {"value": 0, "dual": 0}
+for it in range(n_evals):
+    size = int(rng.choice([1, 2, 5, 17, 64, 85, 86, 200, 511, 512, 513, 700]))
+    lo = int(rng.integers(0, w.n_items - size + 1))
+    sl = slice(lo, lo + size)
+    dual = rng.random() < 0.5
+    if it % 50 == 0:
+        print(f"eval {it} ...", flush=True)
+    f = pfc.configs.build_scenario(w)
+    if dual:
+        got = m.force_all_elastic_intersections_dual(w.pose[sl], w.twist[sl], w.s[sl], d_pose[sl], d_twist[sl], d_s[sl], w.ins_ids[sl])
+        ref = f.force_all_elastic_intersections_dual(w.pose[sl], w.twist[sl], w.s[sl], d_pose[sl], d_twist[sl], d_s[sl], w.ins_ids[sl])
+        pairs = ((got[0], ref[0], 1e-11), (got[1], ref[1], 1e-7), (got[2], ref[2], 1e-9), (got[3], ref[3], 1e-6))
+        cg, cr = got[4], ref[4]
+    else:
+        got = m.force_all_elastic_intersections(w.pose[sl], w.twist[sl], w.s[sl], w.ins_ids[sl])
+        ref = f.force_all_elastic_intersections(w.pose[sl], w.twist[sl], w.s[sl], w.ins_ids[sl])
+        pairs = ((got[0], ref[0], 1e-11), (got[1], ref[1], 1e-7))
+        cg, cr = got[2], ref[2]
+    f.close()
+    kinds["dual" if dual else "value"] += 1
+    ok = np.array_equal(cg, cr)
+    for a, b, tol in pairs:
+        ok = ok and np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-300)
+    if not ok:
+        bad += 1
+        print("MISMATCH at evaluation", it, "size", size, "dual" if dual else "value", flush=True)
+m.close()
+print(f"{n_evals} evaluations ({kinds}), mismatches: {bad}")
+sys.exit(1 if bad else 0)
