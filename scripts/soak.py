@@ -1,13 +1,14 @@
 """Soak run of the host paths: one long-lived handle, hundreds of evaluations of random sizes (1 .. 700 items), value
 and Dual mixed at random -- zero-copy and staged paths, one-graph and two-stage Dual paths, graph re-captures, list
-growth -- each compared with a fresh handle that only ever sees that one call.  usage: python scripts/soak.py [n_evals]"""
+growth -- each compared with a fresh handle that only ever sees that one call.  usage: python scripts/soak.py [n_evals] [big]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pfc_pkg
 pfc = pfc_pkg.load()
 n_evals = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+big = len(sys.argv) > 2 and sys.argv[2] == "big"      # batches around the two-halves threshold (value evaluations split)
 rng = np.random.default_rng(2026)
-w = pfc.configs.c3_blob_tool(700, seed=9, n_div_blob=6, n_div_tool=4)
+w = pfc.configs.c3_blob_tool(3000 if big else 700, seed=9, n_div_blob=6, n_div_tool=4)
 w.s[:] = rng.standard_normal((w.n_items, 6)) * 1e-3
 nd = 6
 d_pose = rng.standard_normal((w.n_items, nd, 24)) * 1e-2
@@ -17,7 +18,7 @@ m = pfc.configs.build_scenario(w)
 bad = 0
 kinds = {"value": 0, "dual": 0}
 for it in range(n_evals):
-    size = int(rng.choice([1, 2, 5, 17, 64, 85, 86, 200, 511, 512, 513, 700]))
+    size = int(rng.choice([5, 600, 1023, 1024, 1025, 1500, 2048, 3000] if big else [1, 2, 5, 17, 64, 85, 86, 200, 511, 512, 513, 700]))
     lo = int(rng.integers(0, w.n_items - size + 1))
     sl = slice(lo, lo + size)
     dual = rng.random() < 0.5
