@@ -14,6 +14,7 @@ struct BpArgs {
     int *icnt;
     unsigned *status;
     int level, fcap, ccap;
+    int n_items;
 };
 
 __device__ __forceinline__ void count_per_item(int *icnt, int item, int slot, bool listed, bool flag, int n = 1) {
@@ -50,6 +51,13 @@ __global__ void __launch_bounds__(256) k_bp_expand(BpArgs g) {
         int fa0 = 0, fa1 = 0, fb0 = 0, fb1 = 0;   // WorkRec.pad flags of the children: bit 0 / 1 = a / b is a leaf (negative link)
         if (active) {
             w = g.fin[idx];
+            if ((unsigned)w.item >= (unsigned)g.n_items) {     // never follows an index that cannot be an item
+                atomicOr(g.status, kStHole);
+                w.item = 0; w.a = 0; w.b = 0; w.pad = 0;
+                active = false;
+            }
+        }
+        if (active) {
             const ItemRec *it = g.items + w.item;
             const NodeRec a = load_node(it->nodes1 + w.a);
             const NodeRec b = load_node(it->nodes2 + w.b);
@@ -154,6 +162,7 @@ struct DfsArgs {
     int reserve;         // 3 * (max remaining depth) + 3 slots kept free for the pure depth-first mode
     unsigned long long *stamps;  // diagnostic builds: [8..12] cycles in pop+load / SAT / push+flush, iterations, lanes
     int no_filter;       // 1: skip the FP32 filter (every pair runs the Float64 test)
+    int n_items;
 };
 
 // one ticket per wave from a device-wide counter: lane 0 takes it, the wave reads it back as a scalar
@@ -192,6 +201,7 @@ struct Dfs32Args {
     unsigned *status;
     int reserve;
     unsigned long long *stamps;   // diagnostic builds: [8..12] cycles in pop+load / test / barrier+prefix / push, iterations
+    int n_items;
 };
 
 __device__ __forceinline__ NodeF load_nodef(const NodeF *n) {
@@ -366,6 +376,10 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
     // one ticket per workgroup (same loop shape as k_bp_dfs: condition in the for header, no break)
     for (int sd = blockIdx.x; sd < n_seed; sd = next_ticket_block(g.next_seed, &s_seed, n_seed)) {
         const WorkRec s = (sd == (int)blockIdx.x) ? s_first : g.seeds[__builtin_amdgcn_readfirstlane(sd)];
+        if ((unsigned)s.item >= (unsigned)g.n_items) {   // uniform over the workgroup: an unwritten seed slot is skipped, not followed
+            if (tid == 0) atomicOr(g.status, kStHole);
+            continue;
+        }
         const int item = __builtin_amdgcn_readfirstlane(s.item);   // uniform: scalar loads of the pose below
         const ItemRec *it = g.items + item;
         // the item's pose lives in LDS (broadcast reads inside the iteration) rather than in 33 registers that would
@@ -517,6 +531,10 @@ __global__ void __launch_bounds__(64) k_bp_dfs(DfsArgs g) {
     // dynamic seed queue: seeds differ in work by orders of magnitude (most of a contact lives in one subtree)
     for (int sd = next_ticket(g.next_seed); sd < n_seed; sd = next_ticket(g.next_seed)) {
         const WorkRec s = g.seeds[sd];
+        if ((unsigned)s.item >= (unsigned)g.n_items) {
+            if (lane == 0) atomicOr(g.status, kStHole);
+            continue;
+        }
         const int item = __builtin_amdgcn_readfirstlane(s.item);
         const ItemRec *it = g.items + item;
         double R12[9], aR12[9], t12[3];

@@ -247,6 +247,7 @@ struct pfc_context {
     pfc_context *twin = nullptr;
     bool is_twin = false;
     int opt_split_min = 1024;          // 0: never split
+    int opt_poison = 0;                // diagnostic: fill (re)allocated work lists with 0xFF bytes (item index -1)
     int split_n0 = 0;                  // items in the first half of the pending evaluation (0: not split)
     int last_parts = 1;                // 2 if the last checked evaluation ran as two halves
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -355,6 +356,12 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
                             h->tail.cap};
     for (size_t k = 0; k < sizeof caps0 / sizeof caps0[0]; ++k)
         if (caps0[k] != caps1[k]) { ++h->epoch; break; }
+    if (h->opt_poison) {    // every evaluation starts from lists full of entries that must never be followed
+        if ((e = hipMemsetAsync(h->frontier[0].p, 0xFF, sizeof(WorkRec) * h->frontier[0].cap, h->stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(h->frontier[1].p, 0xFF, sizeof(WorkRec) * h->frontier[1].cap, h->stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(h->cand.p, 0xFF, sizeof(WorkRec) * h->cand.cap, h->stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
+    }
     return hipSuccess;
 }
 
@@ -416,7 +423,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         BpArgs b;
         b.items = h->items.p; b.fin = h->frontier[lv & 1].p; b.fout = h->frontier[(lv + 1) & 1].p;
         b.cand = h->cand.p; b.fcount = fcount; b.ccount = ccount; b.icnt = h->icnt.p; b.status = h->status.p;
-        b.level = lv; b.fcap = (int)h->fcap; b.ccap = (int)h->ccap;
+        b.level = lv; b.fcap = (int)h->fcap; b.ccap = (int)h->ccap; b.n_items = n_items;
         // upper bound of this level's frontier: n_items * 4^lv, capped by the buffer
         double ub = (double)n_items * std::pow(4.0, (double)(lv < 15 ? lv : 15));
         size_t bound = ub > (double)h->fcap ? h->fcap : (size_t)ub;
@@ -427,7 +434,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         size_t bound = ub > (double)h->fcap ? h->fcap : (size_t)ub;
         DfsArgs d;
         d.items = h->items.p; d.cand = h->cand.p; d.ccount = ccount; d.ccap = (int)h->ccap; d.icnt = h->icnt.p;
-        d.status = h->status.p; d.reserve = 3 * levels + 3; d.stamps = h->stamps.p;
+        d.status = h->status.p; d.reserve = 3 * levels + 3; d.stamps = h->stamps.p; d.n_items = n_items;
         if (h->opt_no_filter) {
             // Float64-only traversal (A/B checks)
             d.seeds = h->frontier[L & 1].p; d.n_seed = fcount + L; d.seed_cap = (int)h->fcap; d.next_seed = next_seed;
@@ -438,7 +445,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
             f.items = h->items.p; f.seeds = h->frontier[L & 1].p; f.n_seed = fcount + L; f.next_seed = next_seed;
             f.seed_cap = (int)h->fcap; f.cand = h->cand.p; f.ccount = ccount; f.ccap = (int)h->ccap;
             f.ucount = ucount; f.icnt = h->icnt.p; f.status = h->status.p; f.stamps = h->stamps.p;
-            f.reserve = 3 * levels + 3;
+            f.reserve = 3 * levels + 3; f.n_items = n_items;
             hipLaunchKernelGGL(k_bp_dfs32, dim3(grid_for(bound, 1, 256 * 6)), dim3(kDfsBlock), 0, st, f);
         }
     }
@@ -446,7 +453,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
 
     NpArgs np;
     np.items = h->items.p; np.cand = h->cand.p; np.ccount = ccount; np.ccap = (int)h->ccap; np.acc = h->acc.p;
-    np.icnt = h->icnt.p; np.clip_n = h->opt_debug ? h->clip_n.p : nullptr; np.trac = trac_view(h);
+    np.icnt = h->icnt.p; np.n_items = n_items; np.clip_n = h->opt_debug ? h->clip_n.p : nullptr; np.trac = trac_view(h);
     np.tcount = tcount; np.tcap = (int)h->tcap; np.status = h->status.p; np.debug = h->opt_debug;
     np.stamps = h->stamps.p;
     np.rec = h->rec.p; np.rgn = h->rgn.p; np.rr_cap = (int)(h->rcap / kRgn);
@@ -555,6 +562,9 @@ int check_one(pfc_context *h) {
     h->stats[6] = status; h->stats[7] = h->last_n_items;
     if (status & kStBadIns) return fail(h, PFC_ERR_BAD_ARG, "instruction id out of range in ins_ids");
     h->last_undecided = ctr[4];
+    // before the overflow branch: also the narrowphase of an overflowing (to be re-issued) evaluation must only see
+    // slots that were written
+    if (status & kStHole) return fail(h, PFC_ERR_STATE, "internal error: a work-list slot was read before it was written");
     if (status & (kStFrontierOvf | kStCandOvf | kStTracOvf | kStRecOvf)) {
         // VectorCache-style growth (src/obb/vector_cache.jl:13-17): at least double, at least the observed need
         if (status & kStFrontierOvf) { size_t f = h->fcap * 2; while (f < (size_t)fpeak) f *= 2; h->fcap = f; }
@@ -566,6 +576,7 @@ int check_one(pfc_context *h) {
     }
     if (status & kStAbort) return fail(h, PFC_ERR_STATE, "broadphase aborted: iteration guard hit (corrupt tree?)");
     if (status & kStPolyOvf) return fail(h, PFC_ERR_STATE, "internal error: a kept-polygon region overflowed");
+
     if (status & kStNonFinite) return fail(h, PFC_ERR_NONFINITE, "Non-finite vertex likely");
     h->stats[0] = (long long)tot[0]; h->stats[2] = (long long)tot[1]; h->stats[3] = (long long)tot[2];
     return PFC_OK;
@@ -909,6 +920,7 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
     if (rc != PFC_OK) return rc;
     pfc_context *t = h->twin;
     t->opt_profile = h->opt_profile; t->opt_max_levels = h->opt_max_levels; t->opt_bfs_levels = h->opt_bfs_levels;
+    t->opt_poison = h->opt_poison;
     t->opt_graph = h->opt_graph;
     if (t->opt_no_filter != h->opt_no_filter) { t->opt_no_filter = h->opt_no_filter; t->ghave[0] = t->ghave[1] = false; }
     const int n0 = n_items / 2, n1 = n_items - n0;
@@ -1242,6 +1254,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "bfs_levels")) h->opt_bfs_levels = (int)value;
     else if (!std::strcmp(name, "graph")) h->opt_graph = value != 0;
     else if (!std::strcmp(name, "split_min")) h->opt_split_min = (int)value;
+    else if (!std::strcmp(name, "poison")) h->opt_poison = value != 0;
     else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;

@@ -22,6 +22,7 @@ enum : unsigned {
     kStAbort = 32u,
     kStRecOvf = 64u,
     kStPolyOvf = 128u,   // a kept-polygon region ran full (sized so that it cannot: an internal error)
+    kStHole = 256u,      // a work-list entry with an item index out of range was read (unwritten slot: an internal error)
 };
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -19,6 +19,7 @@ struct NpArgs {
     int *rgn;        // region counters of the kept-polygon and record lists (kRgn x kRgnStride ints)
     int rr_cap;      // record slots per region
     int *icnt;
+    int n_items;
     int *clip_n;     // per candidate, or null
     // clipped polygons of bristle items, kept for the friction pass (k_fric): SoA [field][slot], slot < pcap
     int *poly_item;  // item | n_poly << 28
@@ -164,10 +165,15 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5;
         STAMP(t0);
         const int idx = rd * stride + blockIdx.x * kNpBlock + lane;
-        const bool active = idx < n_c;
+        bool active = idx < n_c;
         WorkRec cw;
         cw.item = 0; cw.a = 0; cw.b = 0; cw.pad = 0;
         if (active) cw = g.cand[idx];
+        if ((unsigned)cw.item >= (unsigned)g.n_items) {     // an unwritten slot is reported, never followed
+            atomicOr(g.status, kStHole);
+            cw.item = 0; cw.a = 0; cw.b = 0;
+            active = false;
+        }
         const ItemRec *it = g.items + cw.item;
         const GTetRec *tp = (const GTetRec *)(it->tet + cw.b);
         const int nq = it->nq;

@@ -238,3 +238,29 @@ def test_alternating_batch_shapes_on_one_handle(pfc):
             np.testing.assert_allclose(wr, wr0, rtol=1e-11, atol=1e-11 * max(np.abs(wr0).max(), 1e-300))
             np.testing.assert_allclose(sd, sd0, rtol=1e-7, atol=1e-7 * max(np.abs(sd0).max(), 1e-300))
     m.close()
+
+
+def test_overflowing_lists_never_expose_unwritten_slots(pfc):
+    """Option "poison" fills the work lists with entries of item index -1 before every evaluation.  A first evaluation
+    that overflows the candidate list AND the seed frontier several times (buffers grow from their small initial
+    sizes; every overflowing attempt still runs its narrowphase over the truncated lists) must neither report a slot
+    that was read before it was written (PFC_ERR_STATE) nor change a result.  Regression test for appends that skipped
+    their whole run on overflow and left the slots below the capacity unwritten (read as wild indices: a GPU fault
+    once the allocator recycles memory)."""
+    w = pfc.configs.c3_blob_tool(1100, seed=13, n_div_blob=6, n_div_tool=4)
+    w.s[:] = np.random.default_rng(3).standard_normal((w.n_items, 6)) * 1e-3
+    out = []
+    for poison in (0, 1):
+        m = pfc.configs.build_scenario(w)
+        m.set_option("split_min", 0)
+        m.set_option("bfs_levels", 3)        # 1100 x 4^3 seeds > 65536: the frontier overflows as well
+        m.set_option("poison", poison)
+        wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        wr2, sd2, ct2 = m.force_all_elastic_intersections(w.pose[:300], w.twist[:300], w.s[:300], w.ins_ids[:300])
+        out.append((wr, ct, wr2, ct2, m.stats()))
+        m.close()
+    a, b = out
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-11, atol=1e-11 * np.abs(a[0]).max())
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-11, atol=1e-11 * np.abs(a[2]).max())
+    assert a[4]["candidates"] > 65536 // 2
