@@ -360,6 +360,7 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
         if ((e = hipMemsetAsync(h->frontier[0].p, 0xFF, sizeof(WorkRec) * h->frontier[0].cap, h->stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(h->frontier[1].p, 0xFF, sizeof(WorkRec) * h->frontier[1].cap, h->stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(h->cand.p, 0xFF, sizeof(WorkRec) * h->cand.cap, h->stream)) != hipSuccess) return e;
+        if (h->poly_item.p && (e = hipMemsetAsync(h->poly_item.p, 0xFF, sizeof(int) * h->poly_item.cap, h->stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
     }
     return hipSuccess;
@@ -478,6 +479,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         FricArgs fr;
         fr.items = h->items.p; fr.poly_item = h->poly_item.p; fr.poly = h->poly.p; fr.rgn = h->rgn.p;
         fr.pcap = np.pcap; fr.rp_cap = np.rp_cap; fr.res = h->res.p; fr.acc = h->acc.p;
+        fr.n_items = n_items; fr.status = h->status.p;
         hipLaunchKernelGGL(k_fric, dim3(grid_for(h->ccap, 64, 256 * 16)), dim3(64), 0, st, fr);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BR], st));

@@ -798,6 +798,8 @@ struct FricArgs {
     const double *poly;
     const int *rgn;      // region counters (word 0: kept polygons)
     int rp_cap, pcap;    // slots per region, kRgn * rp_cap
+    int n_items;
+    unsigned *status;
     const double *res;
     double *acc;
 };
@@ -815,7 +817,11 @@ __global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
         for (int k = 0; k < 6; ++k) sum[k] = 0.0;
         int item = 0;
         bool contributed = false;
-        const unsigned pk = active ? (unsigned)g.poly_item[idx] : 0u;
+        unsigned pk = active ? (unsigned)g.poly_item[idx] : 0u;
+        if ((pk >> 28) > 8u || ((pk >> 28) >= 3u && (pk & 0x0FFFFFFFu) >= (unsigned)g.n_items)) {
+            atomicOr(g.status, kStHole);     // not a key k_narrow writes: an unwritten slot is reported, never followed
+            pk = 0u;
+        }
         if ((pk >> 28) >= 3u) {     // 0: a reserved slot whose pair had a polygon but no pressure point
             item = (int)(pk & 0x0FFFFFFFu);
             const int n = (int)(pk >> 28);
