@@ -15,6 +15,8 @@ d_pose = rng.standard_normal((w.n_items, nd, 24)) * 1e-2
 d_twist = rng.standard_normal((w.n_items, nd, 6)) * 0.1
 d_s = rng.standard_normal((w.n_items, nd, 6)) * 1e-3
 m = pfc.configs.build_scenario(w)
+if os.environ.get("PFC_SOAK_POISON"):      # the long-lived handle starts every evaluation from poisoned work lists
+    m.set_option("poison", 1)
 bad = 0
 kinds = {"value": 0, "dual": 0}
 for it in range(n_evals):
