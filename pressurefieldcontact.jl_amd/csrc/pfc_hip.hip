@@ -947,6 +947,17 @@ int pfc_check(pfc_handle h) {
     return check_eval(h);
 }
 
+// pinned staging block of at least `bytes` (grown with slack, never shrunk)
+static hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes) {
+    if (*cap >= bytes) return hipSuccess;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr; *cap = 0;
+    hipError_t e = hipHostMalloc(p, bytes * 2);
+    if (e == hipSuccess) *cap = bytes * 2;
+    if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned %p .. %p\n", *p, (void *)((char *)*p + bytes * 2));
+    return e;
+}
+
 int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, const double *twist,
              const double *s, double *wrench, double *sdot, int *counts) {
     if (!h) return PFC_ERR_BAD_ARG;
@@ -963,20 +974,8 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     const size_t out_d = n * 12, out_bytes = out_d * sizeof(double) + n * 4 * sizeof(int);
     const size_t t0 = (((size_t)h->max_levels + 40) + 3) & ~(size_t)3;      // ints in front of the outputs (16-byte multiple)
     const size_t back_bytes = t0 * sizeof(int) + out_bytes;
-    if (h->pin_in_cap < in_bytes) {
-        if (h->pin_in) (void)hipHostFree(h->pin_in);
-        h->pin_in = nullptr; h->pin_in_cap = 0;
-        HIP_TRY(h, hipHostMalloc(&h->pin_in, in_bytes * 2));
-        h->pin_in_cap = in_bytes * 2;
-        if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned in %p .. %p\n", h->pin_in, (void *)((char *)h->pin_in + in_bytes * 2));
-    }
-    if (h->pin_out_cap < back_bytes) {
-        if (h->pin_out) (void)hipHostFree(h->pin_out);
-        h->pin_out = nullptr; h->pin_out_cap = 0;
-        HIP_TRY(h, hipHostMalloc(&h->pin_out, back_bytes * 2));
-        h->pin_out_cap = back_bytes * 2;
-        if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned out %p .. %p\n", h->pin_out, (void *)((char *)h->pin_out + back_bytes * 2));
-    }
+    HIP_TRY(h, ensure_pinned(&h->pin_in, &h->pin_in_cap, in_bytes));
+    HIP_TRY(h, ensure_pinned(&h->pin_out, &h->pin_out_cap, back_bytes));
     HIP_TRY(h, h->h_pose.ensure(in_d + (n + 1) / 2 + 1));      // device mirror of the input block (doubles)
     {
         const size_t cap0 = h->tail.cap;
@@ -1024,15 +1023,6 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
 }
 
 namespace {
-hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes) {
-    if (*cap >= bytes) return hipSuccess;
-    if (*p) (void)hipHostFree(*p);
-    *p = nullptr; *cap = 0;
-    hipError_t e = hipHostMalloc(p, bytes * 2);
-    if (e == hipSuccess) *cap = bytes * 2;
-    if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned (ensure) %p .. %p\n", *p, (void *)((char *)*p + bytes * 2));
-    return e;
-}
 
 // The Dual passes of one evaluation on stream st.  tail: the packed tail of the value pass (device-visible), dp/dt/dsd
 // and dw/dsdot: seeds and results (device-visible), n_pairs_bound: upper bound of the contributing pairs used to size
@@ -1216,20 +1206,8 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     // one pinned block up (d_pose | d_twist | d_s), one down (d_wrench | d_sdot), as in pfc_eval (whose staging
     // buffers are free again at this point)
     const size_t in_bytes = sizeof(double) * nk * 36, out_bytes = sizeof(double) * nk * 12;
-    if (h->pin_in_cap < in_bytes) {
-        if (h->pin_in) (void)hipHostFree(h->pin_in);
-        h->pin_in = nullptr; h->pin_in_cap = 0;
-        HIP_TRY(h, hipHostMalloc(&h->pin_in, in_bytes * 2));
-        h->pin_in_cap = in_bytes * 2;
-        if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned in %p .. %p\n", h->pin_in, (void *)((char *)h->pin_in + in_bytes * 2));
-    }
-    if (h->pin_out_cap < out_bytes) {
-        if (h->pin_out) (void)hipHostFree(h->pin_out);
-        h->pin_out = nullptr; h->pin_out_cap = 0;
-        HIP_TRY(h, hipHostMalloc(&h->pin_out, out_bytes * 2));
-        h->pin_out_cap = out_bytes * 2;
-        if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned out(dual) %p .. %p\n", h->pin_out, (void *)((char *)h->pin_out + out_bytes * 2));
-    }
+    HIP_TRY(h, ensure_pinned(&h->pin_in, &h->pin_in_cap, in_bytes));
+    HIP_TRY(h, ensure_pinned(&h->pin_out, &h->pin_out_cap, out_bytes));
     {
         double *pi = (double *)h->pin_in;
         std::memcpy(pi, d_pose, sizeof(double) * nk * 24);
