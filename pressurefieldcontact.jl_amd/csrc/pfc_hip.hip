@@ -659,6 +659,7 @@ void pfc_destroy(pfc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);   // an unchecked pfc_eval_device on the caller's stream
     if (h->twin) { pfc_destroy(h->twin); h->twin = nullptr; }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
