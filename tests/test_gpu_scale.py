@@ -264,3 +264,36 @@ def test_overflowing_lists_never_expose_unwritten_slots(pfc):
     np.testing.assert_allclose(b[0], a[0], rtol=1e-11, atol=1e-11 * np.abs(a[0]).max())
     np.testing.assert_allclose(b[2], a[2], rtol=1e-11, atol=1e-11 * np.abs(a[2]).max())
     assert a[4]["candidates"] > 65536 // 2
+
+
+def test_soak_mixed_value_and_dual_on_one_handle(pfc):
+    """A short version of scripts/soak.py: one long-lived handle, 40 value / Dual evaluations of random sizes around the
+    path thresholds (zero-copy <= 512 items, one-graph Dual <= 512 items and 4096 pairs, staged above), each against a
+    fresh handle.  Guards the lifetime of everything a replayed graph holds (pinned blocks, Dual buffers, work lists)."""
+    rng = np.random.default_rng(2027)
+    w = pfc.configs.c3_blob_tool(700, seed=9, n_div_blob=6, n_div_tool=4)
+    w.s[:] = rng.standard_normal((w.n_items, 6)) * 1e-3
+    nd = 6
+    d_pose = rng.standard_normal((w.n_items, nd, 24)) * 1e-2
+    d_twist = rng.standard_normal((w.n_items, nd, 6)) * 0.1
+    d_s = rng.standard_normal((w.n_items, nd, 6)) * 1e-3
+    m = pfc.configs.build_scenario(w)
+    for it in range(40):
+        size = int(rng.choice([1, 5, 64, 85, 86, 200, 512, 513, 700]))
+        lo = int(rng.integers(0, w.n_items - size + 1))
+        sl = slice(lo, lo + size)
+        f = pfc.configs.build_scenario(w)
+        if rng.random() < 0.5:
+            args = (w.pose[sl], w.twist[sl], w.s[sl], d_pose[sl], d_twist[sl], d_s[sl], w.ins_ids[sl])
+            got, ref = m.force_all_elastic_intersections_dual(*args), f.force_all_elastic_intersections_dual(*args)
+            cmp = ((0, 1e-11), (1, 1e-7), (2, 1e-9), (3, 1e-6))
+            assert np.array_equal(got[4], ref[4]), (it, size)
+        else:
+            args = (w.pose[sl], w.twist[sl], w.s[sl], w.ins_ids[sl])
+            got, ref = m.force_all_elastic_intersections(*args), f.force_all_elastic_intersections(*args)
+            cmp = ((0, 1e-11), (1, 1e-7))
+            assert np.array_equal(got[2], ref[2]), (it, size)
+        f.close()
+        for k, tol in cmp:
+            np.testing.assert_allclose(got[k], ref[k], rtol=tol, atol=tol * max(np.abs(ref[k]).max(), 1e-300), err_msg=f"{it} {size} {k}")
+    m.close()
