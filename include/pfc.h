@@ -46,6 +46,10 @@ typedef struct pfc_context *pfc_handle;
 
 /* Library/ABI version (PFC_VERSION of the build). */
 int pfc_version(void);
+/* 0 for the product build.  Diagnostic builds report themselves: bit 0 = in-kernel phase stamps (-DPFC_STAMPS, graph
+ * replay off), bits 8..15 = elimination variant (-DPFC_EXP=n: one phase of the narrowphase compiled out, WRONG results).
+ * The Python binding refuses to load a non-product build unless PFC_ALLOW_DIAGNOSTIC=1 is set. */
+int pfc_build_info(void);
 
 /* MechanismScenario() (src/mechanism_scenario.jl:181-198): creates an empty scenario bound to HIP device
  * `device`.  Fails with PFC_ERR_HIP when no device is usable. */

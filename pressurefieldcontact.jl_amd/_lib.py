@@ -10,7 +10,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libpfc_hip.so")
+LIB_PATH = os.path.join(CSRC, "libpfc_hip.so")      # the product build; build() never writes anywhere else
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 
@@ -25,6 +25,7 @@ _ip = C.POINTER(C.c_int)
 # every symbol include/pfc.h declares: (restype, argtypes)
 SIGNATURES = {
     "pfc_version": (C.c_int, []),
+    "pfc_build_info": (C.c_int, []),
     "pfc_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "pfc_destroy": (None, [C.c_void_p]),
     "pfc_last_error": (C.c_char_p, [C.c_void_p]),
@@ -77,13 +78,20 @@ def lib():
     """Load libpfc_hip.so; raises (never falls back) if it is absent."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        # Diagnostic variants (scripts/elimination.sh, scripts/build_stamps.sh) are built to csrc/exp/*.so and selected with
+        # PFC_LIB=<path>; the product library is never overwritten by them.
+        path = os.environ.get("PFC_LIB") or LIB_PATH
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback for the contact hot path")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)       # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        info = L.pfc_build_info()
+        if info != 0 and os.environ.get("PFC_ALLOW_DIAGNOSTIC") != "1":
+            raise ImportError(f"{path} is a diagnostic build (pfc_build_info() = {info:#x}: stamps / elimination variant, "
+                              "results may be wrong); set PFC_ALLOW_DIAGNOSTIC=1 to load it on purpose")
         _lib = L
     return _lib

@@ -316,11 +316,15 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
         const size_t c0 = h->ctr.cap, s0 = h->status.cap;
         if ((e = h->ctr.ensure((size_t)h->max_levels + 12)) != hipSuccess) return e;
         if ((e = h->status.ensure(4)) != hipSuccess) return e;
-        if (h->ctr.cap != c0 && (e = hipMemset(h->ctr.p, 0, sizeof(int) * h->ctr.cap)) != hipSuccess) return e;
-        if (h->status.cap != s0 && (e = hipMemset(h->status.p, 0, sizeof(unsigned) * h->status.cap)) != hipSuccess) return e;
+        // The kernels rely on these being zero on entry and run on non-blocking streams (the handle's, the twin's or
+        // the caller's), which are not ordered against the legacy null stream: clear on the handle's stream and wait.
+        bool cleared = false;
+        if (h->ctr.cap != c0) { if ((e = hipMemsetAsync(h->ctr.p, 0, sizeof(int) * h->ctr.cap, h->stream)) != hipSuccess) return e; cleared = true; }
+        if (h->status.cap != s0) { if ((e = hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * h->status.cap, h->stream)) != hipSuccess) return e; cleared = true; }
         const size_t r0 = h->rgn.cap;
         if ((e = h->rgn.ensure((size_t)kRgn * kRgnStride)) != hipSuccess) return e;
-        if (h->rgn.cap != r0 && (e = hipMemset(h->rgn.p, 0, sizeof(int) * h->rgn.cap)) != hipSuccess) return e;
+        if (h->rgn.cap != r0) { if ((e = hipMemsetAsync(h->rgn.p, 0, sizeof(int) * h->rgn.cap, h->stream)) != hipSuccess) return e; cleared = true; }
+        if (cleared && (e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
     }
     if ((e = h->stamps.ensure(16)) != hipSuccess) return e;
     size_t f = h->fcap ? h->fcap : 1u << 16;
@@ -376,7 +380,13 @@ TracSoA trac_view(pfc_context *h) {
     return t;
 }
 
-// Enqueue one evaluation.  All pointers are device pointers.
+// Option "max_levels" caps the number of broadphase levels the counters / seed expansion are laid out for.  Every buffer
+// (ctr, tail, h_tail) is sized from the finalized depth h->max_levels, so the effective value never exceeds it; the
+// depth-first kernels' stack reserve always uses h->max_levels (a smaller reserve could overrun the LDS stack).
+int eff_levels(const pfc_context *h) {
+    return (h->opt_max_levels > 0 && h->opt_max_levels < h->max_levels) ? h->opt_max_levels : h->max_levels;
+}
+
 int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
     int L = 0;
     if (h->opt_bfs_levels >= 0) {
@@ -399,7 +409,7 @@ int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
 // The launch sequence of one evaluation on stream st (eagerly, or while st is being captured into a graph).
 int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
                 const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st, bool prof) {
-    const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
+    const int levels = eff_levels(h);
     int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2;   // ctr[3]: total records, filled by k_final
     int *ucount = h->ctr.p + 4, *fcount = h->ctr.p + 6;
     int *pcount = h->ctr.p + ((levels + 9) & ~1);   // after the per-level frontier counts; 8-byte aligned pair
@@ -435,7 +445,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         size_t bound = ub > (double)h->fcap ? h->fcap : (size_t)ub;
         DfsArgs d;
         d.items = h->items.p; d.cand = h->cand.p; d.ccount = ccount; d.ccap = (int)h->ccap; d.icnt = h->icnt.p;
-        d.status = h->status.p; d.reserve = 3 * levels + 3; d.stamps = h->stamps.p; d.n_items = n_items;
+        d.status = h->status.p; d.reserve = 3 * h->max_levels + 3; d.stamps = h->stamps.p; d.n_items = n_items;
         if (h->opt_no_filter) {
             // Float64-only traversal (A/B checks)
             d.seeds = h->frontier[L & 1].p; d.n_seed = fcount + L; d.seed_cap = (int)h->fcap; d.next_seed = next_seed;
@@ -446,7 +456,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
             f.items = h->items.p; f.seeds = h->frontier[L & 1].p; f.n_seed = fcount + L; f.next_seed = next_seed;
             f.seed_cap = (int)h->fcap; f.cand = h->cand.p; f.ccount = ccount; f.ccap = (int)h->ccap;
             f.ucount = ucount; f.icnt = h->icnt.p; f.status = h->status.p; f.stamps = h->stamps.p;
-            f.reserve = 3 * levels + 3; f.n_items = n_items;
+            f.reserve = 3 * h->max_levels + 3; f.n_items = n_items;
             hipLaunchKernelGGL(k_bp_dfs32, dim3(grid_for(bound, 1, 256 * 6)), dim3(kDfsBlock), 0, st, f);
         }
     }
@@ -496,7 +506,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
 int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
                  const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st) {
     HIP_TRY(h, ensure_work(h, n_items));
-    const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
+    const int levels = eff_levels(h);
     const bool prof = h->opt_profile != 0;
     if (prof && !h->ev[0])
         for (int k = 0; k < EV_COUNT; ++k) HIP_TRY(h, hipEventCreate(&h->ev[k]));
@@ -640,6 +650,15 @@ hipError_t ensure_dual(pfc_context *h, DevBuf<T> &b, size_t n) {
 extern "C" {
 
 int pfc_version(void) { return PFC_VERSION; }
+
+int pfc_build_info(void) {
+    int f = 0;
+#ifdef PFC_STAMPS
+    f |= 1;
+#endif
+    f |= (PFC_EXP & 0xFF) << 8;
+    return f;
+}
 
 int pfc_create(int device, pfc_handle *out) {
     if (!out) return PFC_ERR_BAD_ARG;
@@ -839,7 +858,8 @@ int pfc_finalize(pfc_handle h) {
     if (h->finalized) return fail(h, PFC_ERR_STATE, "pfc_finalize called twice");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, h->status.ensure(4));
-    HIP_TRY(h, hipMemset(h->status.p, 0, sizeof(unsigned) * 4));
+    HIP_TRY(h, hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * 4, h->stream));   // same stream as k_prep_tet below
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::vector<MeshDev> md(h->meshes.size());
     for (size_t k = 0; k < h->meshes.size(); ++k) {
         HostMesh &m = h->meshes[k];
@@ -902,17 +922,26 @@ int pfc_finalize(pfc_handle h) {
     return PFC_OK;
 }
 
+// Argument checks shared by every evaluation entry point (host- or device-buffer, value or Dual): what the reference
+// would reject with a MethodError / BoundsError before forceAllElasticIntersections! runs.
+static int check_eval_args(pfc_context *h, int n_items, const void *ins_ids, const void *pose, const void *twist,
+                           const void *s, const void *wrench, const void *sdot) {
+    if (!h->finalized) return fail(h, PFC_ERR_STATE, "pfc_eval before pfc_finalize");
+    if (n_items < 0) return fail(h, PFC_ERR_BAD_ARG, "negative n_items");
+    if (n_items == 0) return PFC_OK;
+    if (h->ins.empty()) return fail(h, PFC_ERR_STATE, "no contact instructions");
+    if (!pose || !twist || !wrench || !sdot) return fail(h, PFC_ERR_BAD_ARG, "null buffer");
+    if (!ins_ids && n_items > (int)h->ins.size())
+        return fail(h, PFC_ERR_BAD_ARG, "n_items exceeds the number of instructions and no ins_ids given");
+    if (h->any_bristle && !s) return fail(h, PFC_ERR_BAD_ARG, "bristle instructions need the state buffer s");
+    return PFC_OK;
+}
+
 int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
                     const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, void *stream) {
     if (!h) return PFC_ERR_BAD_ARG;
-    if (!h->finalized) return fail(h, PFC_ERR_STATE, "pfc_eval before pfc_finalize");
-    if (n_items < 0) return fail(h, PFC_ERR_BAD_ARG, "negative n_items");
+    { const int rc = check_eval_args(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot); if (rc != PFC_OK) return rc; }
     if (n_items == 0) { h->pending = false; h->last_n_items = 0; return PFC_OK; }
-    if (h->ins.empty()) return fail(h, PFC_ERR_STATE, "no contact instructions");
-    if (!d_pose || !d_twist || !d_wrench || !d_sdot) return fail(h, PFC_ERR_BAD_ARG, "null buffer");
-    if (!d_ins_ids && n_items > (int)h->ins.size())
-        return fail(h, PFC_ERR_BAD_ARG, "n_items exceeds the number of instructions and no ins_ids given");
-    if (h->any_bristle && !d_s) return fail(h, PFC_ERR_BAD_ARG, "bristle instructions need the state buffer s");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     h->split_n0 = 0;
@@ -1108,7 +1137,7 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     const size_t dpcap = h->any_bristle ? ((bound + cpw - 1) / cpw) * 64 + 64 : 64;
     HIP_TRY(h, ensure_dual(h, h->dual_poly, dpcap * kDpFields));
     HIP_TRY(h, ensure_dual(h, h->dual_pkey, dpcap));
-    const int levels = h->opt_max_levels > 0 ? h->opt_max_levels : h->max_levels;
+    const int levels = eff_levels(h);
     const int L = bfs_levels_for(h, n_items, levels);
     // seeds / results of up to 512 (item, direction) pairs are read / written in place by the kernels; larger ones are
     // copied by memcpy nodes of the graph (reading 288 B per pair over PCIe from inside k_narrow_dual stops paying)
@@ -1184,6 +1213,8 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
     if (n_dir < 1 || n_dir > 16) return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: n_dir must be in 1..16");
     if (n_items > 0 && (!d_pose || !d_twist || !d_wrench || !d_sdot))
         return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: null buffer");
+    // the same argument checks in front of BOTH paths (the one-graph path used to skip them)
+    { const int rc = check_eval_args(h, n_items, ins_ids, pose, twist, s, wrench, sdot); if (rc != PFC_OK) return rc; }
     if (h->finalized && n_items > 0 && n_items <= 512 && (size_t)n_items * n_dir <= 4096 && h->dual_hint >= 0 && pose && twist &&
         wrench && sdot && !h->opt_debug && !(h->opt_split_min > 0 && n_items >= h->opt_split_min)) {
         HIP_TRY(h, hipSetDevice(h->device));
@@ -1231,7 +1262,11 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     if (!h || !name) return PFC_ERR_BAD_ARG;
     if (!std::strcmp(name, "debug")) h->opt_debug = value != 0;
     else if (!std::strcmp(name, "profile")) h->opt_profile = value != 0;
-    else if (!std::strcmp(name, "max_levels")) h->opt_max_levels = (int)value;
+    else if (!std::strcmp(name, "max_levels")) {
+        if (value < 0 || value > (1 << 20) || (h->finalized && value > h->max_levels))
+            return fail(h, PFC_ERR_BAD_ARG, "max_levels must be 0 (automatic) or 1..%d (depth of the finalized trees + 1)", h->max_levels);
+        h->opt_max_levels = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false;
+    }
     else if (!std::strcmp(name, "bfs_levels")) h->opt_bfs_levels = (int)value;
     else if (!std::strcmp(name, "graph")) h->opt_graph = value != 0;
     else if (!std::strcmp(name, "split_min")) h->opt_split_min = (int)value;

@@ -308,12 +308,16 @@ class MechanismScenario:
         s_p = ds_p = id_p = None
         if s is not None:
             s_a, s_p = _d(s)
+            if s_a.size != 6 * n:
+                raise ValueError("s must have 6 entries per item")
         if d_s is not None:
             ds_a, ds_p = _d(d_s)
             if ds_a.size != 6 * n * n_dir:
                 raise ValueError("d_s must be (n, n_dir, 6)")
         if ins_ids is not None:
             id_a, id_p = _i(ins_ids)
+            if id_a.size != n:
+                raise ValueError("ins_ids must have one entry per item")
         wrench = np.zeros((n, 6)); sdot = np.zeros((n, 6)); counts = np.zeros((n, 4), dtype=np.int32)
         dw = np.zeros((n, n_dir, 6)); dsd = np.zeros((n, n_dir, 6))
         self._check(_lib.lib().pfc_eval_dual(self._h, n, n_dir, id_p, pose_p, tw_p, s_p, dp_p, dt_p, ds_p,

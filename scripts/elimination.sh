@@ -1,6 +1,7 @@
 #!/bin/bash
 # Elimination builds of k_narrow (see the PFC_EXP note in csrc/pfc_np.h): build the variants HERE (no GPU needed),
-# then time them on the GPU box; the product library is restored at the end.
+# then time them on the GPU box.  Variants live in csrc/exp/ and are selected with PFC_LIB (+ PFC_ALLOW_DIAGNOSTIC=1);
+# the product library csrc/libpfc_hip.so is never touched.
 #   bash scripts/elimination.sh build                      -> csrc/exp/e{0,3,4,9,7,5}.so
 #   gpurun -- 'bash scripts/elimination.sh run'            -> gpurun_out/elim.txt (unsplit narrowphase ms per variant)
 set -e
@@ -15,12 +16,9 @@ if [ "$1" = build ]; then
   wait; ls -la $C/exp
 else
   mkdir -p $R/gpurun_out; : > $R/gpurun_out/elim.txt
-  cp $C/libpfc_hip.so $C/exp/product.so
   for e in $V; do
-    cp $C/exp/e$e.so $C/libpfc_hip.so
-    (cd $R && timeout -k 10 120 python bench.py --cpu-seconds 0 --split-min 0 --steps 5 > gpurun_out/elim_$e.json) || { cp $C/exp/product.so $C/libpfc_hip.so; exit 1; }
+    (cd $R && PFC_LIB=$C/exp/e$e.so PFC_ALLOW_DIAGNOSTIC=1 timeout -k 10 120 python bench.py --cpu-seconds 0 --split-min 0 --steps 5 --no-validate > gpurun_out/elim_$e.json)
     python3 -c "import json; j=json.load(open('$R/gpurun_out/elim_$e.json')); print('PFC_EXP=$e  step %.3f ms  narrowphase %.3f ms' % (j['ms_per_step'], j['stage_ms_per_step']['narrowphase']))" >> $R/gpurun_out/elim.txt
   done
-  cp $C/exp/product.so $C/libpfc_hip.so
   cat $R/gpurun_out/elim.txt
 fi

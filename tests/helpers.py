@@ -39,3 +39,65 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     scale = max(np.linalg.norm(b), 1e-300)
     return float(np.linalg.norm(a - b) / scale)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# One (mesh_1, mesh_2, instruction, pose) scene through either backend: "oracle" (CPU restatement) or "hip" (the
+# library, through the C ABI, debug views on).  The reference's scene-level tests read m.float.bodyBodyCache after
+# one calcXd (test/test_normal.jl:31-41, test/test_friction.jl:228-236,251-256); both backends return the same view.
+# ----------------------------------------------------------------------------------------------------------------
+class SceneResult:
+    __slots__ = ("status", "wrench", "sdot", "counts", "trac", "has_K", "K", "Kbar_inv_sqrt", "Sinv", "cop")
+
+
+def normal_wrench_from_tractions(trac):
+    """normal_wrench(b) (src/contact_algorithms_normal.jl:2-15) over a TractionCache dump (n 3, r 3, dA, p)."""
+    pdA = trac[:, 6] * trac[:, 7]
+    lin = (pdA[:, None] * trac[:, 0:3]).sum(axis=0)
+    ang = np.cross(trac[:, 3:6], pdA[:, None] * trac[:, 0:3]).sum(axis=0)
+    return np.concatenate([ang, lin])
+
+
+def eval_scene(backend, pfc, mesh_1, Ebar_1, mesh_2, Ebar_2, ins, pose, twist, s=None, trees=None, options=None):
+    """ins: dict(model="regularized"|"bristle", chi, n_quad, mu_s, mu_d, v_c | tau, k_bar, magic).
+    trees: optional (OBBTree, OBBTree) supplied by the host instead of the library's builder."""
+    G = pfc.geometry
+    t1, t2 = trees if trees is not None else (G.build_tree(mesh_1), G.build_tree(mesh_2))
+    r = SceneResult()
+    if backend == "oracle":
+        m1, m2 = O.OracleMesh(mesh_1, t1, Ebar_1 or 0.0), O.OracleMesh(mesh_2, t2, Ebar_2 or 0.0)
+        if ins["model"] == "regularized":
+            oi = O.make_ins(ins["chi"], ins["n_quad"], O.REGULARIZED, ins["mu_s"], ins["mu_d"], v_c=ins["v_c"])
+        else:
+            oi = O.make_ins(ins["chi"], ins["n_quad"], O.BRISTLE, ins["mu_s"], ins["mu_d"], tau=ins["tau"],
+                            k_bar=ins["k_bar"], magic=ins["magic"])
+        e = O.evaluate(m1, m2, oi, pose, twist, s)
+        r.status, r.wrench, r.sdot, r.counts, r.trac = e.status, e.wrench, e.sdot, e.counts, e.trac
+        r.has_K, r.K, r.Kbar_inv_sqrt, r.Sinv, r.cop = e.has_K, e.K, e.Kbar_inv_sqrt, e.Sinv, e.cop
+        return r
+    assert backend == "hip"
+    S = pfc.scenario
+    m = S.MechanismScenario()
+    i1 = m.add_contact("mesh_1", mesh_1, c_prop=None if mesh_1.tri is not None else S.ContactProperties(Ebar_1), tree=t1)
+    i2 = m.add_contact("mesh_2", mesh_2, c_prop=S.ContactProperties(Ebar_2), tree=t2)
+    if ins["model"] == "regularized":
+        m.add_friction_regularize(i1, i2, mu_s=ins["mu_s"], mu_d=ins["mu_d"], chi=ins["chi"], v_tol=ins["v_c"],
+                                  n_quad_rule=ins["n_quad"])
+    else:
+        m.add_friction_bristle(i1, i2, tau=ins["tau"], k_bar=ins["k_bar"], mu_s=ins["mu_s"], mu_d=ins["mu_d"],
+                               chi=ins["chi"], n_quad_rule=ins["n_quad"], magic=ins["magic"])
+    m.finalize()
+    m.set_option("debug", 1)
+    for k, v in (options or {}).items():
+        m.set_option(k, v)
+    pose = np.asarray(pose, dtype=np.float64).reshape(1, 24)
+    twist = np.asarray(twist, dtype=np.float64).reshape(1, 6)
+    s_in = np.zeros((1, 6)) if s is None else np.asarray(s, dtype=np.float64).reshape(1, 6)
+    wrench, sdot, counts = m.force_all_elastic_intersections(pose, twist, s_in)
+    r.status, r.wrench, r.sdot, r.counts = 0, wrench[0], sdot[0], counts[0]
+    r.trac = m.debug_tractions(0)
+    st = m.debug_stiffness(0) if ins["model"] == "bristle" else None
+    r.has_K = st is not None
+    r.K, r.Kbar_inv_sqrt, r.Sinv, r.cop = st if st is not None else (None, None, None, None)
+    m.close()
+    return r

@@ -103,6 +103,32 @@ def test_dual_bad_arguments(pfc):
     with pytest.raises(pfc._lib.PFCError):
         m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, np.zeros((n, 17, 24)), np.zeros((n, 17, 6)), None,
                                                w.ins_ids)
+    # the wrapper validates buffer sizes before the library copies from them
+    with pytest.raises(ValueError):
+        m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s[:2], np.zeros((n, 2, 24)), np.zeros((n, 2, 6)), None,
+                                               w.ins_ids)
+    with pytest.raises(ValueError):
+        m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, np.zeros((n, 2, 24)), np.zeros((n, 2, 6)), None,
+                                               w.ins_ids[:2])
+    m.close()
+
+
+def test_dual_argument_checks_do_not_depend_on_the_path(pfc):
+    """Bristle instructions without the state buffer s: PFC_ERR_BAD_ARG on the two-stage path (first Dual evaluation of
+    a handle) AND on the one-graph small-scene path (every later one), which used to evaluate silently with s = 0."""
+    L = pfc._lib
+    w = pfc.configs.c3_blob_tool(3, n_div_blob=5, n_div_tool=4)
+    m = pfc.configs.build_scenario(w)
+    n = w.n_items
+    dp, dt = np.zeros((n, 2, 24)), np.zeros((n, 2, 6))
+    with pytest.raises(L.PFCError) as ei:
+        m.force_all_elastic_intersections_dual(w.pose, w.twist, None, dp, dt, None, w.ins_ids)
+    assert ei.value.status == L.ERR_BAD_ARG
+    m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, dp, dt, None, w.ins_ids)    # sets the small-scene hint
+    m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, dp, dt, None, w.ins_ids)    # one-graph path
+    with pytest.raises(L.PFCError) as ei:
+        m.force_all_elastic_intersections_dual(w.pose, w.twist, None, dp, dt, None, w.ins_ids)
+    assert ei.value.status == L.ERR_BAD_ARG
     m.close()
 
 

@@ -297,3 +297,32 @@ def test_soak_mixed_value_and_dual_on_one_handle(pfc):
         for k, tol in cmp:
             np.testing.assert_allclose(got[k], ref[k], rtol=tol, atol=tol * max(np.abs(ref[k]).max(), 1e-300), err_msg=f"{it} {size} {k}")
     m.close()
+
+
+def test_max_levels_option_is_clamped(pfc):
+    """Option "max_levels": every counter / tail buffer is sized from the finalized tree depth, so a larger value is
+    refused (PFC_ERR_BAD_ARG) and a smaller one only caps the seed-expansion levels; results never change."""
+    L = pfc._lib
+    w = pfc.configs.c3_blob_tool(40, n_div_blob=6, n_div_tool=5)
+    m = pfc.configs.build_scenario(w)
+    depth_sum = m.MeshCache[0].tree.depth() + m.MeshCache[1].tree.depth()
+    wr0, sd0, ct0 = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    for bad in (depth_sum + 2, 10 ** 6, -1):
+        with pytest.raises(L.PFCError) as ei:
+            m.set_option("max_levels", bad)
+        assert ei.value.status == L.ERR_BAD_ARG
+    for lv in (1, 2, depth_sum + 1, 0):
+        m.set_option("max_levels", lv)
+        for bfs in (-1, 3):
+            m.set_option("bfs_levels", bfs)
+            wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+            assert np.array_equal(ct, ct0), (lv, bfs)
+            np.testing.assert_allclose(wr, wr0, rtol=1e-11, atol=1e-11 * np.abs(wr0).max())
+    m.close()
+    # set before finalize: nothing to validate against yet, the effective value is clamped at evaluation time
+    m2 = pfc.MechanismScenario()
+    for ms in w.meshes:
+        m2.add_contact(ms.name, ms.mesh, c_prop=None if ms.Ebar is None else pfc.ContactProperties(ms.Ebar), tree=ms.tree)
+    m2.add_friction_bristle(0, 1, mu_d=0.3)
+    m2.finalize()
+    m2.close()

@@ -1,5 +1,5 @@
 """The Dual-number (value + partials) oracle, oracle/pfc_oracle_dual.cpp, pinned by central differences of the value
-oracle (which the reference's own analytic tests pin, tests/test_oracle_kat.py / test_oracle_scenes.py).  The Dual
+oracle (which the reference's own analytic tests pin, tests/test_oracle_kat.py / test_scene_kats.py).  The Dual
 path is what Radau's Jacobian evaluation runs (src/mechanism_scenario.jl:187, src/radau/radau_functions.jl:2-40)."""
 import numpy as np
 import pytest
