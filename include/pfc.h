@@ -175,7 +175,10 @@ int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, con
  * vector-ALU-bound broadphase of one half sharing the CUs with the latency-bound narrowphase of the other; results,
  * counters and stream ordering are those of the unsplit call), "poison" (diagnostic, default 0: before every
  * evaluation the work lists are filled with entries whose item index is -1; the kernels never follow an item index
- * out of range but report it, PFC_ERR_STATE "a work-list slot was read before it was written"). */
+ * out of range but report it, PFC_ERR_STATE "a work-list slot was read before it was written"), "fused" (default 1:
+ * an evaluation of <= 256 items over small trees runs as ONE kernel, one workgroup per item, instead of the batched
+ * launch sequence -- the scene sizes Radau evaluates, src/radau/radau_functions.jl:2-14,64-70; same results; 0 = always
+ * batched; the debug / profile options imply the batched path). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);
 
 /* Totals of the last checked evaluation: out[0..7] = {node tests, candidate pairs, non-empty pairs, traction
@@ -187,7 +190,8 @@ int pfc_get_stats(pfc_handle h, long long *out8);
  * ran as two concurrent halves (pfc_last_parts() == 2) a stage time is the mean over the two half-launches, each of
  * which processed half of the items while stages of the other half were running; total is the longer half. */
 int pfc_get_stage_ms(pfc_handle h, float *out6);
-int pfc_last_parts(pfc_handle h);   /* 1, or 2 if the last checked evaluation ran as two concurrent halves */
+int pfc_last_parts(pfc_handle h);   /* 1, or 2 if the last checked evaluation ran as two concurrent halves; 0: it ran as the
+                                     * single fused small-scene kernel (option "fused") */
 
 /*
  * Debug views of the last evaluation (debug option), needed to restate test/test_normal.jl:31-41 and

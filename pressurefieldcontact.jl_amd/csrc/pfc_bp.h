@@ -257,8 +257,8 @@ constexpr int kDfsOut32 = 1280;     // staged candidates per workgroup (10 KiB)
 // bb_compose() / sat15(), so the boolean is the reference's bit for bit, and the per-lane register need is a few
 // dozen instead of the ~220 of the one-lane-per-pair Float64 test (which cost the kernel a third of its occupancy
 // when inlined, and as a no-inline call needed scratch).  xs: 33 doubles per 16-lane group.
-__device__ __forceinline__ void exact_pairs_coop(const ItemRec *it, const double *pose, const int2 *und_l, int n_def,
-                                                 double *xs, int *und_v, int tid) {
+__device__ __forceinline__ void exact_pairs_coop(const NodeRec *nodes1, const NodeRec *nodes2, const double *pose,
+                                                 const int2 *und_l, int n_def, double *xs, int *und_v, int tid) {
     const int grp = tid >> 4, sub = tid & 15;
     double *T = xs + grp * 33, *tt = T + 9, *R = T + 12, *aR = T + 21, *t = T + 30;
     for (int c0 = 0; c0 < n_def; c0 += kDfsBlock / 16) {
@@ -266,7 +266,7 @@ __device__ __forceinline__ void exact_pairs_coop(const ItemRec *it, const double
         const bool valid = j < n_def;
         int2 e = make_int2(0, 0);
         if (valid) e = und_l[j];
-        const GNodeRec *na = (const GNodeRec *)(it->nodes1 + node_index(e.x)), *nb = (const GNodeRec *)(it->nodes2 + node_index(e.y));
+        const GNodeRec *na = (const GNodeRec *)(nodes1 + node_index(e.x)), *nb = (const GNodeRec *)(nodes2 + node_index(e.y));
         if (valid && sub < 9) {
             const int i = sub % 3, jj = sub / 3;
             const double r0 = na->R[3 * i], r1 = na->R[3 * i + 1], r2 = na->R[3 * i + 2];
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
             if (p > pw) p = pw;
             if (settle) {
                 p = n_def;
-                exact_pairs_coop(it, s_pose, und_l, n_def, xs, und_v, tid);   // ends with a barrier
+                exact_pairs_coop(it->nodes1, it->nodes2, s_pose, und_l, n_def, xs, und_v, tid);   // ends with a barrier
             }
             const bool act = tid < p;
             int2 e = make_int2(0, 0);

@@ -168,15 +168,13 @@ __device__ __forceinline__ void jacobi6_wave(double *A, double *V, int lane) {
     }
 }
 
-// decompose_K! / calc_K̄_sqrt_inv / Δ² (friction.jl:85-132): one wave per bristle item in contact
-__global__ void __launch_bounds__(64) k_eig(BrArgs g) {
-    __shared__ double K[36], A[36], V[36], Kis[36], sig[6], Sinv[6];
-    const int i = blockIdx.x, lane = threadIdx.x;
-    if (i >= g.n_items) return;
-    const ItemRec *it = g.items + i;
-    if (it->model != PFC_BRISTLE || g.icnt[4 * (size_t)i + 3] == 0) return;   // uniform over the wave
-    const double *a = g.acc + (size_t)i * kAccStride;
-    double *r = g.res + (size_t)i * kResStride;
+// decompose_K! / calc_K̄_sqrt_inv / Δ² (friction.jl:85-132) of one bristle item in contact, carried by ONE wave.
+// a: the item's accumulator block (kAcc* layout, moments about the cop), r: its result block (kRes* layout, global or
+// LDS), s: the bristle state; E: LDS scratch of the wave.
+struct EigScratch { double K[36], A[36], V[36], Kis[36], sig[6], Sinv[6]; };
+__device__ __forceinline__ void eig_item(const double *a, double k_bar, double magic, const double *s, double *r,
+                                         EigScratch &E, int lane) {
+    double *K = E.K, *A = E.A, *V = E.V, *Kis = E.Kis, *sig = E.sig, *Sinv = E.Sinv;
     // cop = sum w r / sum w (normal.jl:33)
     const double S = a[kAccIp];
     if (lane < 3) r[kResCop + lane] = a[kAccIpc + lane] / S;
@@ -199,14 +197,14 @@ __global__ void __launch_bounds__(64) k_eig(BrArgs g) {
         } else {
             kv = -a[kAccSan + bj + 3 * bi];        // K21 = K12'
         }
-        kv *= it->k_bar;
+        kv *= k_bar;
         K[lane] = kv;
         r[kResK + lane] = kv;
     }
     wave_lds_sync();
     if (lane < 6) {
         const double t1 = (K[0] + K[7]) + K[14], t2 = (K[21] + K[28]) + K[35];
-        Sinv[lane] = lane < 3 ? (1.0 / __builtin_sqrt(t1)) * it->magic : 1.0 / __builtin_sqrt(t2);
+        Sinv[lane] = lane < 3 ? (1.0 / __builtin_sqrt(t1)) * magic : 1.0 / __builtin_sqrt(t2);
     }
     wave_lds_sync();
     if (lane < 36) {
@@ -235,10 +233,20 @@ __global__ void __launch_bounds__(64) k_eig(BrArgs g) {
     if (lane < 6) {
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc += Kis[lane + 6 * k] * it->s[k];
+        for (int k = 0; k < 6; ++k) acc += Kis[lane + 6 * k] * s[k];
         r[kResDelta + lane] = Sinv[lane] * acc;
         r[kResSinv + lane] = Sinv[lane];
     }
+}
+
+// one wave per bristle item in contact
+__global__ void __launch_bounds__(64) k_eig(BrArgs g) {
+    __shared__ EigScratch E;
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= g.n_items) return;
+    const ItemRec *it = g.items + i;
+    if (it->model != PFC_BRISTLE || g.icnt[4 * (size_t)i + 3] == 0) return;   // uniform over the wave
+    eig_item(g.acc + (size_t)i * kAccStride, it->k_bar, it->magic, it->s, g.res + (size_t)i * kResStride, E, lane);
 }
 
 // yes_contact! / no_contact! epilogue (friction.jl:76-81,119-143; non_friction.jl:77-83)

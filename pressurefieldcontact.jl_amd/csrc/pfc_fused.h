@@ -1,0 +1,647 @@
+// pfc_fused.h -- small scenes: the whole evaluation of ONE item by ONE workgroup in ONE launch.  Included by pfc_hip.hip
+// inside namespace pfc (device code only).
+//
+// What Radau actually evaluates (src/radau/radau_functions.jl:2-14,64-70 on scenes like test/boxes.jl: a handful of
+// instructions, <= a few hundred candidate pairs each) is latency, not throughput: the batched pipeline is six to
+// fourteen dependent kernels, each paying a launch boundary and its own chain of memory round trips, for ~200 ops.
+// Here one 256-thread workgroup per (instruction, pose) item does everything force_single_elastic_intersection!
+// (src/contact_algorithms_non_friction.jl:70-84) does, without leaving the CU:
+//   0. item record (instruction parameters, mesh pointers, pose, twist, s) -> LDS: two dependent loads
+//   1. broadphase: the first kFuNodes nodes of both trees (the device node order is breadth-first, so these are the top
+//      levels) are copied to LDS once; the depth-first descent of k_bp_dfs32 (same Float32 filter, same cooperative
+//      exact Float64 settle, same node tests) then runs from LDS; candidates stay in an LDS list
+//   2. clip: one thread per candidate (rounds of 256): gather, tet coordinates, trivial reject, Sutherland-Hodgman in
+//      the LDS polygon ring, Cartesian polygon + centroid -- the expressions of k_narrow, bit for bit
+//   3. integrate: the fan triangles of all polygons of the round are dealt out one per thread (the batched kernel walks
+//      a polygon's <= 8 triangles x 3 points serially in one lane: ~17 k cycles; here a thread does 3 points), sums
+//      stay in registers, one block reduction at the end
+//   4. bristle items: cop -> second pass (patch stiffness moments about the cop, the reference's own second pass,
+//      src/contact_algorithms_friction.jl:147-169) -> 6x6 eigen on wave 0 -> third pass (friction) -> epilogue
+// Outputs: wrench, sdot, counts and a per-item status word; no global counters, no atomics, nothing to zero.
+// An item that does not fit (candidates > kFuCand) reports kStFusedOvf; the host then takes the batched path.
+#pragma once
+
+constexpr int kFuBlock = 256;
+constexpr int kFuWaves = kFuBlock / 64;
+constexpr int kFuCand = 4096;      // candidate pairs per item held in LDS (32 KiB)
+constexpr int kFuNodes = 256;      // nodes per tree cached in LDS (2 x 16 KiB)
+constexpr int kFuStack = 2560;     // node pairs (20 KiB), as k_bp_dfs32
+constexpr unsigned kStFusedOvf = 512u;   // item does not fit the fused kernel's LDS lists: use the batched path
+
+// Everything an item needs from its instruction, in one 256-byte record (built at pfc_finalize): one load instead of
+// the chain InsDev -> MeshDev x 2 of the batched path.
+struct alignas(16) InsFull {
+    const NodeRec *nodes1, *nodes2;
+    const NodeF *nf1, *nf2;
+    const TriRec *tri;       // mesh_1 triangles, or null (tet-tet)
+    const TetRec *tet;       // mesh_2 tets
+    const TetRec *tet1;      // mesh_1 tets (tet-tet) or null
+    const double *eps1, *eps2;
+    double chi, Ebar, Ebar1, mu_s, mu_d, v_c, tau, k_bar, magic;
+    int model, nq, n_node1, n_node2, reserve, pad[11];
+};
+static_assert(sizeof(InsFull) == 208 || sizeof(InsFull) == 256 || sizeof(InsFull) % 16 == 0, "InsFull layout");
+
+struct FuArgs {
+    int n_items, n_ins;
+    const int *ins_ids;      // may be null
+    const double *pose, *twist, *s;
+    const InsFull *ins;
+    double *wrench, *sdot;
+    int *counts;             // may be null
+    int *fout;               // per item 8 ints: status, counts[4], 0, 0, 0
+};
+
+struct FuItem {
+    InsFull ins;
+    double pose[24];         // R21 9, t21 3, R12 9, t12 3
+    double twist[6];         // w 3, v 3
+    double s[6];
+};
+
+// wave total of a double on DPP (row_shr 1/2/4/8, row_bcast 15/31), returned as a uniform value
+__device__ __forceinline__ double wave_total(double v, int lane) {
+    double t;
+    t = dpp_move<0x111, 0xF>(v); v += t;
+    t = dpp_move<0x112, 0xF>(v); v += t;
+    t = dpp_move<0x114, 0xF>(v); v += t;
+    t = dpp_move<0x118, 0xF>(v); v += t;
+    t = dpp_move<0x142, 0xA>(v); v += (lane & 16) ? t : 0.0;
+    t = dpp_move<0x143, 0xC>(v); v += (lane >= 32) ? t : 0.0;
+    return readlane_f64(v, 63);
+}
+__device__ __forceinline__ int wave_total_i(int v, int lane) {
+    return __builtin_amdgcn_readlane(seg_incl_scan(v), 63);
+}
+
+// block totals of N per-thread values: wave totals on DPP, then the four wave totals meet in LDS; every thread returns
+// the same N totals in out[] (same summation order in every thread).  red: kFuWaves x 32 doubles.
+template <int N>
+__device__ __forceinline__ void block_partials(const double *v, double *red, int tid) {
+    static_assert(N <= 32, "red holds 32 values per wave");
+    const int lane = tid & 63, wave = tid >> 6;
+    __syncthreads();                       // red may still be read by the previous reduction
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double t = wave_total(v[k], lane);
+        if (lane == 0) red[wave * 32 + k] = t;
+    }
+    __syncthreads();
+}
+template <int N>
+__device__ __forceinline__ void block_totals(const double *v, double *out, double *red, int tid) {
+    block_partials<N>(v, red, tid);
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = ((red[k] + red[32 + k]) + red[64 + k]) + red[96 + k];
+}
+
+struct FuBp {                 // broadphase view of the scratch region (aliases the polygon ring)
+    int2 stk[kFuStack];
+    NodeF n1[kFuNodes], n2[kFuNodes];
+    int2 und_l[kFuBlock];
+    int und_v[kFuBlock];
+    double xs[(kFuBlock / 16) * 33];
+};
+union FuScratch {
+    FuBp bp;
+    double ring[8 * 4 * kFuBlock];   // polygon ring: [slot][coord][thread]
+    __device__ FuScratch() {}
+};
+
+// polygon ring of thread `t`: logical vertex k lives in physical slot (rb + k) & 7
+#define FR(t, rb, k, c) ring[(((((rb) + (k)) & 7) * 4 + (c)) * kFuBlock) + (t)]
+// after the conversion to Cartesian coordinates the fourth coordinate of every slot is free: slots 0..5 hold n̂, centroid
+#define FX(t, s) ring[((((s) * 4) + 3) * kFuBlock) + (t)]
+
+__global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
+    __shared__ FuScratch S;
+    __shared__ int2 cand[kFuCand];
+    __shared__ unsigned fan[8 * kFuBlock];      // (thread that owns the polygon) | (fan triangle) << 16
+    __shared__ double s_epsr[4][kFuBlock];      // ϵ_r² of the lane's tet
+    __shared__ int s_np[kFuBlock], s_rb[kFuBlock];
+    __shared__ double red[kFuWaves * 32];
+    __shared__ int s_cnt[kFuWaves][2], s_def[2], s_scan[kFuWaves];
+    __shared__ FuItem I;
+    __shared__ double s_acc[kAccStride], s_res[kResStride];
+    __shared__ EigScratch E;
+    __shared__ float s_posef[12];
+    double *ring = S.ring;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int item = blockIdx.x;
+    unsigned status = 0;
+
+    // ==== 0. the item ==============================================================================================
+    int id = g.ins_ids ? g.ins_ids[item] : item;
+    if (id < 0 || id >= g.n_ins) { status |= kStBadIns; id = 0; }
+    {
+        constexpr int nw = (int)(sizeof(InsFull) / sizeof(int));
+        static_assert(nw <= 64, "InsFull is loaded by the first wave");
+        if (tid < nw) reinterpret_cast<int *>(&I.ins)[tid] = reinterpret_cast<const int *>(g.ins + id)[tid];
+        if (tid >= 64 && tid < 88) {
+            const double x = g.pose[24 * (size_t)item + (tid - 64)];
+            I.pose[tid - 64] = x;
+            if (!(__builtin_fabs(x) <= 1.79769313486231570815e308)) status |= kStNonFinite;
+        }
+        if (tid >= 96 && tid < 102) I.twist[tid - 96] = g.twist[6 * (size_t)item + (tid - 96)];
+        if (tid >= 128 && tid < 134) I.s[tid - 128] = g.s ? g.s[6 * (size_t)item + (tid - 128)] : 0.0;
+    }
+    __syncthreads();
+    const bool reg = I.ins.model == PFC_REGULARIZED;
+    const int nq = (I.ins.nq == 1) ? 1 : 3;
+    if (tid < 9) s_posef[tid] = (float)I.pose[12 + tid];
+    // a non-finite pose is reported ("Non-finite vertex likely", static_clip.jl:52), not traversed (uniform)
+    bool pose_ok = true;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) pose_ok &= (__builtin_fabs(I.pose[k]) <= 1.79769313486231570815e308);
+
+    // ==== 1. broadphase (tree_tree_intersect, src/obb/tree_types.jl:88-111) ===========================================
+    int n_cand = 0, n_test = 0;
+    if (pose_ok) {
+        FuBp &B = S.bp;
+        const int nc1 = I.ins.n_node1 < kFuNodes ? I.ins.n_node1 : kFuNodes;
+        const int nc2 = I.ins.n_node2 < kFuNodes ? I.ins.n_node2 : kFuNodes;
+        for (int k = tid; k < nc1 * 4; k += kFuBlock) reinterpret_cast<vec4i *>(B.n1)[k] = ((const gvec4i *)I.ins.nf1)[k];
+        for (int k = tid; k < nc2 * 4; k += kFuBlock) reinterpret_cast<vec4i *>(B.n2)[k] = ((const gvec4i *)I.ins.nf2)[k];
+        if (tid == 0) {
+            // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
+            B.stk[0] = make_int2(I.ins.n_node1 == 1 ? ~0 : 0, I.ins.n_node2 == 1 ? ~0 : 0);
+            s_def[0] = s_def[1] = 0;
+        }
+        __syncthreads();
+        const NodeF *n1 = I.ins.nf1, *n2 = I.ins.nf2;
+        const double *s_pose = I.pose + 12;          // R_a_b (9, column-major), t_a_b (3): x_r1_r2
+        const int reserve = I.ins.reserve;
+        int sp = 1, n_def = 0, par = 0;
+        bool ovf = false;
+        for (int guard = 0; (sp > 0 || n_def > 0) && guard < (1 << 22); ++guard, par ^= 1) {
+            const bool settle = n_def > 0;
+            int pw = (kFuStack - reserve - sp) / 3;
+            int p = sp < kFuBlock ? sp : kFuBlock;
+            if (pw < 1) pw = 1;
+            if (p > pw) p = pw;
+            if (settle) {
+                p = n_def;
+                exact_pairs_coop(I.ins.nodes1, I.ins.nodes2, s_pose, B.und_l, n_def, B.xs, B.und_v, tid);   // ends with a barrier
+            }
+            const bool act = tid < p;
+            int2 e = make_int2(0, 0);
+            if (act) e = settle ? B.und_l[tid] : B.stk[sp - 1 - tid];
+            if (!settle) { sp -= p; n_test += p; }
+            int verdict = 0, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            if (settle && act) verdict = B.und_v[tid];
+            const bool la = act && e.x < 0, lb = act && e.y < 0;
+            if (act) {
+                const int ia = node_index(e.x), ib = node_index(e.y);
+                NodeF a, b;
+                if (ia < nc1) a = B.n1[ia]; else a = load_nodef(n1 + ia);
+                if (ib < nc2) b = B.n2[ib]; else b = load_nodef(n2 + ib);
+                a0 = a.link0; a1 = a.link1; b0 = b.link0; b1 = b.link1;
+                if (!settle) {
+                    double R12[9], t12[3];
+                    float R12f[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) { R12[k] = s_pose[k]; R12f[k] = s_posef[k]; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
+                    verdict = test_pair_f32(a, b, la || lb, R12, R12f, t12);
+                }
+            }
+            if (verdict == 2) B.und_l[atomicAdd(&s_def[par], 1)] = e;
+            const bool hit = verdict == 1;
+            const bool is_cand = hit && la && lb;
+            const bool two = hit && (la != lb);
+            const bool four = hit && !la && !lb;
+            const unsigned long long mc = __ballot(is_cand), m2 = __ballot(two), m4 = __ballot(four);
+            if (lane == 0) {
+                s_cnt[wave][0] = __builtin_popcountll(mc);
+                s_cnt[wave][1] = 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
+            }
+            __syncthreads();
+            n_def = s_def[par];
+            if (tid == 0) s_def[par ^ 1] = 0;
+            int c_off = 0, p_off = 0, c_tot = 0, p_tot = 0;
+#pragma unroll
+            for (int w = 0; w < kFuWaves; ++w) {
+                const int c = s_cnt[w][0], q = s_cnt[w][1];
+                if (w < wave) { c_off += c; p_off += q; }
+                c_tot += c; p_tot += q;
+            }
+            if (is_cand) {
+                const int pos = n_cand + c_off + prefix_count(mc);
+                if (pos < kFuCand) cand[pos] = make_int2(a0, b0);     // leaf: link0 = element index
+            }
+            if (two | four) {
+                const int pos = sp + p_off + 2 * prefix_count(m2) + 4 * prefix_count(m4);
+                if (two) {
+                    if (la) {  // leaf_1: descend tree_2 (:97-98)
+                        B.stk[pos] = make_int2(e.x, b0); B.stk[pos + 1] = make_int2(e.x, b1);
+                    } else {   // leaf_2: descend tree_1 (:101-103)
+                        B.stk[pos] = make_int2(a0, e.y); B.stk[pos + 1] = make_int2(a1, e.y);
+                    }
+                } else {       // (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107)
+                    B.stk[pos] = make_int2(a0, b0); B.stk[pos + 1] = make_int2(a1, b0);
+                    B.stk[pos + 2] = make_int2(a0, b1); B.stk[pos + 3] = make_int2(a1, b1);
+                }
+            }
+            n_cand += c_tot;
+            sp += p_tot;
+            if (n_cand > kFuCand) { ovf = true; sp = 0; n_def = 0; }    // uniform: the item leaves for the batched path
+            __syncthreads();
+        }
+        if (ovf) status |= kStFusedOvf;
+        else if (sp > 0 || n_def > 0) status |= kStAbort;
+    }
+    if (status & (kStFusedOvf | kStAbort)) n_cand = 0;   // uniform
+
+    // ==== 2.-4. narrowphase ===========================================================================================
+    // pass 0: normal wrench (+ regularized friction fused) + cop sums; bristle: pass 1 patch stiffness about the cop,
+    // pass 2 friction.  With more than one round of candidates the polygons of earlier rounds are gone from the ring and
+    // are clipped again in the later passes.
+    const int n_round = (n_cand + kFuBlock - 1) / kFuBlock;
+    int n_nonempty = 0, n_trac = 0;
+    double tot10[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) tot10[k] = 0.0;
+    V3 cop = mk3(0.0, 0.0, 0.0), ts_c0 = cop, ts_e = cop;
+    const V3 w = mk3(I.twist[0], I.twist[1], I.twist[2]), vl = mk3(I.twist[3], I.twist[4], I.twist[5]);
+    const double chi = I.ins.chi, Ebar = I.ins.Ebar, v_c = I.ins.v_c, mu_s = I.ins.mu_s, mu_d = I.ins.mu_d;
+    const int n_pass = reg ? 1 : 3;
+    bool contact = false;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        if (pass > 0 && !contact) break;          // uniform
+        double acc[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+        int my_ne = 0, my_nt = 0;
+        for (int rd = 0; rd < n_round; ++rd) {
+            // ---- clip (only once if a single round holds every candidate) -------------------------------------------
+            if (pass == 0 || n_round > 1) {
+                __syncthreads();               // ring / fan of the previous round are free
+                const int ci = rd * kFuBlock + tid;
+                int n_poly = 0, rbase = 0;
+                if (ci < n_cand) {
+                    const int2 cw = cand[ci];
+                    const GTetRec *tp = (const GTetRec *)(I.ins.tet + cw.y);
+                    const GTriRec *tr = (const GTriRec *)(I.ins.tri + cw.x);
+                    double Z[16], tv[9], tn[3], V[12], er[4];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) tv[k] = tr->v[k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) tn[k] = tr->n[k];
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) er[k] = tp->epsr[k];
+                    double R21[9], t21[3];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) R21[k] = I.pose[k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t21[k] = I.pose[9 + k];
+                    // ---- tri-tet op (non_friction.jl:196-215): x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (:204) ----------------
+                    double X[16], z[3][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
+                        X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + Z[i + 12];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            z[k][i] = ((X[i] * tv[3 * k] + X[i + 4] * tv[3 * k + 1]) + X[i + 8] * tv[3 * k + 2]) + X[i + 12];
+                    const V3 nh_in = mk3((R21[0] * tn[0] + R21[3] * tn[1]) + R21[6] * tn[2],
+                                         (R21[1] * tn[0] + R21[4] * tn[1]) + R21[7] * tn[2],
+                                         (R21[2] * tn[0] + R21[5] * tn[1]) + R21[8] * tn[2]);
+                    bool finite = true;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) finite &= (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
+                    if (!finite) status |= kStNonFinite;
+                    // trivial reject (bit-exact shortcut of static_clip.jl:44, see k_narrow)
+                    bool reject = !finite;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0);
+                    if (!reject) {
+                        // ---- clip_in_tet_coordinates (static_clip.jl:7-23,34-201), in place in the LDS ring ----------
+                        int n = 3;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) FR(tid, rbase, k, i) = z[k][i];
+                        bool err = false;
+                        for (int i = 0; i < 4 && n > 0; ++i) {
+                            unsigned nonpos = 0, nonneg = 0;
+                            for (int k = 0; k < n; ++k) {
+                                const double sv = FR(tid, rbase, k, i);
+                                nonpos |= (unsigned)(sv <= 0.0) << k;
+                                nonneg |= (unsigned)(0.0 <= sv) << k;
+                            }
+                            const unsigned full = (1u << n) - 1u;
+                            if (nonpos == full) { n = 0; break; }       // :44
+                            if (nonneg == full) continue;               // :45-46
+                            const unsigned nxt = ((nonpos >> 1) | ((nonpos & 1u) << (n - 1))) & full;
+                            const unsigned cand_start = nonpos & ~nxt & full;
+                            if (cand_start == 0) { err = true; n = 0; break; }  // "Non-finite vertex likely" (:52)
+                            const int st = __builtin_ctz(cand_start);
+                            int m = n;
+                            while (m > 3) {
+                                int k2 = st + m - 2; if (k2 >= n) k2 -= n;
+                                if ((nonpos >> k2) & 1u) --m; else break;
+                            }
+                            int k1 = st + 1; if (k1 >= n) k1 -= n;
+                            int kl = st + m - 1; if (kl >= n) kl -= n;
+                            int kp = st + m - 2; if (kp >= n) kp -= n;
+                            const bool inside = (m <= 5) ? (((nonpos >> kl) & 1u) == 0) : (((nonneg >> kl) & 1u) != 0);
+                            double zs[4], ze[4];
+                            {
+                                const double w1 = FR(tid, rbase, st, i), w2 = FR(tid, rbase, k1, i);
+                                const double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) zs[c] = c1 * FR(tid, rbase, k1, c) - c2 * FR(tid, rbase, st, c);
+                            }
+                            {
+                                const int kn = inside ? st : kl, kq = inside ? kl : kp;
+                                const double w1 = FR(tid, rbase, kn, i), w2 = FR(tid, rbase, kq, i);
+                                const double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) ze[c] = c1 * FR(tid, rbase, kq, c) - c2 * FR(tid, rbase, kn, c);
+                            }
+                            const int ncopy = inside ? (m - 1) : (m - 2);
+                            for (int q = n - st - 1; q < ncopy; ++q) {
+                                const int src = st + 1 + q - n, dst = st + 1 + q;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) { const double t = FR(tid, rbase, src, c); FR(tid, rbase, dst, c) = t; }
+                            }
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) { FR(tid, rbase, st, c) = zs[c]; FR(tid, rbase, st + ncopy + 1, c) = ze[c]; }
+                            rbase = (rbase + st) & 7;
+                            n = ncopy + 2;
+                            if (m == 7) break;  // the 7-vertex method returns the polygon directly (:185-195)
+                        }
+                        if (err) status |= kStNonFinite;
+                        n_poly = n;
+                    }
+                    if (n_poly >= 3) {
+                        // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98) fused with centroid(poly_r2, n̂2)
+                        // (poly_eight.jl:35-52), as in k_narrow
+                        const int n = n_poly;
+                        auto conv = [&](int k) {
+                            const double z0 = FR(tid, rbase, k, 0), z1 = FR(tid, rbase, k, 1), z2 = FR(tid, rbase, k, 2), z3 = FR(tid, rbase, k, 3);
+                            const V3 x = mk3(((V[0] * z0 + V[3] * z1) + V[6] * z2) + V[9] * z3,
+                                             ((V[1] * z0 + V[4] * z1) + V[7] * z2) + V[10] * z3,
+                                             ((V[2] * z0 + V[5] * z1) + V[8] * z2) + V[11] * z3);
+                            FR(tid, rbase, k, 0) = x.x; FR(tid, rbase, k, 1) = x.y; FR(tid, rbase, k, 2) = x.z;
+                            return x;
+                        };
+                        const V3 a = conv(0);
+                        V3 cc = conv(1);
+                        double cum_sum = 0.0;
+                        V3 cum_prod = mk3(0.0, 0.0, 0.0);
+                        for (int k = 2; k < n; ++k) {
+                            const V3 b = cc;
+                            cc = conv(k);
+                            const double ar = triangle_area(a, b, cc, nh_in);
+                            cum_prod = cum_prod + ((a + b) + cc) * (1.0 / 3.0) * ar;
+                            cum_sum += ar;
+                        }
+                        const V3 cen = (cum_sum == 0.0) ? a : cum_prod / cum_sum;
+                        FX(tid, 0) = nh_in.x; FX(tid, 1) = nh_in.y; FX(tid, 2) = nh_in.z;
+                        FX(tid, 3) = cen.x; FX(tid, 4) = cen.y; FX(tid, 5) = cen.z;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) s_epsr[k][tid] = er[k];
+                        if (pass == 0) ++my_ne;
+                    }
+                }
+                s_np[tid] = n_poly >= 3 ? n_poly : 0;
+                s_rb[tid] = rbase;
+                // ---- deal the fan triangles out: exclusive scan of the vertex counts over the workgroup -------------
+                const int np = n_poly >= 3 ? n_poly : 0;
+                const int incl = seg_incl_scan(np);
+                if (lane == 63) s_scan[wave] = incl;
+                __syncthreads();
+                int off = incl - np;
+                for (int wv = 0; wv < kFuWaves; ++wv) if (wv < wave) off += s_scan[wv];
+                for (int k = 0; k < np; ++k) fan[off + k] = (unsigned)tid | ((unsigned)k << 16);
+                __syncthreads();
+            }
+            const int n_fan = ((s_scan[0] + s_scan[1]) + s_scan[2]) + s_scan[3];
+            // ---- integrate_over_polygon_patch! (non_friction.jl:217-265): one fan triangle per thread ------------------
+            for (int wi = tid; wi < n_fan; wi += kFuBlock) {
+                const unsigned fe = fan[wi];
+                const int pt = (int)(fe & 0xFFFFu), k = (int)(fe >> 16);
+                const int n = s_np[pt], rb = s_rb[pt];
+                const int km = k == 0 ? n - 1 : k - 1;
+                const V3 nh = mk3(FX(pt, 0), FX(pt, 1), FX(pt, 2)), cen = mk3(FX(pt, 3), FX(pt, 4), FX(pt, 5));
+                const V3 v1 = mk3(FR(pt, rb, km, 0), FR(pt, rb, km, 1), FR(pt, rb, km, 2));
+                const V3 v2 = mk3(FR(pt, rb, k, 0), FR(pt, rb, k, 1), FR(pt, rb, k, 2));
+                const double er0 = s_epsr[0][pt], er1 = s_epsr[1][pt], er2 = s_epsr[2][pt], er3 = s_epsr[3][pt];
+                const double area = triangle_area(v1, v2, cen, nh);
+                if (!(0.0 < area)) continue;  // :232
+                double tW = 0.0, tm[3] = {0.0, 0.0, 0.0}, tq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                for (int q = 0; q < nq; ++q) {
+                    // TriTetQuadRule rules 1 and 2, literal decimals of src/clip/quadrature.jl:24-39
+                    double q0, q1, q2, qw;
+                    if (nq == 1) {
+                        q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
+                    } else {
+                        const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
+                        q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
+                        qw = 0.33333333333333331483;
+                    }
+                    // fillTractionCacheInnerLoop! (:251-265)
+                    const V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
+                                     (v1.z * q0 + v2.z * q1) + cen.z * q2);
+                    double eq = __builtin_fma(er0, r.x, er3);
+                    eq = __builtin_fma(er1, r.y, eq);
+                    eq = __builtin_fma(er2, r.z, eq);
+                    const V3 rdot = vl + cross(w, r);
+                    const double ee = -dot(mk3(er0, er1, er2), rdot);
+                    const double damp = fmax(0.0, 1.0 + chi * ee);
+                    const double p = eq * Ebar * damp;
+                    const double dA = qw * area;
+                    if (!(0.0 < p)) continue;  // :245
+                    const double p_dA = p * dA;
+                    if (pass == 0) {
+                        ++my_nt;
+                        if (reg) {
+                            // yes_contact!(::Regularized) (friction.jl:50-72), as fused in k_narrow
+                            const V3 vt = vec_sub_vec_proj(rdot, nh);
+                            const double m2 = dot_fma(vt, vt);
+                            V3 T;
+                            if (m2 < v_c * v_c) {
+                                T = vt * (-(mu_s / v_c));
+                            } else {
+                                double ri = __builtin_amdgcn_rsq(m2);
+                                const double hm = 0.5 * m2;
+                                ri = ri * __builtin_fma(-hm * ri, ri, 1.5);
+                                ri = ri * __builtin_fma(-hm * ri, ri, 1.5);
+                                const double mg = m2 * ri;
+                                const double mu = clamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
+                                T = vt * (-(mu * ri));
+                            }
+                            const V3 tk = (nh + T) * p_dA;
+                            const V3 ta = cross_fma(r, tk);
+                            acc[0] += ta.x; acc[1] += ta.y; acc[2] += ta.z;
+                            acc[3] += tk.x; acc[4] += tk.y; acc[5] += tk.z;
+                        } else {
+                            // normal_wrench_cop (normal.jl:17-34): n̂ is constant over the polygon
+                            const V3 rc = r - cen;
+                            tW += p_dA;
+                            tm[0] += p_dA * rc.x; tm[1] += p_dA * rc.y; tm[2] += p_dA * rc.z;
+                        }
+                    } else if (pass == 1) {
+                        // calc_patch_spatial_stiffness! (friction.jl:147-169): W, sum w x, sum w x x' with x = r - cop
+                        const V3 x = r - cop;
+                        const double wx = p_dA * x.x, wy = p_dA * x.y, wz = p_dA * x.z;
+                        tW += p_dA;
+                        tm[0] += wx; tm[1] += wy; tm[2] += wz;
+                        tq[0] = __builtin_fma(wx, x.x, tq[0]); tq[1] = __builtin_fma(wx, x.y, tq[1]);
+                        tq[2] = __builtin_fma(wx, x.z, tq[2]); tq[3] = __builtin_fma(wy, x.y, tq[3]);
+                        tq[4] = __builtin_fma(wy, x.z, tq[4]); tq[5] = __builtin_fma(wz, x.z, tq[5]);
+                    } else {
+                        // calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48), as in k_fric
+                        const V3 x = r - cop;
+                        V3 Ts = ts_c0 + cross_fma(ts_e, r);
+                        Ts = axpy_fma(-dot_fma(Ts, nh), nh, Ts);      // vec_sub_vec_proj
+                        const double m2 = dot_fma(Ts, Ts);
+                        V3 T;
+                        if (m2 < mu_s * mu_s) {
+                            T = Ts;
+                        } else {
+                            double ri = __builtin_amdgcn_rsq(m2);
+                            const double hm = 0.5 * m2;
+                            ri = ri * __builtin_fma(-hm * ri, ri, 1.5);
+                            ri = ri * __builtin_fma(-hm * ri, ri, 1.5);
+                            const double mg = m2 * ri;
+                            const double mu_slope = (mu_d - mu_s) / (3 * mu_s - 2 * mu_s);
+                            const double y = mu_s + (mg - 2 * mu_s) * mu_slope;
+                            const double mu = (y > mu_s) ? mu_s : ((y < mu_d) ? mu_d : y);
+                            T = Ts * (mu * ri);
+                        }
+                        const V3 Tc = T * p_dA;
+                        const V3 ta = cross_fma(x, Tc);
+                        acc[0] += ta.x; acc[1] += ta.y; acc[2] += ta.z;
+                        acc[3] += Tc.x; acc[4] += Tc.y; acc[5] += Tc.z;
+                    }
+                }
+                if (pass == 0 && !reg) {
+                    const V3 Sr = mk3(tm[0] + tW * cen.x, tm[1] + tW * cen.y, tm[2] + tW * cen.z);   // sum w r
+                    const V3 ta = cross(Sr, nh);
+                    acc[0] += ta.x; acc[1] += ta.y; acc[2] += ta.z;
+                    acc[3] += nh.x * tW; acc[4] += nh.y * tW; acc[5] += nh.z * tW;
+                    acc[6] += tW; acc[7] += Sr.x; acc[8] += Sr.y; acc[9] += Sr.z;
+                } else if (pass == 1) {
+                    // n̂ is constant over the polygon: sum w n n' = W n n', sum w (x x n) n' = (m1 x n) n',
+                    // sum w (x x n)(x x n)' = [n]x Q [n]x'   (acc: Snn 6, San 9, Saa 6, Srr 6 -- the kAccSnn.. layout)
+                    acc[0] += tW * nh.x * nh.x; acc[1] += tW * nh.x * nh.y; acc[2] += tW * nh.x * nh.z;
+                    acc[3] += tW * nh.y * nh.y; acc[4] += tW * nh.y * nh.z; acc[5] += tW * nh.z * nh.z;
+                    const V3 an = cross(mk3(tm[0], tm[1], tm[2]), nh);
+                    acc[6] += an.x * nh.x; acc[7] += an.y * nh.x; acc[8] += an.z * nh.x;
+                    acc[9] += an.x * nh.y; acc[10] += an.y * nh.y; acc[11] += an.z * nh.y;
+                    acc[12] += an.x * nh.z; acc[13] += an.y * nh.z; acc[14] += an.z * nh.z;
+                    const V3 c0 = mk3(tq[0], tq[1], tq[2]), c1 = mk3(tq[1], tq[3], tq[4]), c2 = mk3(tq[2], tq[4], tq[5]);
+                    const V3 m0 = cross(nh, c0), m1c = cross(nh, c1), m2c = cross(nh, c2);       // M = [n]x Q
+                    const V3 r0 = cross(nh, mk3(m0.x, m1c.x, m2c.x)), r1 = cross(nh, mk3(m0.y, m1c.y, m2c.y));
+                    const V3 r2 = cross(nh, mk3(m0.z, m1c.z, m2c.z));
+                    acc[15] += r0.x; acc[16] += r0.y; acc[17] += r0.z; acc[18] += r1.y; acc[19] += r1.z; acc[20] += r2.z;
+#pragma unroll
+                    for (int kk = 0; kk < 6; ++kk) acc[21 + kk] += tq[kk];
+                }
+            }
+        }
+        // ---- block reductions and the per-pass epilogue --------------------------------------------------------------
+        if (pass == 0) {
+            block_totals<10>(acc, tot10, red, tid);
+            // counts: non-empty polygons and traction points
+            const int ne_w = wave_total_i(my_ne, lane), nt_w = wave_total_i(my_nt, lane);
+            __syncthreads();
+            if (lane == 0) { s_cnt[wave][0] = ne_w; s_cnt[wave][1] = nt_w; }
+            __syncthreads();
+            n_nonempty = ((s_cnt[0][0] + s_cnt[1][0]) + s_cnt[2][0]) + s_cnt[3][0];
+            n_trac = ((s_cnt[0][1] + s_cnt[1][1]) + s_cnt[2][1]) + s_cnt[3][1];
+            contact = n_trac > 0;
+            if (!reg && contact) {
+                const double iS = tot10[6];
+                cop = mk3(tot10[7] / iS, tot10[8] / iS, tot10[9] / iS);      // normal.jl:33
+            }
+        } else if (pass == 1) {
+            block_partials<27>(acc, red, tid);
+            // the item's accumulator block in the kAcc* layout (read by eig_item); a register array indexed by the thread
+            // id would live in scratch, so the 27 totals are formed from the wave partials by the thread that stores them
+            if (tid < 27) s_acc[kAccSnn + tid] = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
+            if (tid == 32) {
+                s_acc[kAccIp] = tot10[6];
+                s_acc[kAccIpc] = tot10[7]; s_acc[kAccIpc + 1] = tot10[8]; s_acc[kAccIpc + 2] = tot10[9];
+            }
+            __syncthreads();
+            if (wave == 0) eig_item(s_acc, I.ins.k_bar, I.ins.magic, I.s, s_res, E, lane);
+            __syncthreads();
+            // per-item constants of the friction pass (k_fric): T̄s = c0 + e x r
+            const V3 copr = ld3(s_res + kResCop), Da = ld3(s_res + kResDelta), Dl = ld3(s_res + kResDelta + 3);
+            cop = copr;
+            ts_c0 = ((Dl - cross(Da, copr)) + vl * I.ins.tau) * (-I.ins.k_bar);
+            ts_e = (Da + w * I.ins.tau) * (-I.ins.k_bar);
+        } else {
+            block_partials<6>(acc, red, tid);
+            if (tid < 6) s_acc[kAccFric + tid] = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
+            __syncthreads();
+        }
+    }
+
+    // ==== 5. yes_contact! / no_contact! epilogue (friction.jl:76-81,119-143; non_friction.jl:77-83) ====================
+    // status: every thread may have set bits
+    {
+        const unsigned long long any_nf = __ballot((status & kStNonFinite) != 0);
+        if (any_nf) status |= kStNonFinite;
+        __syncthreads();
+        if (lane == 0) s_cnt[wave][0] = (int)status;
+        __syncthreads();
+        status = (unsigned)(((s_cnt[0][0] | s_cnt[1][0]) | s_cnt[2][0]) | s_cnt[3][0]);
+    }
+    if (tid == 0) {     // one lane, static indices only (a register array indexed by the thread id would live in scratch)
+        double wv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sd[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (reg) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wv[k] = contact ? tot10[k] : 0.0;
+        } else {
+            const double tau_inv = 1.0 / I.ins.tau;
+            if (!contact) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sd[k] = -tau_inv * I.s[k];
+            } else {
+                const V3 fang = ld3(s_acc + kAccFric), flin = ld3(s_acc + kAccFric + 3);
+                const V3 fang2 = fang + cross(cop, flin);
+                wv[0] = tot10[0] + fang2.x; wv[1] = tot10[1] + fang2.y; wv[2] = tot10[2] + fang2.z;
+                wv[3] = tot10[3] + flin.x; wv[4] = tot10[4] + flin.y; wv[5] = tot10[5] + flin.z;
+                double sw[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sw[k] = s_res[kResSinv + k] * s_acc[kAccFric + k];
+#pragma unroll
+                for (int ii = 0; ii < 6; ++ii) {
+                    double a6 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) a6 += s_res[kResKis + ii + 6 * k] * sw[k];
+                    sd[ii] = -tau_inv * (a6 + I.s[ii]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { g.wrench[6 * (size_t)item + k] = wv[k]; g.sdot[6 * (size_t)item + k] = sd[k]; }
+    }
+    if (tid == 0) {
+        int *fo = g.fout + 8 * (size_t)item;
+        fo[0] = (int)status; fo[1] = n_test; fo[2] = n_cand; fo[3] = n_nonempty; fo[4] = n_trac;
+        fo[5] = fo[6] = fo[7] = 0;
+        if (g.counts) {
+            int *co = g.counts + 4 * (size_t)item;
+            co[0] = n_test; co[1] = n_cand; co[2] = n_nonempty; co[3] = n_trac;
+        }
+    }
+}
+#undef FR
+#undef FX

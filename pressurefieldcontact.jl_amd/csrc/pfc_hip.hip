@@ -127,6 +127,7 @@ __global__ void k_setup_items(EvalArgs g) {
 #include "pfc_np.h"
 #include "pfc_dual.h"
 #include "pfc_br.h"
+#include "pfc_fused.h"
 
 }  // namespace pfc
 
@@ -246,6 +247,16 @@ struct pfc_context {
     // s_waitcnt half of the time).  Measured on the C3 batch: 2.39 -> 2.04 ms per 2 048 poses; four parts are slower.
     pfc_context *twin = nullptr;
     bool is_twin = false;
+    // small scenes: one fused kernel, one workgroup per item (pfc_fused.h)
+    InsFull *d_insfull = nullptr;
+    DevBuf<int> fout;                  // per item 8 ints (status, counts) of the fused kernel (device-buffer entry point)
+    int *h_fout = nullptr;             // pinned host mirror
+    size_t h_fout_cap = 0;
+    int *fout_dev = nullptr;           // set by pfc_eval: the kernel writes its per-item block straight into pinned host memory
+    const int *fout_host = nullptr;    //   ... and this is where the host reads it
+    int opt_fused = 1;                 // option "fused"
+    int fused_skip = 0;                // evaluations left for which the fused kernel stays off after an item did not fit
+    bool pending_fused = false, last_fused = false;
     int opt_split_min = 1024;          // 0: never split
     int opt_poison = 0;                // diagnostic: fill (re)allocated work lists with 0xFF bytes (item index -1)
     int split_n0 = 0;                  // items in the first half of the pending evaluation (0: not split)
@@ -595,7 +606,10 @@ int check_one(pfc_context *h) {
 }
 
 // Synchronise the pending evaluation (both halves of a split one) and merge the counters.
+int check_fused(pfc_context *h);
 int check_eval(pfc_context *h) {
+    if (h->pending_fused) return check_fused(h);
+    h->last_fused = false;
     if (!h->split_n0) { h->last_parts = 1; return check_one(h); }
     h->last_parts = 2;
     pfc_context *t = h->twin;
@@ -609,6 +623,65 @@ int check_eval(pfc_context *h) {
     h->stats[6] |= t->stats[6];
     h->stats[7] += t->stats[7];
     h->last_undecided += t->last_undecided;
+    return PFC_OK;
+}
+
+// ---- fused small-scene path (pfc_fused.h) -------------------------------------------------------------------------
+constexpr int kFusedMaxItems = 256;      // one workgroup (one CU) per item
+constexpr int kFusedMaxLeaves = 6144;    // n_leaf(mesh_1) + n_leaf(mesh_2): above this one workgroup's descent is the slower one
+
+bool fused_ok(const pfc_context *h, int n_items) {
+    return h->opt_fused && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv && !h->any_tet_tet &&
+           !h->is_twin && h->d_insfull && n_items <= kFusedMaxItems && h->max_leaves <= kFusedMaxLeaves;
+}
+
+int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
+                  const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st) {
+    FuArgs a;
+    a.n_items = n_items; a.n_ins = (int)h->ins.size(); a.ins_ids = d_ins_ids; a.pose = d_pose; a.twist = d_twist; a.s = d_s;
+    a.ins = h->d_insfull; a.wrench = d_wrench; a.sdot = d_sdot; a.counts = d_counts;
+    if (h->fout_dev) {
+        a.fout = h->fout_dev;
+    } else {
+        HIP_TRY(h, h->fout.ensure((size_t)kFusedMaxItems * 8));
+        if (!h->h_fout) {
+            HIP_TRY(h, hipHostMalloc((void **)&h->h_fout, sizeof(int) * kFusedMaxItems * 8));
+            h->h_fout_cap = (size_t)kFusedMaxItems * 8;
+        }
+        a.fout = h->fout.p;
+    }
+    hipLaunchKernelGGL(k_fused, dim3(n_items), dim3(kFuBlock), 0, st, a);   // a direct launch: cheaper than a graph replay
+    HIP_TRY(h, hipGetLastError());
+    h->last_n_items = n_items; h->pending = true; h->pending_fused = true; h->last_stream = st; h->ev_valid = false;
+    h->last_bfs_levels = 0; h->split_n0 = 0;
+    return PFC_OK;
+}
+
+int check_fused(pfc_context *h) {
+    const int n = h->last_n_items;
+    const int *fo = h->fout_host;
+    if (!fo) {
+        HIP_TRY(h, hipMemcpyAsync(h->h_fout, h->fout.p, sizeof(int) * 8 * (size_t)n, hipMemcpyDeviceToHost, h->last_stream));
+        fo = h->h_fout;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    h->pending = false; h->pending_fused = false; h->last_parts = 1; h->last_fused = true;
+    unsigned status = 0;
+    long long tot[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        status |= (unsigned)fo[8 * i];
+        for (int k = 0; k < 4; ++k) tot[k] += fo[8 * i + 1 + k];
+    }
+    for (int k = 0; k < 4; ++k) h->stats[k] = tot[k];
+    h->stats[4] = 0; h->stats[5] = 0; h->stats[6] = status; h->stats[7] = n;
+    h->last_undecided = 0; h->last_tslots = 0;
+    if (status & kStBadIns) return fail(h, PFC_ERR_BAD_ARG, "instruction id out of range in ins_ids");
+    if (status & kStNonFinite) return fail(h, PFC_ERR_NONFINITE, "Non-finite vertex likely");
+    if (status & kStAbort) return fail(h, PFC_ERR_STATE, "broadphase aborted: iteration guard hit (corrupt tree?)");
+    if (status & kStFusedOvf) {
+        h->fused_skip = 64;     // the batched path takes over (and the re-issue), the fused kernel is tried again later
+        return fail(h, PFC_ERR_OVERFLOW, "an item has more candidate pairs than the small-scene kernel holds: re-issue (batched path)");
+    }
     return PFC_OK;
 }
 
@@ -682,7 +755,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->twin) { pfc_destroy(h->twin); h->twin = nullptr; }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->is_twin) { h->d_meshes = nullptr; h->d_ins = nullptr; }   // owned by the parent
+    if (h->is_twin) { h->d_meshes = nullptr; h->d_ins = nullptr; h->d_insfull = nullptr; }   // owned by the parent
     for (auto &m : h->meshes) {
         if (m.d_nodes) (void)hipFree(m.d_nodes);
         if (m.d_nodesf) (void)hipFree(m.d_nodesf);
@@ -692,6 +765,9 @@ void pfc_destroy(pfc_handle h) {
     }
     if (h->d_meshes) (void)hipFree(h->d_meshes);
     if (h->d_ins) (void)hipFree(h->d_ins);
+    if (h->d_insfull) (void)hipFree(h->d_insfull);
+    if (h->h_fout) (void)hipHostFree(h->h_fout);
+    h->fout.release();
     h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
     h->clip_n.release(); h->icnt.release(); h->trac_item.release(); h->acc.release(); h->res.release();
     h->trac_d.release(); h->rec.release(); h->ctr.release(); h->status.release(); h->stamps.release();
@@ -776,6 +852,27 @@ int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int
     m.n_leaf = n_leaf;
     m.depth = tree_depth(m.nodes);
     if (m.depth < 0) return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: the node array is not a tree");
+    // Device node order: breadth-first (the host passes any order with node 0 = root; node indices never leave the
+    // library, leaf ids are element indices).  The two children of a node become neighbours (one 128-byte line of
+    // NodeF), and the first N nodes are the top levels of the tree, which the small-scene kernel keeps in LDS.
+    {
+        std::vector<int> order;          // order[new] = old
+        order.reserve(n_node);
+        order.push_back(0);
+        for (size_t q = 0; q < order.size(); ++q) {
+            const NodeRec &r = m.nodes[order[q]];
+            if (r.leaf == kInternal) { order.push_back(r.child0); order.push_back(r.child1); }
+        }
+        if ((int)order.size() != n_node) return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: the node array is not a tree");
+        std::vector<int> inv(n_node);
+        for (int k = 0; k < n_node; ++k) inv[order[k]] = k;
+        std::vector<NodeRec> bfs(n_node);
+        for (int k = 0; k < n_node; ++k) {
+            bfs[k] = m.nodes[order[k]];
+            if (bfs[k].leaf == kInternal) { bfs[k].child0 = inv[bfs[k].child0]; bfs[k].child1 = inv[bfs[k].child1]; }
+        }
+        m.nodes.swap(bfs);
+    }
     // Device encoding: a child link to a LEAF is stored as ~index (negative), so the broadphase knows from the link
     // alone whether the child needs its rotation R (tight-fitted leaf) and can issue every load of an iteration at once.
     for (NodeRec &r : m.nodes)
@@ -917,6 +1014,23 @@ int pfc_finalize(pfc_handle h) {
     if (!h->ins.empty()) {
         HIP_TRY(h, hipMalloc((void **)&h->d_ins, sizeof(InsDev) * h->ins.size()));
         HIP_TRY(h, hipMemcpy(h->d_ins, h->ins.data(), sizeof(InsDev) * h->ins.size(), hipMemcpyHostToDevice));
+        // one self-contained record per instruction for the fused small-scene kernel
+        std::vector<InsFull> full(h->ins.size());
+        for (size_t k = 0; k < h->ins.size(); ++k) {
+            const InsDev &in = h->ins[k];
+            const HostMesh &m1 = h->meshes[in.m1], &m2 = h->meshes[in.m2];
+            InsFull f;
+            std::memset(&f, 0, sizeof f);
+            f.nodes1 = m1.d_nodes; f.nodes2 = m2.d_nodes; f.nf1 = m1.d_nodesf; f.nf2 = m2.d_nodesf;
+            f.tri = m1.d_tri; f.tet = m2.d_tet; f.tet1 = m1.d_tri ? nullptr : m1.d_tet; f.eps1 = m1.d_tet_eps; f.eps2 = m2.d_tet_eps;
+            f.chi = in.chi; f.Ebar = m2.Ebar; f.Ebar1 = m1.Ebar; f.mu_s = in.mu_s; f.mu_d = in.mu_d; f.v_c = in.v_c;
+            f.tau = in.tau; f.k_bar = in.k_bar; f.magic = in.magic;
+            f.model = in.model; f.nq = in.nq; f.n_node1 = m1.n_node; f.n_node2 = m2.n_node;
+            f.reserve = 3 * (m1.depth + m2.depth + 1) + 3;
+            full[k] = f;
+        }
+        HIP_TRY(h, hipMalloc((void **)&h->d_insfull, sizeof(InsFull) * full.size()));
+        HIP_TRY(h, hipMemcpy(h->d_insfull, full.data(), sizeof(InsFull) * full.size(), hipMemcpyHostToDevice));
     }
     h->finalized = true;
     return PFC_OK;
@@ -945,6 +1059,10 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     h->split_n0 = 0;
+    h->pending_fused = false;
+    if (fused_ok(h, n_items))
+        return enqueue_fused(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
+    if (h->fused_skip > 0 && n_items <= kFusedMaxItems) --h->fused_skip;
     const bool split = h->opt_split_min > 0 && n_items >= h->opt_split_min && d_ins_ids && !h->opt_debug &&
                        !h->want_surv && !h->is_twin;
     if (!split) return enqueue_eval(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
@@ -1005,7 +1123,8 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     const size_t t0 = (((size_t)h->max_levels + 40) + 3) & ~(size_t)3;      // ints in front of the outputs (16-byte multiple)
     const size_t back_bytes = t0 * sizeof(int) + out_bytes;
     HIP_TRY(h, ensure_pinned(&h->pin_in, &h->pin_in_cap, in_bytes));
-    HIP_TRY(h, ensure_pinned(&h->pin_out, &h->pin_out_cap, back_bytes));
+    // behind the outputs: the per-item words of the fused small-scene kernel (status, counts: 8 ints per item)
+    HIP_TRY(h, ensure_pinned(&h->pin_out, &h->pin_out_cap, back_bytes + (n <= (size_t)kFusedMaxItems ? n * 8 * sizeof(int) : 0)));
     HIP_TRY(h, h->h_pose.ensure(in_d + (n + 1) / 2 + 1));      // device mirror of the input block (doubles)
     {
         const size_t cap0 = h->tail.cap;
@@ -1034,14 +1153,18 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     int rc = PFC_OK;
     for (int attempt = 0; attempt < 40; ++attempt) {
         h->tail_dev = zero_copy ? reinterpret_cast<int *>(dout) - t0 : nullptr;
+        if (zero_copy && n <= (size_t)kFusedMaxItems) {
+            h->fout_dev = reinterpret_cast<int *>(reinterpret_cast<char *>(dout) + out_bytes);
+            h->fout_host = reinterpret_cast<const int *>(reinterpret_cast<const char *>(h->pin_out) + back_bytes);
+        }
         rc = pfc_eval_device(h, n_items, ins_ids ? (const int *)(di + in_d) : nullptr, di, di + n * 24,
                              s ? di + n * 30 : nullptr, dout, dout + n * 6, (int *)(dout + out_d), st);
-        h->tail_dev = nullptr;
-        if (rc != PFC_OK) return rc;
-        if (!zero_copy) HIP_TRY(h, hipMemcpyAsync(h->pin_out, h->tail.p, back_bytes, hipMemcpyDeviceToHost, st));
+        h->tail_dev = nullptr; h->fout_dev = nullptr;
+        if (rc != PFC_OK) { h->fout_host = nullptr; return rc; }
+        if (!zero_copy && !h->pending_fused) HIP_TRY(h, hipMemcpyAsync(h->pin_out, h->tail.p, back_bytes, hipMemcpyDeviceToHost, st));
         h->tail_host = (const int *)h->pin_out;
         rc = check_eval(h);
-        h->tail_host = nullptr;
+        h->tail_host = nullptr; h->fout_host = nullptr;
         if (rc != PFC_ERR_OVERFLOW) break;
     }
     if (rc != PFC_OK) return rc;
@@ -1271,6 +1394,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "graph")) h->opt_graph = value != 0;
     else if (!std::strcmp(name, "split_min")) h->opt_split_min = (int)value;
     else if (!std::strcmp(name, "poison")) h->opt_poison = value != 0;
+    else if (!std::strcmp(name, "fused")) { h->opt_fused = value != 0; h->fused_skip = 0; }
     else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;
@@ -1302,7 +1426,7 @@ int pfc_get_stage_ms(pfc_handle h, float *out6) {
     return PFC_OK;
 }
 
-int pfc_last_parts(pfc_handle h) { return h ? h->last_parts : 0; }
+int pfc_last_parts(pfc_handle h) { return h ? (h->last_fused ? 0 : h->last_parts) : 0; }
 
 int pfc_debug_pairs(pfc_handle h, int item, int *pairs, int *clip_n, int cap) {
     if (!h) return -PFC_ERR_BAD_ARG;
@@ -1357,6 +1481,8 @@ int pfc_debug_tractions(pfc_handle h, int item, double *buf, int cap) {
 int pfc_debug_stiffness(pfc_handle h, int item, double *K36, double *Kis36, double *Sinv6, double *cop3) {
     if (!h) return -PFC_ERR_BAD_ARG;
     if (h->pending) { int rc = check_eval(h); if (rc) return -rc; }
+    if (h->last_fused)      // the fused small-scene kernel keeps K in LDS only
+        return -fail(h, PFC_ERR_STATE, "pfc_debug_stiffness: set option debug (or fused = 0) before the evaluation");
     if (item < 0 || item >= h->last_n_items) return -fail(h, PFC_ERR_BAD_ARG, "bad item");
     std::vector<double> r(kResStride);
     int ic[4];

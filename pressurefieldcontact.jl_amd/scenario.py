@@ -363,7 +363,8 @@ class MechanismScenario:
         return dict(zip(k, [int(v) for v in out]))
 
     def last_parts(self) -> int:
-        """1, or 2 if the last checked evaluation ran as two concurrent halves (option split_min)."""
+        """1, or 2 if the last checked evaluation ran as two concurrent halves (option split_min); 0 if it ran as the
+        single fused small-scene kernel (option fused)."""
         return int(_lib.lib().pfc_last_parts(self._h))
 
     def stage_ms(self) -> dict:

@@ -1,0 +1,154 @@
+"""The fused small-scene kernel (csrc/pfc_fused.h: one workgroup per item, one launch per evaluation; what Radau's
+stage evaluations of scenes like test/boxes.jl go through, src/radau/radau_functions.jl:64-70) against the CPU oracle
+and against the batched launch sequence.  Integer outputs bit-exact, wrenches 1e-9, as for the batched path."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _run(pfc, w, fused=1):
+    m = pfc.configs.build_scenario(w)
+    m.set_option("fused", fused)
+    out = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    return m, out
+
+
+def _against_oracle(pfc, w, wrench, sdot, counts, sd_tol=1e-6):
+    ref = H.oracle_run(pfc, w, debug=False)
+    for k, r in enumerate(ref):
+        assert np.array_equal(counts[k], r.counts), (k, counts[k], r.counts)
+        for name, a, b, tol in (("wrench", wrench[k], r.wrench, TOL), ("sdot", sdot[k], r.sdot, sd_tol)):
+            if np.linalg.norm(b) == 0.0:
+                assert np.linalg.norm(a) == 0.0, (name, k, a)
+            else:
+                assert H.rel_err(a, b) < tol, (name, k, a, b)
+    return ref
+
+
+@pytest.mark.parametrize("config", ["c1", "c2", "c4"])
+def test_fused_regularized_configs(pfc, config):
+    w = {"c1": pfc.configs.c1_boxes, "c2": lambda: pfc.configs.c2_box_on_plane(1),
+         "c4": lambda: pfc.configs.c2_box_on_plane(256, montecarlo=True)}[config]()
+    m, (wrench, sdot, counts) = _run(pfc, w)
+    assert m.last_parts() == 0, "the fused kernel did not run"
+    _against_oracle(pfc, w, wrench, sdot, counts)
+    st = m.stats()
+    assert st["candidates"] == int(counts[:, 1].sum()) and st["node_tests"] == int(counts[:, 0].sum())
+    assert st["nonempty"] == int(counts[:, 2].sum()) and st["tractions"] == int(counts[:, 3].sum())
+    m.close()
+
+
+@pytest.mark.parametrize("n_quad", [1, 2])
+def test_fused_bristle(pfc, n_quad):
+    """Bristle items: three passes inside the kernel (cop; patch stiffness about the cop; friction) with the 6x6 eigen
+    on one wave in between."""
+    w = pfc.configs.c3_blob_tool(12, n_div_blob=8, n_div_tool=6)
+    w.instructions[0].n_quad_rule = n_quad
+    m, (wrench, sdot, counts) = _run(pfc, w)
+    assert m.last_parts() == 0
+    _against_oracle(pfc, w, wrench, sdot, counts)
+    assert np.count_nonzero(counts[:, 3]) >= 6
+    m.close()
+    # separated bodies: zero wrench, sdot = -s / tau bit for bit
+    w = pfc.configs.c3_blob_tool(3, n_div_blob=6, n_div_tool=5, distance=0.25)
+    m, (wrench, sdot, counts) = _run(pfc, w)
+    assert m.last_parts() == 0
+    ref = H.oracle_run(pfc, w, debug=False)
+    for k, r in enumerate(ref):
+        assert np.array_equal(counts[k], r.counts) and np.all(wrench[k] == 0.0) and np.array_equal(sdot[k], r.sdot)
+    m.close()
+
+
+@pytest.mark.parametrize("degenerate", [False, True])
+def test_fused_fuzz(pfc, degenerate):
+    """Random and degenerate (axis-aligned, lattice) poses of small meshes, both friction models in one evaluation."""
+    from test_gpu_parity import _fuzz_workload
+    rng = np.random.default_rng(191 + int(degenerate))
+    w = _fuzz_workload(pfc, rng, 256, degenerate, tet_tet=False)
+    m, (wrench, sdot, counts) = _run(pfc, w)
+    assert m.last_parts() == 0
+    ref = H.oracle_run(pfc, w, debug=False)
+    n_contact = 0
+    for k, r in enumerate(ref):
+        assert np.array_equal(counts[k], r.counts), (k, counts[k], r.counts)
+        if np.linalg.norm(r.wrench) > 0:
+            assert H.rel_err(wrench[k], r.wrench) < TOL, (k, wrench[k], r.wrench)
+            n_contact += 1
+        else:
+            assert np.linalg.norm(wrench[k]) == 0.0
+    assert n_contact > 40
+    m.close()
+
+
+def test_fused_equals_batched(pfc):
+    for w in (pfc.configs.c1_boxes(), pfc.configs.c2_box_on_plane(40, montecarlo=True),
+              pfc.configs.c3_blob_tool(5, n_div_blob=7, n_div_tool=5)):
+        m1, (w1, s1, c1) = _run(pfc, w, fused=1)
+        m0, (w0, s0, c0) = _run(pfc, w, fused=0)
+        assert m1.last_parts() == 0 and m0.last_parts() == 1
+        assert np.array_equal(c1, c0)
+        np.testing.assert_allclose(w1, w0, rtol=1e-11, atol=1e-11 * max(np.abs(w0).max(), 1e-300))
+        np.testing.assert_allclose(s1, s0, rtol=1e-6, atol=1e-6 * max(np.abs(s0).max(), 1e-300))
+        m1.close(); m0.close()
+
+
+def test_fused_item_that_does_not_fit_falls_back(pfc):
+    """More candidate pairs than the kernel's LDS list holds: the evaluation is transparently re-issued on the batched
+    path (pfc_eval), the fused kernel stays off for a while and comes back."""
+    w = pfc.configs.c3_blob_tool(3, n_div_blob=8, n_div_tool=6, distance=0.04)
+    m, (wrench, sdot, counts) = _run(pfc, w)
+    assert counts[:, 1].max() > 4096, counts[:, 1]
+    assert m.last_parts() == 1           # ended on the batched path
+    ref = H.oracle_run(pfc, w, debug=False)
+    for k, r in enumerate(ref):
+        assert np.array_equal(counts[k], r.counts)
+        assert H.rel_err(wrench[k], r.wrench) < TOL
+    # a scene that fits, same handle: batched while the back-off lasts, fused again afterwards
+    w2 = pfc.configs.c3_blob_tool(3, n_div_blob=8, n_div_tool=6)
+    paths = []
+    for _ in range(70):
+        wr2, sd2, ct2 = m.force_all_elastic_intersections(w2.pose, w2.twist, w2.s, w2.ins_ids)
+        paths.append(m.last_parts())
+    assert paths[0] == 1 and paths[-1] == 0
+    ref2 = H.oracle_run(pfc, w2, debug=False)
+    for k, r in enumerate(ref2):
+        assert np.array_equal(ct2[k], r.counts) and H.rel_err(wr2[k], r.wrench) < TOL
+    m.close()
+
+
+def test_fused_errors_and_device_buffers(pfc):
+    import torch
+    L = pfc._lib
+    w = pfc.configs.c2_box_on_plane(8, montecarlo=True)
+    m = pfc.configs.build_scenario(w)
+    bad = w.pose.copy(); bad[3, 5] = np.inf
+    with pytest.raises(L.PFCError) as ei:
+        m.force_all_elastic_intersections(bad, w.twist, w.s, w.ins_ids)
+    assert ei.value.status == L.ERR_NONFINITE
+    with pytest.raises(L.PFCError) as ei:
+        m.force_all_elastic_intersections(w.pose, w.twist, w.s, np.full(8, 3, dtype=np.int32))
+    assert ei.value.status == L.ERR_BAD_ARG
+    wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert m.last_parts() == 0
+    # pfc_eval_device + pfc_check: buffers resident in HBM, caller's stream
+    dev = torch.device("cuda", 0)
+    n = w.n_items
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    d_ins, d_pose, d_tw, d_s = d(w.ins_ids, torch.int32), d(w.pose, torch.float64), d(w.twist, torch.float64), d(w.s, torch.float64)
+    d_w = torch.zeros((n, 6), dtype=torch.float64, device=dev); d_sd = torch.zeros_like(d_w)
+    d_ct = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    for counts_ptr in (d_ct.data_ptr(), 0):
+        m.eval_device(n, d_ins.data_ptr(), d_pose.data_ptr(), d_tw.data_ptr(), d_s.data_ptr(), d_w.data_ptr(), d_sd.data_ptr(),
+                      counts_ptr, torch.cuda.current_stream().cuda_stream)
+        assert m.check() == 0 and m.last_parts() == 0
+        np.testing.assert_allclose(d_w.cpu().numpy(), wr, rtol=1e-12, atol=1e-12 * np.abs(wr).max())
+        assert np.array_equal(d_ct.cpu().numpy(), ct)
+        assert m.stats()["candidates"] == int(ct[:, 1].sum())
+    # debug views belong to the batched path
+    with pytest.raises(L.PFCError):
+        m.debug_stiffness(0)
+    m.close()
