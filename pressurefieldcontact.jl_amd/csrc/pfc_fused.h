@@ -7,9 +7,10 @@
 // Here one 256-thread workgroup per (instruction, pose) item does everything force_single_elastic_intersection!
 // (src/contact_algorithms_non_friction.jl:70-84) does, without leaving the CU:
 //   0. item record (instruction parameters, mesh pointers, pose, twist, s) -> LDS: two dependent loads
-//   1. broadphase: the first kFuNodes nodes of both trees (the device node order is breadth-first, so these are the top
-//      levels) are copied to LDS once; the depth-first descent of k_bp_dfs32 (same Float32 filter, same cooperative
-//      exact Float64 settle, same node tests) then runs from LDS; candidates stay in an LDS list
+//   1. broadphase: small trees whole, large ones by the heads of their first kFuNodes nodes (the device node order is
+//      breadth-first, so these are the top levels), are copied to LDS once; the workgroup depth-first descent of
+//      k_bp_dfs32 (same node tests, 256 per iteration) then runs from LDS with the exact Float64 test per pair;
+//      candidates stay in an LDS list
 //   2. clip: one thread per candidate (rounds of 256): gather, tet coordinates, trivial reject, Sutherland-Hodgman in
 //      the LDS polygon ring, Cartesian polygon + centroid -- the expressions of k_narrow, bit for bit
 //   3. integrate: the fan triangles of all polygons of the round are dealt out one per thread (the batched kernel walks
@@ -24,7 +25,8 @@
 constexpr int kFuBlock = 256;
 constexpr int kFuWaves = kFuBlock / 64;
 constexpr int kFuCand = 4096;      // candidate pairs per item held in LDS (32 KiB)
-constexpr int kFuNodes = 256;      // nodes per tree cached in LDS (2 x 16 KiB)
+constexpr int kFuNodes = 256;      // node heads per tree cached in LDS (2 x 16 KiB) ...
+constexpr int kFuFull = (kFuNodes * 4) / 9;   // ... or the whole tree (144-byte NodeRec) if it has at most this many nodes
 constexpr int kFuStack = 2560;     // node pairs (20 KiB), as k_bp_dfs32
 constexpr unsigned kStFusedOvf = 512u;   // item does not fit the fused kernel's LDS lists: use the batched path
 
@@ -50,7 +52,17 @@ struct FuArgs {
     double *wrench, *sdot;
     int *counts;             // may be null
     int *fout;               // per item 8 ints: status, counts[4], 0, 0, 0
+    unsigned long long *stamps;   // diagnostic builds (-DPFC_STAMPS): block 0 leaves wall-clock stamps (10 ns ticks) of its phases
 };
+
+#ifdef PFC_STAMPS
+#define FSTAMP(k)                                                                                   \
+    do {                                                                                            \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && g.stamps) g.stamps[k] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define FSTAMP(k) do { } while (0)
+#endif
 
 struct FuItem {
     InsFull ins;
@@ -97,10 +109,7 @@ __device__ __forceinline__ void block_totals(const double *v, double *out, doubl
 
 struct FuBp {                 // broadphase view of the scratch region (aliases the polygon ring)
     int2 stk[kFuStack];
-    NodeF n1[kFuNodes], n2[kFuNodes];
-    int2 und_l[kFuBlock];
-    int und_v[kFuBlock];
-    double xs[(kFuBlock / 16) * 33];
+    vec4i na[kFuNodes * 4], nb[kFuNodes * 4];   // per tree 16 KiB: kFuNodes heads (4 x 16 B) or <= kFuFull whole NodeRec (9 x 16 B)
 };
 union FuScratch {
     FuBp bp;
@@ -120,16 +129,20 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     __shared__ double s_epsr[4][kFuBlock];      // ϵ_r² of the lane's tet
     __shared__ int s_np[kFuBlock], s_rb[kFuBlock];
     __shared__ double red[kFuWaves * 32];
-    __shared__ int s_cnt[kFuWaves][2], s_def[2], s_scan[kFuWaves];
+    __shared__ int s_cnt[kFuWaves][4], s_scan[kFuWaves];
     __shared__ FuItem I;
     __shared__ double s_acc[kAccStride], s_res[kResStride];
     __shared__ EigScratch E;
-    __shared__ float s_posef[12];
+    __shared__ double s_aR12[9];
     double *ring = S.ring;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int item = blockIdx.x;
     unsigned status = 0;
 
+    FSTAMP(0);
+#ifdef PFC_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.stamps) g.stamps[10] = __builtin_amdgcn_s_memtime();
+#endif
     // ==== 0. the item ==============================================================================================
     int id = g.ins_ids ? g.ins_ids[item] : item;
     if (id < 0 || id >= g.n_ins) { status |= kStBadIns; id = 0; }
@@ -148,87 +161,177 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     __syncthreads();
     const bool reg = I.ins.model == PFC_REGULARIZED;
     const int nq = (I.ins.nq == 1) ? 1 : 3;
-    if (tid < 9) s_posef[tid] = (float)I.pose[12 + tid];
     // a non-finite pose is reported ("Non-finite vertex likely", static_clip.jl:52), not traversed (uniform)
     bool pose_ok = true;
 #pragma unroll
     for (int k = 0; k < 24; ++k) pose_ok &= (__builtin_fabs(I.pose[k]) <= 1.79769313486231570815e308);
 
+    FSTAMP(1);
     // ==== 1. broadphase (tree_tree_intersect, src/obb/tree_types.jl:88-111) ===========================================
+    // Every node pair is decided by the reference's own Float64 BB_BB_intersect (src/obb/bb_intersection.jl:2-74) in the
+    // iteration that pops it: axis-aligned shortcut for two merged boxes, general composition when a tight-fitted leaf
+    // is involved.  (The batched kernel's Float32 filter + parked exact settle buys occupancy, which one workgroup per
+    // CU does not need, and costs an extra iteration whenever pairs come back undecided -- every pair of an axis-aligned
+    // scene like a box resting on a plane, whose parallel-edge cross axes are exactly degenerate.)
     int n_cand = 0, n_test = 0;
     if (pose_ok) {
         FuBp &B = S.bp;
-        const int nc1 = I.ins.n_node1 < kFuNodes ? I.ins.n_node1 : kFuNodes;
-        const int nc2 = I.ins.n_node2 < kFuNodes ? I.ins.n_node2 : kFuNodes;
-        for (int k = tid; k < nc1 * 4; k += kFuBlock) reinterpret_cast<vec4i *>(B.n1)[k] = ((const gvec4i *)I.ins.nf1)[k];
-        for (int k = tid; k < nc2 * 4; k += kFuBlock) reinterpret_cast<vec4i *>(B.n2)[k] = ((const gvec4i *)I.ins.nf2)[k];
+        // node cache: the whole tree as NodeRec if it fits its 16 KiB area, else the 64-byte heads (c, e, links, flags)
+        // of the first kFuNodes nodes (breadth-first order: the top levels)
+        const int nn1 = I.ins.n_node1, nn2 = I.ins.n_node2;
+        const bool full1 = nn1 <= kFuFull, full2 = nn2 <= kFuFull;
+        const int nc1 = nn1 < kFuNodes ? nn1 : kFuNodes, nc2 = nn2 < kFuNodes ? nn2 : kFuNodes;   // nodes held in LDS
+        if (full1) { for (int k = tid; k < nn1 * 9; k += kFuBlock) B.na[k] = ((const gvec4i *)I.ins.nodes1)[k]; }
+        else { for (int k = tid; k < nc1 * 4; k += kFuBlock) B.na[k] = ((const gvec4i *)I.ins.nodes1)[(k >> 2) * 9 + (k & 3)]; }
+        if (full2) { for (int k = tid; k < nn2 * 9; k += kFuBlock) B.nb[k] = ((const gvec4i *)I.ins.nodes2)[k]; }
+        else { for (int k = tid; k < nc2 * 4; k += kFuBlock) B.nb[k] = ((const gvec4i *)I.ins.nodes2)[(k >> 2) * 9 + (k & 3)]; }
         if (tid == 0) {
             // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
-            B.stk[0] = make_int2(I.ins.n_node1 == 1 ? ~0 : 0, I.ins.n_node2 == 1 ? ~0 : 0);
-            s_def[0] = s_def[1] = 0;
+            B.stk[0] = make_int2(nn1 == 1 ? ~0 : 0, nn2 == 1 ? ~0 : 0);
         }
+        if (tid < 9) s_aR12[tid] = __builtin_fabs(I.pose[12 + tid]) + 1.0e-14;    // abs_R of an all-identity pair (:10)
         __syncthreads();
-        const NodeF *n1 = I.ins.nf1, *n2 = I.ins.nf2;
+        FSTAMP(2);
         const double *s_pose = I.pose + 12;          // R_a_b (9, column-major), t_a_b (3): x_r1_r2
         const int reserve = I.ins.reserve;
-        int sp = 1, n_def = 0, par = 0;
+        int sp = 1;
         bool ovf = false;
-        for (int guard = 0; (sp > 0 || n_def > 0) && guard < (1 << 22); ++guard, par ^= 1) {
-            const bool settle = n_def > 0;
-            int pw = (kFuStack - reserve - sp) / 3;
-            int p = sp < kFuBlock ? sp : kFuBlock;
-            if (pw < 1) pw = 1;
-            if (p > pw) p = pw;
-            if (settle) {
-                p = n_def;
-                exact_pairs_coop(I.ins.nodes1, I.ins.nodes2, s_pose, B.und_l, n_def, B.xs, B.und_v, tid);   // ends with a barrier
+        // a node: head from LDS or global; R only where the link says leaf (tight-fitted box) or the head says "not
+        // axis aligned" (a host-supplied tree may hold such internal boxes).  Explicit branches: a select between an LDS
+        // and a global load would issue both.
+#define FU_FETCH(u, LDSARR, FULL, NC, GLOB, IDX, LEAF)                                              \
+    do {                                                                                            \
+        const int idx_ = (IDX);                                                                     \
+        const gvec4i *gp_ = (const gvec4i *)((GLOB) + idx_);                                        \
+        const bool in_lds_ = idx_ < (NC);                                                           \
+        const int base_ = (FULL) ? idx_ * 9 : idx_ * 4;                                             \
+        if (in_lds_) { u.v[0] = LDSARR[base_]; u.v[1] = LDSARR[base_ + 1]; u.v[2] = LDSARR[base_ + 2]; u.v[3] = LDSARR[base_ + 3]; } \
+        else { u.v[0] = gp_[0]; u.v[1] = gp_[1]; u.v[2] = gp_[2]; u.v[3] = gp_[3]; }               \
+        if ((LEAF) || !u.r.aabb) {                                                                  \
+            if (in_lds_ && (FULL)) { u.v[4] = LDSARR[base_ + 4]; u.v[5] = LDSARR[base_ + 5]; u.v[6] = LDSARR[base_ + 6]; u.v[7] = LDSARR[base_ + 7]; u.v[8] = LDSARR[base_ + 8]; } \
+            else { u.v[4] = gp_[4]; u.v[5] = gp_[5]; u.v[6] = gp_[6]; u.v[7] = gp_[7]; u.v[8] = gp_[8]; } \
+        } else {                                                                                    \
+            u.r.R[0] = 1.0; u.r.R[1] = 0.0; u.r.R[2] = 0.0; u.r.R[3] = 0.0; u.r.R[4] = 1.0; u.r.R[5] = 0.0; \
+            u.r.R[6] = 0.0; u.r.R[7] = 0.0; u.r.R[8] = 1.0;                                         \
+        }                                                                                           \
+    } while (0)
+        union NodeU { vec4i v[9]; NodeRec r; __device__ NodeU() {} };
+#ifdef PFC_STAMPS
+        unsigned long long cy[4] = {0, 0, 0, 0}, it_n = 0;
+#endif
+        for (int guard = 0; sp > 0 && guard < (1 << 22); ++guard) {
+            unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0; (void)u0; (void)u1; (void)u2; (void)u3; (void)u4;
+            STAMP(u0);
+            // Lookahead.  An iteration costs ~4 000 cycles whatever the number of busy lanes (one Float64 test per lane, a
+            // single wave per SIMD), and the top of a descent has 1, 2, 4 ... pairs: with few pairs on the stack the
+            // children (and grandchildren) of a popped pair are tested in the SAME iteration by neighbouring lanes -- 8
+            // (32) lanes per popped pair: lane 0 the pair, lanes 1..4 its child pairs, lanes 5..20 theirs.  A lane's
+            // result counts only if every ancestor pair it descends from overlaps (the reference tests a pair iff its
+            // parent pair intersects, tree_types.jl:88-111), so node tests and candidates are the reference's.
+            const int room = kFuStack - reserve - sp;
+            int LA = 1, p;
+            if (sp <= 8 && room >= 64 * sp) { LA = 3; p = sp; }
+            else if (sp <= 32 && room >= 16 * sp) { LA = 2; p = sp; }
+            else {
+                int pw = room / 3;
+                p = sp < kFuBlock ? sp : kFuBlock;
+                if (pw < 1) pw = 1;
+                if (p > pw) p = pw;
             }
-            const bool act = tid < p;
+            const int gl = LA == 3 ? 32 : (LA == 2 ? 8 : 1);       // lanes per popped pair
+            const int grp = tid / gl, r = tid - grp * gl;
+            int lvl = 0, c1 = 0, c2 = 0;
+            bool act = grp < p;
+            if (r >= 1 && r <= 4) { lvl = 1; c1 = r - 1; }
+            else if (LA == 3 && r >= 5 && r <= 20) { lvl = 2; c1 = (r - 5) >> 2; c2 = (r - 5) & 3; }
+            else if (r >= 5) act = false;
             int2 e = make_int2(0, 0);
-            if (act) e = settle ? B.und_l[tid] : B.stk[sp - 1 - tid];
-            if (!settle) { sp -= p; n_test += p; }
-            int verdict = 0, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-            if (settle && act) verdict = B.und_v[tid];
-            const bool la = act && e.x < 0, lb = act && e.y < 0;
-            if (act) {
-                const int ia = node_index(e.x), ib = node_index(e.y);
-                NodeF a, b;
-                if (ia < nc1) a = B.n1[ia]; else a = load_nodef(n1 + ia);
-                if (ib < nc2) b = B.n2[ib]; else b = load_nodef(n2 + ib);
-                a0 = a.link0; a1 = a.link1; b0 = b.link0; b1 = b.link1;
-                if (!settle) {
-                    double R12[9], t12[3];
-                    float R12f[9];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) { R12[k] = s_pose[k]; R12f[k] = s_posef[k]; }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
-                    verdict = test_pair_f32(a, b, la || lb, R12, R12f, t12);
+            if (act) e = B.stk[sp - 1 - grp];
+            // walk down to the lane's own pair: child order (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107), or the two
+            // children of the internal node when the other one is a leaf (:97-103)
+#define FU_LINKS(LDSARR, FULL, NC, GLOB, IDX) ((IDX) < (NC) ? LDSARR[((FULL) ? (IDX) * 9 : (IDX) * 4) + 3] : ((const gvec4i *)((GLOB) + (IDX)))[3])
+            for (int step = 0; step < LA - 1; ++step) {
+                if (act && step < lvl) {
+                    const int c = step == 0 ? c1 : c2;
+                    const bool xa = e.x < 0, xb = e.y < 0;
+                    if ((xa && xb) || ((xa || xb) && c >= 2)) {
+                        act = false;
+                    } else {
+                        if (!xa) {
+                            const int ia = e.x;
+                            vec4i lk;
+                            if (ia < nc1) lk = B.na[(full1 ? ia * 9 : ia * 4) + 3]; else lk = ((const gvec4i *)(I.ins.nodes1 + ia))[3];
+                            const int sel = xb ? c : (c & 1);
+                            e.x = sel ? lk.y : lk.x;
+                        }
+                        if (!xb) {
+                            const int ib = e.y;
+                            vec4i lk;
+                            if (ib < nc2) lk = B.nb[(full2 ? ib * 9 : ib * 4) + 3]; else lk = ((const gvec4i *)(I.ins.nodes2 + ib))[3];
+                            const int sel = xa ? c : (c >> 1);
+                            e.y = sel ? lk.y : lk.x;
+                        }
+                    }
                 }
             }
-            if (verdict == 2) B.und_l[atomicAdd(&s_def[par], 1)] = e;
-            const bool hit = verdict == 1;
-            const bool is_cand = hit && la && lb;
-            const bool two = hit && (la != lb);
-            const bool four = hit && !la && !lb;
-            const unsigned long long mc = __ballot(is_cand), m2 = __ballot(two), m4 = __ballot(four);
+#undef FU_LINKS
+            sp -= p;
+            bool hit = false;
+            int a0 = 0, a1 = 0, b0 = 0, b1 = 0, la_id = 0, lb_id = 0;
+            const bool la = act && e.x < 0, lb = act && e.y < 0;
+            if (act) {
+                NodeU ua, ub;
+                FU_FETCH(ua, B.na, full1, nc1, I.ins.nodes1, node_index(e.x), la);
+                FU_FETCH(ub, B.nb, full2, nc2, I.ins.nodes2, node_index(e.y), lb);
+                const NodeRec &a = ua.r, &b = ub.r;
+                a0 = a.child0; a1 = a.child1; b0 = b.child0; b1 = b.child1; la_id = a.leaf; lb_id = b.leaf;
+#ifdef PFC_STAMPS
+                { double keep = a.c[0] + b.c[0] + a.R[4] + b.R[4]; asm volatile("" ::"v"(keep)); }   // the loads have landed
+                STAMP(u1);
+#endif
+                double R12[9], t12[3];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) R12[k] = s_pose[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
+                if (a.aabb && b.aabb) {
+                    double aR12[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) aR12[k] = s_aR12[k];
+                    hit = bb_bb_intersect_aabb(a.c, a.e, b.c, b.e, R12, aR12, t12);
+                } else {
+                    hit = bb_bb_intersect(a, b, R12, t12);
+                }
+            }
+            STAMP(u2);
+            // live: the pair is one the reference tests (all its ancestors in this iteration overlap); fin: its expansion
+            // is not already covered by lanes of this iteration
+            const unsigned long long hm = __ballot(hit);
+            const int gb = lane & ~(gl - 1);
+            const bool live = act && (lvl == 0 || ((hm >> gb) & 1ull)) && (lvl <= 1 || ((hm >> (gb + 1 + c1)) & 1ull));
+            const bool fin = live && hit && (lvl == LA - 1 || (la && lb));
+            const bool is_cand = fin && la && lb;
+            const bool two = fin && (la != lb);
+            const bool four = fin && !la && !lb;
+            const unsigned long long mc = __ballot(is_cand), m2 = __ballot(two), m4 = __ballot(four), ml = __ballot(live);
             if (lane == 0) {
                 s_cnt[wave][0] = __builtin_popcountll(mc);
                 s_cnt[wave][1] = 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
+                s_cnt[wave][2] = __builtin_popcountll(ml);
             }
             __syncthreads();
-            n_def = s_def[par];
-            if (tid == 0) s_def[par ^ 1] = 0;
+            STAMP(u3);
             int c_off = 0, p_off = 0, c_tot = 0, p_tot = 0;
 #pragma unroll
             for (int w = 0; w < kFuWaves; ++w) {
                 const int c = s_cnt[w][0], q = s_cnt[w][1];
                 if (w < wave) { c_off += c; p_off += q; }
                 c_tot += c; p_tot += q;
+                n_test += s_cnt[w][2];
             }
             if (is_cand) {
                 const int pos = n_cand + c_off + prefix_count(mc);
-                if (pos < kFuCand) cand[pos] = make_int2(a0, b0);     // leaf: link0 = element index
+                if (pos < kFuCand) cand[pos] = make_int2(la_id, lb_id);     // element indices
             }
             if (two | four) {
                 const int pos = sp + p_off + 2 * prefix_count(m2) + 4 * prefix_count(m4);
@@ -245,13 +348,28 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             }
             n_cand += c_tot;
             sp += p_tot;
-            if (n_cand > kFuCand) { ovf = true; sp = 0; n_def = 0; }    // uniform: the item leaves for the batched path
+            if (n_cand > kFuCand) { ovf = true; sp = 0; }    // uniform: the item leaves for the batched path
             __syncthreads();
+#ifdef PFC_STAMPS
+            STAMP(u4);
+            if (u1 == 0) u1 = u0;
+            cy[0] += u1 - u0; cy[1] += u2 - u1; cy[2] += u3 - u2; cy[3] += u4 - u3; ++it_n;
+#endif
         }
+#ifdef PFC_STAMPS
+        if (blockIdx.x == 0 && tid == 0 && g.stamps) {
+            g.stamps[12] = cy[0]; g.stamps[13] = cy[1]; g.stamps[14] = cy[2]; g.stamps[15] = (cy[3] << 16) | it_n;
+        }
+#endif
+#undef FU_FETCH
         if (ovf) status |= kStFusedOvf;
-        else if (sp > 0 || n_def > 0) status |= kStAbort;
+        else if (sp > 0) status |= kStAbort;
     }
     if (status & (kStFusedOvf | kStAbort)) n_cand = 0;   // uniform
+    FSTAMP(3);
+#ifdef PFC_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.stamps) g.stamps[8] = (unsigned long long)n_test;
+#endif
 
     // ==== 2.-4. narrowphase ===========================================================================================
     // pass 0: normal wrench (+ regularized friction fused) + cop sums; bristle: pass 1 patch stiffness about the cop,
@@ -429,6 +547,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                 for (int k = 0; k < np; ++k) fan[off + k] = (unsigned)tid | ((unsigned)k << 16);
                 __syncthreads();
             }
+            if (pass == 0 && rd == 0) FSTAMP(4);
             const int n_fan = ((s_scan[0] + s_scan[1]) + s_scan[2]) + s_scan[3];
             // ---- integrate_over_polygon_patch! (non_friction.jl:217-265): one fan triangle per thread ------------------
             for (int wi = tid; wi < n_fan; wi += kFuBlock) {
@@ -555,6 +674,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             }
         }
         // ---- block reductions and the per-pass epilogue --------------------------------------------------------------
+        if (pass == 0) FSTAMP(5);
         if (pass == 0) {
             block_totals<10>(acc, tot10, red, tid);
             // counts: non-empty polygons and traction points
@@ -593,6 +713,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         }
     }
 
+    FSTAMP(6);
     // ==== 5. yes_contact! / no_contact! epilogue (friction.jl:76-81,119-143; non_friction.jl:77-83) ====================
     // status: every thread may have set bits
     {
@@ -642,6 +763,10 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             co[0] = n_test; co[1] = n_cand; co[2] = n_nonempty; co[3] = n_trac;
         }
     }
+    FSTAMP(9);
+#ifdef PFC_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.stamps) g.stamps[11] = __builtin_amdgcn_s_memtime();
+#endif
 }
 #undef FR
 #undef FX

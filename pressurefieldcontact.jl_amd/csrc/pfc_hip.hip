@@ -650,6 +650,11 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
         }
         a.fout = h->fout.p;
     }
+    a.stamps = nullptr;
+#ifdef PFC_STAMPS
+    HIP_TRY(h, h->stamps.ensure(16));
+    a.stamps = h->stamps.p;
+#endif
     hipLaunchKernelGGL(k_fused, dim3(n_items), dim3(kFuBlock), 0, st, a);   // a direct launch: cheaper than a graph replay
     HIP_TRY(h, hipGetLastError());
     h->last_n_items = n_items; h->pending = true; h->pending_fused = true; h->last_stream = st; h->ev_valid = false;
