@@ -4,24 +4,36 @@
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 the driver launches it under
 ``python -m torch.distributed.run --nproc-per-node N`` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json metric / configs[2], "C3"): a 9 680-tet compliant blob against a 5 120-triangle rigid
-tool, bristle friction, evaluated for a batch of independent Monte-Carlo poses.  One *step* = one pass of the whole
-hot path (OBB-tree broadphase -> tri/tet clip + quadrature -> bristle friction reductions) over the batch, with
-meshes, trees, poses, twists and bristle states already resident in HBM, plus (N > 1) the RCCL all-gather of the
-per-item [wrench, sdot] rows.  Work per GPU is fixed as N grows (weak scaling): rank r evaluates its own
-``--poses`` poses (PRNG streams r*poses ...).
+Workloads (BASELINE.json configs; ``--config``):
+  C3 (default, the configuration the metric is quoted on): a 9 680-tet compliant blob against a 5 120-triangle rigid
+     tool, bristle friction, a batch of independent Monte-Carlo poses per GPU.  Weak scaling: rank r evaluates its own
+     ``--poses`` poses.
+  C4: 256 independent box-on-plane scenes (regularized), sharded across the ranks in contiguous blocks
+     (parallel.shard_block).  Strong scaling: the 256 scenes are the whole job.
+  C5: pile of 64 compliant boxes, all 2 016 body pairs as bristle instructions, sharded by cost (leaf-count product,
+     parallel.shard_by_cost).  Strong scaling.
+One *step* = one pass of the whole hot path (OBB-tree broadphase -> tri/tet clip + quadrature -> friction reductions)
+over the rank's items with meshes, trees, poses, twists and bristle states already resident in HBM, plus (N > 1) the
+RCCL all-gather of the per-item result rows (parallel.all_gather_rows for C4/C5: [wrench | sdot | counts]).
 
 metric  = tet-tri clip+integrate ops/s, one op = one broadphase candidate (triangle, tet) pair pushed through
           the narrowphase; contact-pairs/s (items/s) is reported beside it.
-roofline: HBM-bound (no MFMA: branchy Float64 geometry); ``achieved`` = algorithmic bytes (236 B per op for
-          the narrowphase kernel, 240 B per OBB node test for the broadphase kernel) / kernel time measured with
-          HIP events on the launch stream inside libpfc_hip (pfc_get_stage_ms).
+timing  = ``--reps`` repetitions of the K-step block, each bracketed by barrier + synchronize; ``value`` and
+          ``ms_per_step`` are the MEDIAN repetition (max over ranks per repetition); the spread is reported.
+roofline: the dominant kernel with the SURVEY §8(d) accounting (algorithmic bytes / kernel time vs the 8 TB/s HBM
+          peak; kernel time from HIP events on the launch stream inside libpfc_hip) plus the measured PMC traffic and
+          the vector-issue view (``valu``), which is what actually bounds these kernels.  The other hot kernel is
+          reported under ``roofline_other`` against the bound that applies to it (vector issue), never against HBM with
+          cache-served algorithmic bytes.
+validation: after the timed region ``validated_items`` random items of the batch are re-evaluated by the CPU oracle
+          and compared (counts bit-equal, wrench 1e-9, sdot 1e-6).
 cpu_baseline: the plain-C oracle (a scalar port of the reference algorithm; the Julia reference cannot run here)
-          timed single-threaded on a bounded sample of the same poses, rank 0, N = 1 only.
+          timed single-threaded on a bounded sample of the same items, rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,11 +43,10 @@ sys.path.insert(0, ROOT)
 BYTES_PER_OP = 236          # pair 8 + tri idx 12 + 3 verts 72 + tet idx 16 + 4 verts 96 + 4 eps 32
 BYTES_PER_NODE_TEST = 240   # 2 x (c 24 + e 24 + R 72)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+N_SIMD, CLOCK_HZ = 1024, 2.4e9
 
 
-def cpu_baseline(pfc, w, budget_s: float, n_threads: int = 1):
-    """Oracle ("port") timed on the host cores: items evaluated independently by pfo_eval_batch, serially
-    (n_threads = 1, the reference's own execution model) or spread over OpenMP threads."""
+def oracle_setup(pfc, w):
     from oracle import oracle as O
     O.build()
     om = [O.OracleMesh(ms.mesh, ms.tree, ms.Ebar or 0.0) for ms in w.meshes]
@@ -47,13 +58,21 @@ def cpu_baseline(pfc, w, budget_s: float, n_threads: int = 1):
         else:
             oi.append(O.make_ins(c.chi, c.n_quad_rule, O.BRISTLE, mu_s, mu_d, tau=c.tau, k_bar=c.k_bar, magic=c.magic))
         m1.append(c.id_1); m2.append(c.id_2)
+    return O, om, oi, m1, m2
+
+
+def cpu_baseline(pfc, w, budget_s: float, n_threads: int = 1):
+    """Oracle ("port") timed on the host cores: items evaluated independently by pfo_eval_batch, serially
+    (n_threads = 1, the reference's own execution model) or spread over OpenMP threads."""
+    O, om, oi, m1, m2 = oracle_setup(pfc, w)
     chunk = max(8 * n_threads, 16)
     O.evaluate_batch(om, oi, m1, m2, w.ins_ids[:chunk], w.pose[:chunk], w.twist[:chunk], w.s[:chunk], n_threads)  # warm
     ops = items = 0
     k = 0
     t0 = time.perf_counter()
     while True:
-        sl = slice(k % w.n_items, k % w.n_items + chunk)
+        lo = k % w.n_items
+        sl = slice(lo, min(lo + chunk, w.n_items))
         st, _, _, ct = O.evaluate_batch(om, oi, m1, m2, w.ins_ids[sl], w.pose[sl], w.twist[sl], w.s[sl], n_threads)
         assert st == 0
         ops += int(ct[:, 1].sum()); items += int(ct.shape[0]); k += chunk
@@ -61,9 +80,64 @@ def cpu_baseline(pfc, w, budget_s: float, n_threads: int = 1):
         if dt >= budget_s:
             break
     return {"value": ops / dt, "unit": "ops/s", "cores": n_threads, "kind": "port",
-            "sample": f"{items} poses of the same batch, {ops} ops, {dt:.1f} s, oracle/pfc_oracle.c "
+            "sample": f"{items} items of the same batch, {ops} ops, {dt:.1f} s, oracle/pfc_oracle.c "
                       f"({'single thread' if n_threads == 1 else str(n_threads) + ' OpenMP threads over items'})",
             "contact_pairs_per_s": items / dt}
+
+
+def validate(pfc, w, local_ids, wrench, sdot, counts, k: int, seed: int = 7):
+    """Oracle check of k random items of what was just timed: counts bit-equal, wrench 1e-9, sdot 1e-6 (1e-3 where
+    K̄ has >= 2 near-null eigenvalues: DESIGN.md §5.7)."""
+    import numpy as np
+    O, om, oi, m1, m2 = oracle_setup(pfc, w)
+    rng = np.random.default_rng(seed)
+    pick = rng.choice(len(local_ids), size=min(k, len(local_ids)), replace=False)
+    worst_w = worst_s = 0.0
+    for j in pick:
+        g = int(local_ids[j])
+        ins = int(w.ins_ids[g])
+        r = O.evaluate(om[m1[ins]], om[m2[ins]], oi[ins], w.pose[g], w.twist[g], w.s[g], debug=True)
+        if not np.array_equal(np.asarray(counts[j]), r.counts):
+            raise AssertionError(f"validation: counts of item {g} differ: {counts[j]} vs oracle {r.counts}")
+        for name, a, b, tol in (("wrench", wrench[j], r.wrench, 1e-9), ("sdot", sdot[j], r.sdot, 1e-6)):
+            nb = float(np.linalg.norm(b))
+            if nb == 0.0:
+                if float(np.linalg.norm(a)) != 0.0:
+                    raise AssertionError(f"validation: {name} of item {g} should be zero")
+                continue
+            err = float(np.linalg.norm(np.asarray(a) - b) / nb)
+            if name == "sdot" and r.has_K:
+                Kb = np.diag(r.Sinv) @ r.K @ np.diag(r.Sinv)
+                ev = np.linalg.eigvalsh((Kb + Kb.T) / 2)
+                if np.sum(ev < 1e-12 * ev[-1]) >= 2:
+                    tol = 1e-3
+            if err >= tol:
+                raise AssertionError(f"validation: {name} of item {g} off by {err:.3e} (tolerance {tol})")
+            if name == "wrench":
+                worst_w = max(worst_w, err)
+            else:
+                worst_s = max(worst_s, err)
+    return {"validated_items": int(len(pick)), "validation": "counts bit-equal; worst relative error wrench "
+            f"{worst_w:.1e}, sdot {worst_s:.1e} (CPU oracle, same inputs)"}
+
+
+def small_scene_latencies(pfc, reps: int = 200):
+    """What one Radau stage evaluation costs (host buffers, Python caller: ~15 us of ctypes / numpy on top of the C ABI):
+    C1 (test/boxes.jl) and C2, through pfc_eval; and a single C3 pose."""
+    import numpy as np
+    out = {}
+    for name, w in (("C1", pfc.configs.c1_boxes()), ("C2", pfc.configs.c2_box_on_plane(1)), ("C3_single_pose", pfc.configs.c3_blob_tool(1))):
+        m = pfc.configs.build_scenario(w)
+        for _ in range(10):
+            m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"us_per_eval": dt * 1e6, "ops": int(ct[:, 1].sum()), "ops_per_s": float(ct[:, 1].sum()) / dt,
+                     "path": {0: "fused", 1: "batched", 2: "batched, two halves"}[m.last_parts()]}
+        m.close()
+    return out
 
 
 def main():
@@ -71,8 +145,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--poses", type=int, default=8192, help="Monte-Carlo poses (items) per GPU per step")
+    ap.add_argument("--config", choices=["C3", "C4", "C5"], default="C3")
+    ap.add_argument("--poses", type=int, default=8192, help="C3: Monte-Carlo poses (items) per GPU per step")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step block (median reported)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--validate", type=int, default=8, help="items re-evaluated by the CPU oracle after the timed region")
+    ap.add_argument("--no-validate", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the small-scene latency block")
     ap.add_argument("--friction", choices=["bristle", "regularized"], default="bristle",
                     help="friction model of the C3 instruction (BASELINE: bristle; regularized is an experiment knob)")
     ap.add_argument("--split-min", type=int, default=-1, help="library option split_min (-1: library default 1024; 0: never split)")
@@ -109,40 +188,55 @@ def main():
 
     import pfc_pkg
     pfc = pfc_pkg.load()
+    P = pfc.parallel
 
-    # ---- synthetic C3 batch; meshes are identical on every rank, poses are rank-specific ---------------------------
-    w = pfc.configs.c3_blob_tool(args.poses, seed=20260103 + 7919 * rank)
-    if args.friction == "regularized":
-        w.instructions[0].model = "regularized"
+    # ---- workload; meshes are identical on every rank ------------------------------------------------------------
+    if args.config == "C3":
+        w = pfc.configs.c3_blob_tool(args.poses, seed=20260103 + 7919 * rank)     # weak scaling: rank-specific poses
+        if args.friction == "regularized":
+            w.instructions[0].model = "regularized"
+        mine = np.arange(w.n_items)
+        parts, n_global, scaling = None, w.n_items * world, "weak"
+        desc = (f"C3: 9680-tet blob x 5120-tri tool, {args.friction} friction, quad rule 2, {args.poses} Monte-Carlo poses per GPU per step")
+    elif args.config == "C4":
+        w = pfc.configs.c2_box_on_plane(256, montecarlo=True)
+        parts = P.shard_block(w.n_items, world)
+        mine, n_global, scaling = parts[rank], w.n_items, "strong"
+        desc = "C4: 256 independent box-on-plane scenes (972-tet box, 2-triangle ground, regularized), contiguous blocks of scenes per GPU"
+    else:
+        w = pfc.configs.c5_pile()
+        leaves = [ms.tree.n_leaf for ms in w.meshes]
+        cost = [leaves[c.id_1] * leaves[c.id_2] for c in w.instructions]
+        parts = P.shard_by_cost(cost, world)
+        mine, n_global, scaling = parts[rank], w.n_items, "strong"
+        desc = "C5: pile of 64 compliant boxes (108..2352 tets), all 2016 body pairs as bristle instructions, cost-weighted shards"
     m = pfc.configs.build_scenario(w, device=local_rank)
     if args.bfs_levels >= 0:
         m.set_option("bfs_levels", args.bfs_levels)
     if args.split_min >= 0:
         m.set_option("split_min", args.split_min)
     if os.environ.get("PFC_NO_FILTER"):
-        m.set_option("no_filter", int(os.environ["PFC_NO_FILTER"]))     # experiment knob (1: FP64 only, 2: skip R loads - wrong results)
-    n = w.n_items
-    d_ins = torch.from_numpy(w.ins_ids.astype(np.int32)).to(dev)
-    d_pose = torch.from_numpy(np.ascontiguousarray(w.pose)).to(dev)
-    d_twist = torch.from_numpy(np.ascontiguousarray(w.twist)).to(dev)
-    d_s = torch.from_numpy(np.ascontiguousarray(w.s)).to(dev)
-    d_out = torch.zeros((n, 12), dtype=torch.float64, device=dev)      # [wrench 6 | sdot 6] per item
-    d_wrench = torch.zeros((n, 6), dtype=torch.float64, device=dev)
-    d_sdot = torch.zeros((n, 6), dtype=torch.float64, device=dev)
-    d_counts = torch.zeros((n, 4), dtype=torch.int32, device=dev)
-    gathered = torch.zeros((world * n, 12), dtype=torch.float64, device=dev) if world > 1 else None
+        m.set_option("no_filter", int(os.environ["PFC_NO_FILTER"]))     # experiment knob (1: FP64 only)
+    n = int(len(mine))
+    d_ins = torch.from_numpy(np.ascontiguousarray(w.ins_ids[mine]).astype(np.int32)).to(dev)
+    d_pose = torch.from_numpy(np.ascontiguousarray(w.pose[mine])).to(dev)
+    d_twist = torch.from_numpy(np.ascontiguousarray(w.twist[mine])).to(dev)
+    d_s = torch.from_numpy(np.ascontiguousarray(w.s[mine])).to(dev)
+    d_wrench = torch.zeros((max(n, 1), 6), dtype=torch.float64, device=dev)
+    d_sdot = torch.zeros((max(n, 1), 6), dtype=torch.float64, device=dev)
+    d_counts = torch.zeros((max(n, 1), 4), dtype=torch.int32, device=dev)
+    d_out = torch.zeros((max(n, 1), 12), dtype=torch.float64, device=dev)      # C3 exchange: [wrench 6 | sdot 6] per item
+    gathered = torch.zeros((world * n, 12), dtype=torch.float64, device=dev) if (world > 1 and args.config == "C3") else None
     stream = torch.cuda.current_stream().cuda_stream
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    xchg_ms = [0.0]
 
-    def step():
-        # re-issue while a work list overflowed (only happens while buffers are still growing, i.e. in warmup)
-        for _ in range(40):
-            m.eval_device(n, d_ins.data_ptr(), d_pose.data_ptr(), d_twist.data_ptr(), d_s.data_ptr(),
-                          d_wrench.data_ptr(), d_sdot.data_ptr(), d_counts.data_ptr(), stream)
-            if m.check() == 0:
-                break
-        else:
-            raise RuntimeError("work lists kept overflowing")
-        if world > 1:
+    def exchange(timed: bool):
+        if world == 1:
+            return
+        if timed:
+            ev_a.record()
+        if args.config == "C3":
             d_out[:, :6] = d_wrench
             d_out[:, 6:] = d_sdot
             if backend == "nccl":
@@ -151,6 +245,28 @@ def main():
                 parts_cpu = [torch.empty((n, 12), dtype=torch.float64) for _ in range(world)]
                 dist.all_gather(parts_cpu, d_out.cpu())
                 gathered.copy_(torch.cat(parts_cpu).to(dev))
+        else:
+            # the product exchange: per-item rows [wrench | sdot | counts] of the rank's own items -> item order, every rank
+            rows = P.pack_rows(d_wrench[:n], d_sdot[:n], d_counts[:n])
+            if backend != "nccl":
+                rows = rows.cpu()
+            P.all_gather_rows(rows, parts, n_global)
+        if timed:
+            ev_b.record()
+            ev_b.synchronize()
+            xchg_ms[0] += ev_a.elapsed_time(ev_b)
+
+    def step(timed: bool = False):
+        # re-issue while a work list overflowed (only happens while buffers are still growing, i.e. in warmup)
+        if n:
+            for _ in range(40):
+                m.eval_device(n, d_ins.data_ptr(), d_pose.data_ptr(), d_twist.data_ptr(), d_s.data_ptr(),
+                              d_wrench.data_ptr(), d_sdot.data_ptr(), d_counts.data_ptr(), stream)
+                if m.check() == 0:
+                    break
+            else:
+                raise RuntimeError("work lists kept overflowing")
+        exchange(timed)
 
     def fence():
         if world > 1:
@@ -159,70 +275,84 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    m.set_option("profile", 1)
+    # ---- timed region: --reps repetitions of the K-step block ------------------------------------------------------
+    rep_dt = []
+    for _ in range(max(args.reps, 1)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            if backend != "nccl":
+                t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rep_dt.append(float(t.item()))
+    dt = statistics.median(rep_dt)
+    st = m.stats() if n else {"candidates": 0, "node_tests": 0, "tractions": 0}
+    path = m.last_parts() if n else 1      # 0: fused small-scene kernel, 1: batched, 2: batched as two concurrent halves
+    # ---- per-stage kernel times (HIP events inside the library, batched path) and the exchange's share: extra steps --
     stage = {}
-    fence()
-    t0 = time.perf_counter()
+    if n:
+        m.set_option("profile", 1)
+        for _ in range(args.steps):
+            step()
+            for k, v in m.stage_ms().items():
+                stage[k] = stage.get(k, 0.0) + v
+        st_prof = m.stats()
+        parts_prof = max(m.last_parts(), 1)
+        m.set_option("profile", 0)
     for _ in range(args.steps):
-        step()
-        for k, v in m.stage_ms().items():
-            stage[k] = stage.get(k, 0.0) + v
-    fence()
-    dt = time.perf_counter() - t0
-    st = m.stats()
-    parts = m.last_parts()      # 2: the step ran as two concurrent half-batches (library option split_min)
+        step(timed=True)
+    xchg_per_step = xchg_ms[0] / max(args.steps, 1)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(st["candidates"]), float(n), float(st["node_tests"]), float(st["tractions"])],
                        dtype=torch.float64, device=dev)
     if world > 1:
         if backend != "nccl":
-            t, tot = t.cpu(), tot.cpu()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tot = tot.cpu()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt = float(t.item())
     ops_step, items_step, nodes_step, trac_step = [float(v) for v in tot.tolist()]
 
     if rank == 0:
         K = args.steps
         np_ms = stage["narrowphase"] / K
         bp_ms = stage["broadphase"] / K
-        # SURVEY §8(d) accounting: algorithmic bytes / kernel time against the HBM peak.  Both kernels re-read their
-        # 96..256-byte records from L2 / Infinity Cache across the poses of a batch, so "achieved" can exceed what HBM
-        # could deliver while the PMC traffic stays tiny: the kernels are vector-issue / latency bound (see "valu").
-        roof_np = {"kernel": "k_narrow<false>", "bound": "hbm", "achieved": BYTES_PER_OP * st["candidates"] / parts / (np_ms * 1e-3) / 1e9,
+        parts_n = parts_prof
+        # SURVEY §8(d) accounting: algorithmic bytes / kernel time against the HBM peak (well below 1: these kernels re-read
+        # their 64..256-byte records from L2 / Infinity Cache and are bound by vector issue, see "valu").
+        roof_np = {"kernel": "k_narrow<false>", "bound": "hbm",
+                   "achieved": BYTES_PER_OP * st_prof["candidates"] / parts_n / (np_ms * 1e-3) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms_per_launch": np_ms,
-                   "units_per_launch": st["candidates"] / parts, "bytes_per_unit": BYTES_PER_OP}
-        roof_bp = {"kernel": "k_bp_dfs32 (+ k_bp_expand seed levels when the batch has < 2048 items)", "bound": "hbm",
-                   "achieved": BYTES_PER_NODE_TEST * st["node_tests"] / parts / (bp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                   "unit": "GB/s", "traffic": None, "ms_per_launch": bp_ms,
-                   "units_per_launch": st["node_tests"] / parts, "bytes_per_unit": BYTES_PER_NODE_TEST}
-        for r in (roof_np, roof_bp):
-            r["frac"] = r["achieved"] / r["peak"]
-            if parts > 1:
-                r["launch_note"] = (f"the step runs as {parts} concurrent half-batches on two streams: a launch processes "
-                                    "1/2 of the step's units WHILE kernels of the other half share the CUs, so per-launch "
-                                    "durations are longer than those of an exclusive launch (stage_ms_per_step = mean over "
-                                    "the half-launches; they overlap and do not add up to ms_per_step)")
-        # vector-ALU view (what actually bounds both kernels): measured wave-level VALU instruction counts per unit
-        # (rocprofv3 SQ_INSTS_VALU, profiles/pmc_valu.json) x the issue cost of a wave64 instruction on a SIMD-32
-        # (MI355X_MICROARCH.md: 2 cycles single precision, 4 cycles double precision) over 1024 SIMDs at 2.4 GHz
-        pv = os.path.join(ROOT, "profiles", "pmc_valu.json")
-        if os.path.exists(pv):
+                   "units_per_launch": st_prof["candidates"] / parts_n, "bytes_per_unit": BYTES_PER_OP}
+        roof_np["frac"] = roof_np["achieved"] / roof_np["peak"]
+        # The broadphase reads two 64-byte NodeF lines per node test, all from L2 / Infinity Cache (PMC traffic ~0.1 % of the
+        # 240 algorithmic bytes): HBM is not its roofline.  It is priced against vector-instruction issue instead.
+        roof_bp = {"kernel": "k_bp_dfs32 (+ k_bp_expand seed levels for small batches)", "bound": "valu_fp32",
+                   "unit": "wave-instructions/s", "traffic": None, "ms_per_launch": bp_ms,
+                   "units_per_launch": st_prof["node_tests"] / parts_n,
+                   "algorithmic_gbs_cache_served": BYTES_PER_NODE_TEST * st_prof["node_tests"] / parts_n / (bp_ms * 1e-3) / 1e9,
+                   "peak": N_SIMD * CLOCK_HZ / 2.0}
+        pv = os.path.join(ROOT, "profiles", "pmc_valu.json")      # counters were measured on the C3 default workload
+        if os.path.exists(pv) and args.config == "C3":
             try:
                 vj = json.load(open(pv))
                 for r, key, unit_key, cyc, what in ((roof_bp, "k_bp_dfs32_valu_insts", "node_tests", 2.0, "single"),
                                                     (roof_np, "k_narrow_valu_insts", "candidates", 4.0, "double")):
                     per_unit = vj[key] / vj[unit_key]
-                    issue_ms = per_unit * r["units_per_launch"] * cyc / (1024 * 2.4e9) * 1e3
+                    issue_ms = per_unit * r["units_per_launch"] * cyc / (N_SIMD * CLOCK_HZ) * 1e3
                     r["valu"] = {"wave_instructions_per_unit": per_unit, "issue_bound_ms": issue_ms,
                                  "frac_of_issue_peak": issue_ms / r["ms_per_launch"],
                                  "note": f"{what}-precision wave64 VALU instruction = {cyc:.0f} cycles on a SIMD-32; 1024 SIMDs, "
-                                         "2.4 GHz; instruction counts from profiles/pmc_valu.json"}
+                                         f"2.4 GHz; instruction counts from profiles/pmc_valu.json ({vj.get('measured', 'see file')})"}
+                roof_bp["achieved"] = roof_bp["valu"]["wave_instructions_per_unit"] * roof_bp["units_per_launch"] / (bp_ms * 1e-3)
+                roof_bp["frac"] = roof_bp["achieved"] / roof_bp["peak"]
             except Exception:
                 pass
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # measured offline with rocprofv3 --pmc
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.config == "C3" and args.poses == 8192:
             try:
                 tj = json.load(open(pmc))
                 roof_np["traffic"] = tj.get("k_narrow0_bytes_per_launch")
@@ -230,7 +360,11 @@ def main():
                 roof_np["traffic_note"] = roof_bp["traffic_note"] = tj.get("note")
             except Exception:
                 pass
-        dominant, other = (roof_bp, roof_np) if bp_ms >= np_ms else (roof_np, roof_bp)
+        if parts_n > 1:
+            for r in (roof_np, roof_bp):
+                r["launch_note"] = (f"the step runs as {parts_n} concurrent half-batches on two streams: a launch processes "
+                                    "1/2 of the step's units WHILE kernels of the other half share the CUs, so per-launch "
+                                    "durations are longer than those of an exclusive launch (they overlap and do not add up to ms_per_step)")
         out = {
             "metric": "tet-tri clip+integrate ops/s",
             "value": ops_step * K / dt,
@@ -238,23 +372,36 @@ def main():
             "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"C3: 9680-tet blob x 5120-tri tool, {args.friction} friction, quad rule 2, "
-                                   f"{args.poses} Monte-Carlo poses per GPU per step",
-                       "poses_per_gpu": args.poses, "ops_per_step": ops_step, "node_tests_per_step": nodes_step,
-                       "traction_points_per_step": trac_step,
-                       "exchange": ("none" if world == 1 else "RCCL all-gather of [wrench, sdot] per item" if backend == "nccl"
-                                    else f"REHEARSAL ({backend}, ranks share GPUs): all-gather through host memory")},
+            "config": {"workload": desc, "name": args.config, "items_per_step": items_step, "ops_per_step": ops_step,
+                       "node_tests_per_step": nodes_step, "traction_points_per_step": trac_step,
+                       "exchange": ("none" if world == 1 else
+                                    ("RCCL all-gather of [wrench, sdot] per item" if args.config == "C3" else
+                                     "RCCL all-gather of [wrench | sdot | counts] rows (parallel.all_gather_rows)")
+                                    if backend == "nccl" else f"REHEARSAL ({backend}, ranks share GPUs): all-gather through host memory")},
+            "timing": {"reps": len(rep_dt), "median_ms_per_step": dt / K * 1e3,
+                       "min_ms_per_step": min(rep_dt) / K * 1e3, "max_ms_per_step": max(rep_dt) / K * 1e3,
+                       "seconds_timed": sum(rep_dt)},
             "contact_pairs_per_s": items_step * K / dt,
             "node_tests_per_s": nodes_step * K / dt,
             "stage_ms_per_step": {k: v / K for k, v in stage.items()},
-            "concurrent_parts": parts,
-            "roofline": dominant,
-            "roofline_other": other,
+            "exchange_ms_per_step": xchg_per_step,
+            "exchange_share": (xchg_per_step / (dt / K * 1e3)) if world > 1 else 0.0,
+            "path": {0: "fused small-scene kernel", 1: "batched", 2: "batched, two concurrent halves"}[path],
+            "concurrent_parts": max(path, 1),
+            "roofline": roof_np if (args.config != "C3" or np_ms >= bp_ms) else roof_bp,
+            "roofline_other": roof_bp if (args.config != "C3" or np_ms >= bp_ms) else roof_np,
         }
+        if not args.no_validate and n:
+            out.update(validate(pfc, w, mine, d_wrench[:n].cpu().numpy(), d_sdot[:n].cpu().numpy(),
+                                d_counts[:n].cpu().numpy(), args.validate))
+        if world == 1 and not args.no_extras:
+            # single-pose rate of the C3 scene and the small reference-sized scenes (latency, not throughput)
+            out["small_scenes"] = small_scene_latencies(pfc)
+            out["single_pose_ops_per_s"] = out["small_scenes"]["C3_single_pose"]["ops_per_s"]
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pfc, w, args.cpu_seconds, 1)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()

@@ -51,7 +51,8 @@ struct FuArgs {
     const InsFull *ins;
     double *wrench, *sdot;
     int *counts;             // may be null
-    int *fout;               // per item 8 ints: status, counts[4], 0, 0, 0
+    int *fout;               // per item 8 ints: status, counts[4], seq (written LAST, behind a system-scope fence), 0, 0
+    int seq;                 // evaluation sequence number (never 0): the host may poll fout[8 i + 5] instead of synchronising
     unsigned long long *stamps;   // diagnostic builds (-DPFC_STAMPS): block 0 leaves wall-clock stamps (10 ns ticks) of its phases
 };
 
@@ -754,14 +755,17 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) { g.wrench[6 * (size_t)item + k] = wv[k]; g.sdot[6 * (size_t)item + k] = sd[k]; }
     }
-    if (tid == 0) {
+    if (tid == 0) {      // the same lane stored wrench and sdot above
         int *fo = g.fout + 8 * (size_t)item;
         fo[0] = (int)status; fo[1] = n_test; fo[2] = n_cand; fo[3] = n_nonempty; fo[4] = n_trac;
-        fo[5] = fo[6] = fo[7] = 0;
+        fo[6] = fo[7] = 0;
         if (g.counts) {
             int *co = g.counts + 4 * (size_t)item;
             co[0] = n_test; co[1] = n_cand; co[2] = n_nonempty; co[3] = n_trac;
         }
+        // completion word: everything this item writes is visible to the host before it (system-scope release)
+        __threadfence_system();
+        __hip_atomic_store(&fo[5], g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     FSTAMP(9);
 #ifdef PFC_STAMPS

@@ -12,6 +12,7 @@
 // hipGraph capture / replay, the two-half evaluation and every extern "C" entry point.
 #include "pfc_kernels.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -256,6 +257,7 @@ struct pfc_context {
     const int *fout_host = nullptr;    //   ... and this is where the host reads it
     int opt_fused = 1;                 // option "fused"
     int fused_skip = 0;                // evaluations left for which the fused kernel stays off after an item did not fit
+    int fused_seq = 0;                 // sequence number of the last fused launch (completion word of the polled path)
     bool pending_fused = false, last_fused = false;
     int opt_split_min = 1024;          // 0: never split
     int opt_poison = 0;                // diagnostic: fill (re)allocated work lists with 0xFF bytes (item index -1)
@@ -650,6 +652,8 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
         }
         a.fout = h->fout.p;
     }
+    if (++h->fused_seq == 0) h->fused_seq = 1;
+    a.seq = h->fused_seq;
     a.stamps = nullptr;
 #ifdef PFC_STAMPS
     HIP_TRY(h, h->stamps.ensure(16));
@@ -668,8 +672,22 @@ int check_fused(pfc_context *h) {
     if (!fo) {
         HIP_TRY(h, hipMemcpyAsync(h->h_fout, h->fout.p, sizeof(int) * 8 * (size_t)n, hipMemcpyDeviceToHost, h->last_stream));
         fo = h->h_fout;
+        HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    } else {
+        // The kernel wrote its results straight into pinned host memory; every workgroup ends with a system-scope
+        // release and its completion word.  Polling those words returns ~3 us earlier than hipStreamSynchronize wakes
+        // up; after ~200 us without completion (a long evaluation, a stalled queue) the stream is synchronised instead.
+        const volatile int *vf = fo;
+        const int seq = h->fused_seq;
+        bool done = false;
+        for (int spin = 0; spin < 200000 && !done; ++spin) {
+            done = true;
+            for (int i = n - 1; i >= 0; --i)
+                if (vf[8 * i + 5] != seq) { done = false; break; }
+        }
+        if (done) std::atomic_thread_fence(std::memory_order_acquire);
+        else HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     }
-    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     h->pending = false; h->pending_fused = false; h->last_parts = 1; h->last_fused = true;
     unsigned status = 0;
     long long tot[4] = {0, 0, 0, 0};
@@ -1106,7 +1124,7 @@ static hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes) {
     if (*p) (void)hipHostFree(*p);
     *p = nullptr; *cap = 0;
     hipError_t e = hipHostMalloc(p, bytes * 2);
-    if (e == hipSuccess) *cap = bytes * 2;
+    if (e == hipSuccess) { *cap = bytes * 2; std::memset(*p, 0, bytes * 2); }   // completion words are polled: never start from stale bytes
     if (std::getenv("PFC_LOG_ALLOC")) std::fprintf(stderr, "pfc pinned %p .. %p\n", *p, (void *)((char *)*p + bytes * 2));
     return e;
 }

@@ -326,3 +326,30 @@ def test_max_levels_option_is_clamped(pfc):
     m2.add_friction_bristle(0, 1, mu_d=0.3)
     m2.finalize()
     m2.close()
+
+
+def test_evaluate_sharded_with_the_hip_evaluator(pfc):
+    """parallel.evaluate_sharded (the product sharding + exchange code, world = 1 here; 2 ranks over gloo in
+    tests/test_host.py) with MechanismScenario.force_all_elastic_intersections as the evaluator, block and cost-weighted
+    shards, against the oracle."""
+    P = pfc.parallel
+    w = pfc.configs.c2_box_on_plane(48, montecarlo=True)
+    m = pfc.configs.build_scenario(w)
+
+    def evaluator(idx):
+        return m.force_all_elastic_intersections(w.pose[idx], w.twist[idx], w.s[idx], w.ins_ids[idx])
+
+    ref = H.oracle_run(pfc, w, debug=False)
+    cost = np.arange(w.n_items, dtype=np.float64) % 7 + 1.0
+    for parts in (P.shard_block(w.n_items, 1), P.shard_by_cost(cost, 1), None):
+        wr, sd, ct = P.evaluate_sharded(evaluator, w.n_items, parts)
+        for k, r in enumerate(ref):
+            assert np.array_equal(ct[k], r.counts)
+            assert H.rel_err(wr[k], r.wrench) < TOL
+    # a rank's shard of a multi-rank partition, evaluated alone: rows land at the right items
+    parts4 = P.shard_by_cost(cost, 4)
+    for p in parts4:
+        wr, sd, ct = evaluator(p)
+        for j, k in enumerate(p):
+            assert np.array_equal(ct[j], ref[k].counts) and H.rel_err(wr[j], ref[k].wrench) < TOL
+    m.close()
