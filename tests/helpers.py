@@ -47,7 +47,7 @@ def rel_err(a, b):
 # one calcXd (test/test_normal.jl:31-41, test/test_friction.jl:228-236,251-256); both backends return the same view.
 # ----------------------------------------------------------------------------------------------------------------
 class SceneResult:
-    __slots__ = ("status", "wrench", "sdot", "counts", "trac", "has_K", "K", "Kbar_inv_sqrt", "Sinv", "cop")
+    __slots__ = ("status", "wrench", "sdot", "counts", "trac", "has_K", "K", "Kbar_inv_sqrt", "Sinv", "cop", "pairs", "clip_n")
 
 
 def normal_wrench_from_tractions(trac):
@@ -58,7 +58,8 @@ def normal_wrench_from_tractions(trac):
     return np.concatenate([ang, lin])
 
 
-def eval_scene(backend, pfc, mesh_1, Ebar_1, mesh_2, Ebar_2, ins, pose, twist, s=None, trees=None, options=None):
+def eval_scene(backend, pfc, mesh_1, Ebar_1, mesh_2, Ebar_2, ins, pose, twist, s=None, trees=None, options=None,
+               want_pairs=False):
     """ins: dict(model="regularized"|"bristle", chi, n_quad, mu_s, mu_d, v_c | tau, k_bar, magic).
     trees: optional (OBBTree, OBBTree) supplied by the host instead of the library's builder."""
     G = pfc.geometry
@@ -74,6 +75,7 @@ def eval_scene(backend, pfc, mesh_1, Ebar_1, mesh_2, Ebar_2, ins, pose, twist, s
         e = O.evaluate(m1, m2, oi, pose, twist, s)
         r.status, r.wrench, r.sdot, r.counts, r.trac = e.status, e.wrench, e.sdot, e.counts, e.trac
         r.has_K, r.K, r.Kbar_inv_sqrt, r.Sinv, r.cop = e.has_K, e.K, e.Kbar_inv_sqrt, e.Sinv, e.cop
+        r.pairs, r.clip_n = e.pairs, e.clip_n
         return r
     assert backend == "hip"
     S = pfc.scenario
@@ -96,6 +98,7 @@ def eval_scene(backend, pfc, mesh_1, Ebar_1, mesh_2, Ebar_2, ins, pose, twist, s
     wrench, sdot, counts = m.force_all_elastic_intersections(pose, twist, s_in)
     r.status, r.wrench, r.sdot, r.counts = 0, wrench[0], sdot[0], counts[0]
     r.trac = m.debug_tractions(0)
+    r.pairs, r.clip_n = m.debug_pairs(0) if want_pairs else (None, None)
     st = m.debug_stiffness(0) if ins["model"] == "bristle" else None
     r.has_K = st is not None
     r.K, r.Kbar_inv_sqrt, r.Sinv, r.cop = st if st is not None else (None, None, None, None)
