@@ -131,6 +131,18 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
                   double *sdot, double *d_wrench, double *d_sdot, int *counts);
 
 /*
+ * pfc_eval_dual with every buffer resident in device memory and no host synchronisation (the Dual sibling of
+ * pfc_eval_device; Radau's Jacobian evaluations are half of its calls, src/radau/radau_functions.jl:2-14): value pass and
+ * Dual passes are enqueued back to back on `stream`.  The Dual polygons kept between the passes are sized from the
+ * previous Dual evaluation of the handle; pfc_check() synchronises and returns PFC_ERR_OVERFLOW if a work list or that
+ * speculation fell short (buffers have grown: re-issue).  d_ds may be NULL (zeros); d_ins_ids and d_counts may be NULL.
+ */
+int pfc_eval_dual_device(pfc_handle h, int n_items, int n_dir, const int *d_ins_ids, const double *d_pose,
+                         const double *d_twist, const double *d_s, const double *d_dpose, const double *d_dtwist,
+                         const double *d_ds, double *d_wrench, double *d_sdot, double *d_dwrench, double *d_dsdot,
+                         int *d_counts, void *stream);
+
+/*
  * eMesh_to_tree (src/geometry/blob_types.jl:136-173) on the host: builds the flattened binary OBB tree that
  * pfc_add_mesh takes.  method PFC_TREE_BLOB follows the reference (bottom-up merging of face/edge-adjacent blobs by
  * marginal cost :74-134, median-split top-down over the remaining blobs src/geometry/top_down.jl:10-32, tight leaf

@@ -207,6 +207,10 @@ struct pfc_context {
     void *pin_din = nullptr, *pin_dout = nullptr; // pinned blocks of the small-scene Dual path (partials in / out)
     size_t pin_din_cap = 0, pin_dout_cap = 0;
     long long dual_hint = -1;                     // contributing pairs of the last Dual evaluation (-1: none yet)
+    bool pending_dual = false;                    // pfc_eval_dual_device enqueued: pfc_check also checks the speculative polygon capacity
+    size_t pending_dpcap = 0;
+    int pending_ndir = 0;
+    DevBuf<double> dual_zero;                     // zeros standing in for a null d_ds
     unsigned long long epoch = 0;        // bumped whenever a device work buffer is reallocated
     // captured launch sequence (hipGraph) of the last evaluation shape
     hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [0] plain evaluation, [1] with the contributing-pair list (Dual)
@@ -808,7 +812,7 @@ void pfc_destroy(pfc_handle h) {
     h->tail.release();
     h->rgn.release(); h->poly_item.release(); h->poly.release(); h->surv.release(); h->scat_d.release(); h->scat_i.release();
     h->dual_poly.release(); h->dual_pkey.release();
-    h->dual_in.release(); h->dual_acc.release(); h->dual_res.release(); h->dual_out.release();
+    h->dual_in.release(); h->dual_acc.release(); h->dual_res.release(); h->dual_out.release(); h->dual_zero.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1115,7 +1119,18 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
 int pfc_check(pfc_handle h) {
     if (!h) return PFC_ERR_BAD_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
-    return check_eval(h);
+    const bool dual = h->pending_dual;
+    h->pending_dual = false;
+    const int rc = check_eval(h);
+    if (rc != PFC_OK || !dual) return rc;
+    // did the kept Dual polygons of pfc_eval_dual_device fit?  (contributing pairs: the counter next to the polygon total
+    // in the packed tail, which check_eval has just brought over)
+    const long long pairs = h->h_tail[12 + (((h->last_levels + 9) & ~1) + 1)];
+    h->dual_hint = pairs;
+    const int cpw = 64 / h->pending_ndir;
+    if (h->any_bristle && (size_t)((pairs + cpw - 1) / cpw) * 64 + 64 > h->pending_dpcap)
+        return fail(h, PFC_ERR_OVERFLOW, "Dual evaluation: %lld contributing pairs exceed the speculative polygon capacity: re-issue", pairs);
+    return PFC_OK;
 }
 
 // pinned staging block of at least `bytes` (grown with slack, never shrunk)
@@ -1352,6 +1367,45 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
 }
 }  // namespace
 
+int pfc_eval_dual_device(pfc_handle h, int n_items, int n_dir, const int *d_ins_ids, const double *d_pose,
+                         const double *d_twist, const double *d_s, const double *d_dpose, const double *d_dtwist,
+                         const double *d_ds, double *d_wrench, double *d_sdot, double *d_dwrench, double *d_dsdot,
+                         int *d_counts, void *stream) {
+    if (!h) return PFC_ERR_BAD_ARG;
+    if (n_dir < 1 || n_dir > 16) return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual_device: n_dir must be in 1..16");
+    { const int rc = check_eval_args(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot); if (rc != PFC_OK) return rc; }
+    h->pending_dual = false;
+    if (n_items == 0) { h->pending = false; h->last_n_items = 0; return PFC_OK; }
+    if (!d_dpose || !d_dtwist || !d_dwrench || !d_dsdot) return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual_device: null buffer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const size_t nk = (size_t)n_items * n_dir;
+    // Kept Dual polygons are sized WITHOUT reading the value pass back: twice the contributing pairs of the previous Dual
+    // evaluation (a power of two, so that the buffers settle), a guess the first time.  pfc_check compares the actual
+    // count with the capacity after the one synchronisation and asks for a re-issue if it fell short.
+    size_t bound = 4096;
+    while (bound < (size_t)(h->dual_hint > 0 ? h->dual_hint : 0) * 2 + 64 || bound < (size_t)n_items * 8) bound *= 2;
+    HIP_TRY(h, ensure_dual(h, h->dual_acc, nk * kDaStride));
+    HIP_TRY(h, ensure_dual(h, h->dual_res, nk * kDrStride));
+    if (!d_ds) {
+        const size_t c0 = h->dual_zero.cap;
+        HIP_TRY(h, h->dual_zero.ensure(nk * 6));
+        if (h->dual_zero.cap != c0) HIP_TRY(h, hipMemsetAsync(h->dual_zero.p, 0, sizeof(double) * h->dual_zero.cap, st));
+        d_ds = h->dual_zero.p;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
+    h->split_n0 = 0; h->pending_fused = false;
+    h->want_surv = true;         // the value pass also lists the contributing candidates; batched path, one part
+    int rc = enqueue_eval(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
+    h->want_surv = false;
+    if (rc != PFC_OK) return rc;
+    size_t dpcap = 0;
+    rc = launch_dual(h, n_items, n_dir, h->tail.p, d_dpose, d_dtwist, d_ds, d_dwrench, d_dsdot, bound, st, &dpcap, true);
+    if (rc != PFC_OK) return rc;
+    h->pending_dual = true; h->pending_dpcap = dpcap; h->pending_ndir = n_dir;
+    return PFC_OK;
+}
+
 int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, const double *pose, const double *twist,
                   const double *s, const double *d_pose, const double *d_twist, const double *d_s, double *wrench,
                   double *sdot, double *d_wrench, double *d_sdot, int *counts) {
@@ -1368,14 +1422,58 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
                                              d_wrench, d_sdot, counts);
         if (rc_small != PFC_ERR_OVERFLOW) return rc_small;    // else: lists grown / speculation short -> two-stage path
     }
-    // values, candidate list and per-item counters: the ordinary evaluation (the broadphase ignores partials,
-    // src/contact_algorithms_non_friction.jl:95)
+    if (n_items == 0) return PFC_OK;
+    const size_t nk = (size_t)n_items * n_dir;
+    hipStream_t st = h->stream;
+    if (!h->opt_debug && std::getenv("PFC_DUAL_TWO_STAGE") == nullptr) {
+        // One synchronisation: inputs up in one pinned block, pfc_eval_dual_device (value pass + Dual passes back to back,
+        // kept Dual polygons sized from the previous evaluation), results down in one pinned block, pfc_check.  A work
+        // list that overflowed or a speculation that fell short re-issues the evaluation (buffers have grown).
+        HIP_TRY(h, hipSetDevice(h->device));
+        const size_t n = (size_t)n_items;
+        const size_t in_d = n * 36 + nk * 36, in_bytes = in_d * sizeof(double) + n * sizeof(int);
+        const size_t out_d = n * 12 + nk * 12, out_bytes = out_d * sizeof(double) + n * 4 * sizeof(int);
+        HIP_TRY(h, ensure_pinned(&h->pin_din, &h->pin_din_cap, in_bytes));
+        HIP_TRY(h, ensure_pinned(&h->pin_dout, &h->pin_dout_cap, out_bytes));
+        HIP_TRY(h, ensure_dual(h, h->dual_in, in_d + (n + 1) / 2 + 1));
+        HIP_TRY(h, ensure_dual(h, h->dual_out, out_d + (n * 4 + 1) / 2 + 1));
+        double *pi = (double *)h->pin_din;
+        std::memcpy(pi, pose, sizeof(double) * n * 24);
+        std::memcpy(pi + n * 24, twist, sizeof(double) * n * 6);
+        if (s) std::memcpy(pi + n * 30, s, sizeof(double) * n * 6); else std::memset(pi + n * 30, 0, sizeof(double) * n * 6);
+        double *pd = pi + n * 36;
+        std::memcpy(pd, d_pose, sizeof(double) * nk * 24);
+        std::memcpy(pd + nk * 24, d_twist, sizeof(double) * nk * 6);
+        if (d_s) std::memcpy(pd + nk * 30, d_s, sizeof(double) * nk * 6); else std::memset(pd + nk * 30, 0, sizeof(double) * nk * 6);
+        if (ins_ids) std::memcpy(pi + in_d, ins_ids, sizeof(int) * n);
+        double *di = h->dual_in.p, *dd = di + n * 36, *dout = h->dual_out.p, *ddo = dout + n * 12;
+        HIP_TRY(h, hipMemcpyAsync(di, pi, ins_ids ? in_bytes : in_d * sizeof(double), hipMemcpyHostToDevice, st));
+        int rc2 = PFC_OK;
+        for (int attempt = 0; attempt < 40; ++attempt) {
+            rc2 = pfc_eval_dual_device(h, n_items, n_dir, ins_ids ? (const int *)(di + in_d) : nullptr, di, di + n * 24,
+                                       s ? di + n * 30 : nullptr, dd, dd + nk * 24, dd + nk * 30, dout, dout + n * 6,
+                                       ddo, ddo + nk * 6, (int *)(dout + out_d), st);
+            if (rc2 != PFC_OK) return rc2;
+            HIP_TRY(h, hipMemcpyAsync(h->pin_dout, dout, out_bytes, hipMemcpyDeviceToHost, st));
+            rc2 = pfc_check(h);
+            if (rc2 != PFC_ERR_OVERFLOW) break;
+        }
+        if (rc2 != PFC_OK) return rc2;
+        const double *po = (const double *)h->pin_dout;
+        std::memcpy(wrench, po, sizeof(double) * n * 6);
+        std::memcpy(sdot, po + n * 6, sizeof(double) * n * 6);
+        std::memcpy(d_wrench, po + n * 12, sizeof(double) * nk * 6);
+        std::memcpy(d_sdot, po + n * 12 + nk * 6, sizeof(double) * nk * 6);
+        if (counts) std::memcpy(counts, po + out_d, sizeof(int) * n * 4);
+        return PFC_OK;
+    }
+    // two-stage path (debug option, or PFC_DUAL_TWO_STAGE set for A/B runs): values, candidate list and per-item counters
+    // by the ordinary evaluation (the broadphase ignores partials, src/contact_algorithms_non_friction.jl:95), read the
+    // contributing-pair count, then the Dual passes
     h->want_surv = true;
     int rc = pfc_eval(h, n_items, ins_ids, pose, twist, s, wrench, sdot, counts);
     h->want_surv = false;
-    if (rc != PFC_OK || n_items == 0) return rc;
-    const size_t nk = (size_t)n_items * n_dir;
-    hipStream_t st = h->stream;
+    if (rc != PFC_OK) return rc;
     HIP_TRY(h, ensure_dual(h, h->dual_in, nk * 36));
     HIP_TRY(h, ensure_dual(h, h->dual_acc, nk * kDaStride));
     HIP_TRY(h, ensure_dual(h, h->dual_res, nk * kDrStride));

@@ -349,6 +349,14 @@ class MechanismScenario:
         self._check(_lib.lib().pfc_eval_device(self._h, int(n_items), d_ins_ids or None, d_pose, d_twist,
                                                d_s or None, d_wrench, d_sdot, d_counts or None, stream or None))
 
+    def eval_dual_device(self, n_items: int, n_dir: int, d_ins_ids: int, d_pose: int, d_twist: int, d_s: int, d_dpose: int,
+                         d_dtwist: int, d_ds: int, d_wrench: int, d_sdot: int, d_dwrench: int, d_dsdot: int, d_counts: int,
+                         stream: int = 0):
+        """pfc_eval_dual_device: raw device addresses; asynchronous; follow with check() (re-issue on ERR_OVERFLOW)."""
+        self._check(_lib.lib().pfc_eval_dual_device(self._h, int(n_items), int(n_dir), d_ins_ids or None, d_pose, d_twist,
+                                                    d_s or None, d_dpose, d_dtwist, d_ds or None, d_wrench, d_sdot,
+                                                    d_dwrench, d_dsdot, d_counts or None, stream or None))
+
     def check(self) -> int:
         """pfc_check: synchronise; returns the status (PFC_ERR_OVERFLOW means: re-issue, buffers were grown)."""
         rc = _lib.lib().pfc_check(self._h)

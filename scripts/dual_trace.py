@@ -1,0 +1,32 @@
+"""Diagnostic: N device-resident Dual evaluations (pfc_eval_dual_device) of one config, for a rocprofv3 kernel trace.
+usage: dual_trace.py <c1|c2|c4|c5|c3> [n_evals] [n_dir]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, pfc_pkg
+pfc = pfc_pkg.load()
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c5"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+nd = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+w = {"c1": pfc.configs.c1_boxes, "c2": lambda: pfc.configs.c2_box_on_plane(1), "c3": lambda: pfc.configs.c3_blob_tool(1),
+     "c4": lambda: pfc.configs.c2_box_on_plane(256, montecarlo=True), "c5": pfc.configs.c5_pile}[cfg]()
+m = pfc.configs.build_scenario(w)
+dev = torch.device("cuda", 0)
+T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+ni = w.n_items
+t = [T(w.ins_ids, torch.int32), T(w.pose), T(w.twist), T(w.s), T(np.zeros((ni, nd, 24))), T(np.zeros((ni, nd, 6))), T(np.zeros((ni, nd, 6)))]
+o = [torch.zeros((ni, 6), dtype=torch.float64, device=dev), torch.zeros((ni, 6), dtype=torch.float64, device=dev),
+     torch.zeros((ni, nd, 6), dtype=torch.float64, device=dev), torch.zeros((ni, nd, 6), dtype=torch.float64, device=dev),
+     torch.zeros((ni, 4), dtype=torch.int32, device=dev)]
+st = torch.cuda.current_stream().cuda_stream
+def run():
+    for _ in range(40):
+        m.eval_dual_device(ni, nd, *[x.data_ptr() for x in t], *[x.data_ptr() for x in o], st)
+        if m.check() == 0:
+            return
+for _ in range(5):
+    run()
+t0 = time.perf_counter()
+for _ in range(n):
+    run()
+print(f"{cfg}: {(time.perf_counter() - t0) / n * 1e6:.1f} us per device-resident Dual({nd}) evaluation; stats {m.stats()}")
+m.close()

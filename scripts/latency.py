@@ -34,4 +34,29 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
         m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
     dd = (time.perf_counter() - t0) / (n // 2) - dt
     print(f"{'':45s} {dd*1e6:9.1f} us/Dual eval (6 partials)")
+    # device-resident Dual evaluation (pfc_eval_dual_device + pfc_check): what the host-buffer figure above pays on top is
+    # 288 B per (item, direction) of seeds over PCIe and the staging copies
+    try:
+        import torch
+        dev = torch.device("cuda", 0)
+        T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+        ni = w.n_items
+        t = [T(w.ins_ids, torch.int32), T(w.pose), T(w.twist), T(w.s), T(dz[0]), T(dz[1]), T(dz[2])]
+        o = [torch.zeros((ni, 6), dtype=torch.float64, device=dev), torch.zeros((ni, 6), dtype=torch.float64, device=dev),
+             torch.zeros((ni, nd, 6), dtype=torch.float64, device=dev), torch.zeros((ni, nd, 6), dtype=torch.float64, device=dev),
+             torch.zeros((ni, 4), dtype=torch.int32, device=dev)]
+        st = torch.cuda.current_stream().cuda_stream
+        def dual_dev():
+            for _ in range(40):
+                m.eval_dual_device(ni, nd, *[x.data_ptr() for x in t], *[x.data_ptr() for x in o], st)
+                if m.check() == 0:
+                    return
+        for _ in range(5):
+            dual_dev()
+        t0 = time.perf_counter()
+        for _ in range(n // 2):
+            dual_dev()
+        print(f"{'':45s} {(time.perf_counter() - t0) / (n // 2) * 1e6:9.1f} us/Dual eval (6 partials), device-resident buffers")
+    except ImportError:
+        pass
     m.close()

@@ -197,3 +197,77 @@ def test_dual_one_graph_path_with_copied_seeds(pfc):
         else:   # linear in the seeds: doubling d_pose (with the same d_twist) changes the partials, not the values
             assert np.abs(got[2] - ref[2]).max() > 1e-6 * np.abs(ref[2]).max()
     m.close()
+
+
+def test_dual_device_resident_entry_point(pfc):
+    """pfc_eval_dual_device + pfc_check (buffers in HBM, caller's stream, one synchronisation) against the host-buffer
+    call; the first call of a handle has no pair count to size the kept Dual polygons from and may ask for a re-issue."""
+    import torch
+    rng = np.random.default_rng(23)
+    w = pfc.configs.c3_blob_tool(40, n_div_blob=8, n_div_tool=6)
+    n, nd = w.n_items, 6
+    d_pose = rng.standard_normal((n, nd, 24)) * 1e-2
+    d_twist = rng.standard_normal((n, nd, 6)) * 0.1
+    d_s = rng.standard_normal((n, nd, 6)) * 1e-3
+    f = pfc.configs.build_scenario(w)
+    ref = f.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, d_pose, d_twist, d_s, w.ins_ids)
+    f.close()
+    dev = torch.device("cuda", 0)
+    T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    t_ins, t_pose, t_tw, t_s = T(w.ins_ids, torch.int32), T(w.pose), T(w.twist), T(w.s)
+    t_dp, t_dt, t_ds = T(d_pose), T(d_twist), T(d_s)
+    o_w, o_sd = torch.zeros((n, 6), dtype=torch.float64, device=dev), torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    o_dw, o_dsd = torch.zeros((n, nd, 6), dtype=torch.float64, device=dev), torch.zeros((n, nd, 6), dtype=torch.float64, device=dev)
+    o_ct = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    m = pfc.configs.build_scenario(w)
+    stream = torch.cuda.current_stream().cuda_stream
+    attempts = []
+    for rep in range(3):
+        for k in range(40):
+            m.eval_dual_device(n, nd, t_ins.data_ptr(), t_pose.data_ptr(), t_tw.data_ptr(), t_s.data_ptr(), t_dp.data_ptr(),
+                               t_dt.data_ptr(), t_ds.data_ptr(), o_w.data_ptr(), o_sd.data_ptr(), o_dw.data_ptr(), o_dsd.data_ptr(),
+                               o_ct.data_ptr(), stream)
+            if m.check() == 0:
+                break
+        attempts.append(k + 1)
+        assert np.array_equal(o_ct.cpu().numpy(), ref[4])
+        for got, want, tol in ((o_w, ref[0], 1e-11), (o_sd, ref[1], 1e-7), (o_dw, ref[2], 1e-9), (o_dsd, ref[3], 1e-6)):
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=tol, atol=tol * max(np.abs(want).max(), 1e-300))
+    assert attempts[-1] == 1, attempts          # settled: no re-issue once the pair count is known
+    # d_ds = NULL means zeros
+    m.eval_dual_device(n, nd, t_ins.data_ptr(), t_pose.data_ptr(), t_tw.data_ptr(), t_s.data_ptr(), t_dp.data_ptr(),
+                       t_dt.data_ptr(), 0, o_w.data_ptr(), o_sd.data_ptr(), o_dw.data_ptr(), o_dsd.data_ptr(), 0, stream)
+    assert m.check() == 0
+    f = pfc.configs.build_scenario(w)
+    ref0 = f.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, d_pose, d_twist, None, w.ins_ids)
+    f.close()
+    np.testing.assert_allclose(o_dsd.cpu().numpy(), ref0[3], rtol=1e-6, atol=1e-6 * np.abs(ref0[3]).max())
+    m.close()
+
+
+def test_dual_large_batch_one_sync_equals_two_stage(pfc):
+    """Above the small-scene limits pfc_eval_dual goes through pfc_eval_dual_device (one synchronisation per attempt);
+    the former two-stage path (PFC_DUAL_TWO_STAGE=1: value pass, host reads the pair count, Dual passes) is the reference."""
+    import os
+    rng = np.random.default_rng(29)
+    w = pfc.configs.c3_blob_tool(700, n_div_blob=6, n_div_tool=5)
+    n, nd = w.n_items, 6
+    d_pose = rng.standard_normal((n, nd, 24)) * 1e-2
+    d_twist = rng.standard_normal((n, nd, 6)) * 0.1
+    d_s = rng.standard_normal((n, nd, 6)) * 1e-3
+    outs = []
+    for two_stage in (True, False):
+        if two_stage:
+            os.environ["PFC_DUAL_TWO_STAGE"] = "1"
+        else:
+            os.environ.pop("PFC_DUAL_TWO_STAGE", None)
+        m = pfc.configs.build_scenario(w)
+        for _ in range(2):
+            out = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, d_pose, d_twist, d_s, w.ins_ids)
+        outs.append(out)
+        m.close()
+    os.environ.pop("PFC_DUAL_TWO_STAGE", None)
+    a, b = outs
+    assert np.array_equal(a[4], b[4])
+    for x, y, tol in ((a[0], b[0], 1e-11), (a[1], b[1], 1e-7), (a[2], b[2], 1e-9), (a[3], b[3], 1e-6)):
+        np.testing.assert_allclose(y, x, rtol=tol, atol=tol * max(np.abs(x).max(), 1e-300))
