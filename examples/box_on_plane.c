@@ -102,6 +102,20 @@ int main(int argc, char **argv) {
         clock_gettime(CLOCK_MONOTONIC, &t1);
         printf("%d evaluations: %.1f us per pfc_eval\n", n_rep,
                ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 1e3 / (n_rep > 0 ? n_rep : 1));
+        /* the same scene on Dual numbers with 6 seed directions (what one chunk of Radau's Jacobian costs, src/radau/
+         * radau_functions.jl:2-14): unit seeds on the translation and on the twist */
+        enum { ND = 6 };
+        double d_pose[ND * 24] = {0}, d_twist[ND * 6] = {0}, d_wrench[ND * 6], d_sdot[ND * 6];
+        for (int d = 0; d < 3; ++d) { d_pose[d * 24 + 9 + d] = 1.0; d_pose[d * 24 + 21 + d] = -1.0; d_twist[(3 + d) * 6 + d] = 1.0; }
+        for (int k = 0; k < 20; ++k)
+            CHECK(pfc_eval_dual(h, 1, ND, NULL, pose, twist, NULL, d_pose, d_twist, NULL, wrench, sdot, d_wrench, d_sdot, counts));
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int k = 0; k < n_rep; ++k)
+            CHECK(pfc_eval_dual(h, 1, ND, NULL, pose, twist, NULL, d_pose, d_twist, NULL, wrench, sdot, d_wrench, d_sdot, counts));
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        printf("%d evaluations: %.1f us per pfc_eval_dual (6 directions); d f_z / d z = %.6e (analytic %.6e)\n", n_rep,
+               ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 1e3 / (n_rep > 0 ? n_rep : 1), d_wrench[2 * 6 + 5],
+               Ebar * 4 * r * r);
     }
     pfc_destroy(h);
     return sqrt(err / nrm) < 1.0e-8 ? 0 : 1;

@@ -123,9 +123,12 @@ constexpr int kDpFields = 64;
 
 // fan quadrature of one Dual polygon (integrate_over_polygon_patch!, non_friction.jl:217-265) with the pass-specific
 // integrand: MODE 0 normal wrench + regularized friction + cop sums, 1 patch stiffness about the cop, 2 bristle force
+// [k0, k1): the fan triangles (v_{k-1}, v_k, centroid) this lane integrates: all of them (0, n) with one lane per
+// polygon; one of them when the fused small-scene kernel deals the triangles out one per thread.
 template <int MODE, class VF>
 __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, const double *er, const ItemRec *it,
-                                       const double *dt, bool reg, Du3 cop, Du3 Da, Du3 Dl, Du *sum, int &n_trac) {
+                                       const double *dt, bool reg, Du3 cop, Du3 Da, Du3 Dl, Du *sum, int &n_trac,
+                                       int k0, int k1) {
     const double er0 = er[0], er1 = er[1], er2 = er[2], er3 = er[3];
     const Du3 w = dmk(du(it->w[0], dt[0]), du(it->w[1], dt[1]), du(it->w[2], dt[2]));
     const Du3 vl = dmk(du(it->v[0], dt[3]), du(it->v[1], dt[4]), du(it->v[2], dt[5]));
@@ -135,8 +138,8 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
     const int nq = it->nq;
     Du kW = du(0.0), km[3] = {du(0.0), du(0.0), du(0.0)};   // MODE 1 accumulators
     Du kQ[6] = {du(0.0), du(0.0), du(0.0), du(0.0), du(0.0), du(0.0)};
-    Du3 v2 = vert(n - 1);
-    for (int k = 0; k < n; ++k) {
+    Du3 v2 = vert(k0 == 0 ? n - 1 : k0 - 1);
+    for (int k = k0; k < k1; ++k) {
         const Du3 v1 = v2;
         v2 = vert(k);
         const Du area = dtriangle_area(v1, v2, cen, nh);
@@ -526,7 +529,7 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
             const double er[4] = {tp->epsr[0], tp->epsr[1], tp->epsr[2], tp->epsr[3]};
             Du3 cop = dmk(du(0.0), du(0.0), du(0.0)), Da = cop, Dl = cop;
             dual_integrate<0>([&](int k) { return PVT(k); }, n, nh, cen, er, it, g.d_twist + (size_t)key * 6, reg, cop, Da,
-                              Dl, sum, n_trac_lane);
+                              Dl, sum, n_trac_lane, 0, n);
             cen_keep = cen;
 #undef PVT
         }
@@ -611,7 +614,7 @@ __global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
                     const double *q = o + (size_t)(16 + 6 * k) * P;
                     return dmk(du(q[0], q[3 * P]), du(q[P], q[4 * P]), du(q[2 * P], q[5 * P]));
                 },
-                n, nh, cen, er, it, g.d_twist + (size_t)key * 6, false, cop, Da, Dl, sum, n_trac);
+                n, nh, cen, er, it, g.d_twist + (size_t)key * 6, false, cop, Da, Dl, sum, n_trac, 0, n);
         }
         double flat[2 * NS];
 #pragma unroll

@@ -29,6 +29,9 @@ constexpr int kFuNodes = 256;      // node heads per tree cached in LDS (2 x 16 
 constexpr int kFuFull = (kFuNodes * 4) / 9;   // ... or the whole tree (144-byte NodeRec) if it has at most this many nodes
 constexpr int kFuStack = 2560;     // node pairs (20 KiB), as k_bp_dfs32
 constexpr unsigned kStFusedOvf = 512u;   // item does not fit the fused kernel's LDS lists: use the batched path
+constexpr unsigned kStFusedDualSkip = 1024u;   // too many (polygon, direction) pairs for the in-kernel Dual passes: batched Dual path
+constexpr int kFuDualLanes = 128;        // (polygon, direction) lanes per Dual clip round: value + partial ring = 512 B per lane
+constexpr int kFuDualMax = 512;          // (polygon, direction) pairs an item may have for the in-kernel Dual passes
 
 // Everything an item needs from its instruction, in one 256-byte record (built at pfc_finalize): one load instead of
 // the chain InsDev -> MeshDev x 2 of the batched path.
@@ -53,6 +56,10 @@ struct FuArgs {
     int *counts;             // may be null
     int *fout;               // per item 8 ints: status, counts[4], seq (written LAST, behind a system-scope fence), 0, 0
     int seq;                 // evaluation sequence number (never 0): the host may poll fout[8 i + 5] instead of synchronising
+    // Dual evaluation (pfc_eval_dual of a small all-regularized scene): n_dir > 0
+    int n_dir;
+    const double *d_pose, *d_twist;     // (item, dir) x 24 / x 6 partials of the inputs
+    double *d_wrench, *d_sdot;          // OUT (item, dir) x 6
     unsigned long long *stamps;   // diagnostic builds (-DPFC_STAMPS): block 0 leaves wall-clock stamps (10 ns ticks) of its phases
 };
 
@@ -135,6 +142,10 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     __shared__ double s_acc[kAccStride], s_res[kResStride];
     __shared__ EigScratch E;
     __shared__ double s_aR12[9];
+    __shared__ int s_plist[kFuCand];            // candidates that gave a polygon (Dual passes)
+    __shared__ int s_npoly;
+    __shared__ double s_dacc[16][6];            // per direction: partials of the wrench
+    __shared__ ItemRec s_it;                    // what dual_integrate reads of an item
     double *ring = S.ring;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int item = blockIdx.x;
@@ -159,6 +170,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         if (tid >= 96 && tid < 102) I.twist[tid - 96] = g.twist[6 * (size_t)item + (tid - 96)];
         if (tid >= 128 && tid < 134) I.s[tid - 128] = g.s ? g.s[6 * (size_t)item + (tid - 128)] : 0.0;
     }
+    if (tid == 0) s_npoly = 0;
     __syncthreads();
     const bool reg = I.ins.model == PFC_REGULARIZED;
     const int nq = (I.ins.nq == 1) ? 1 : 3;
@@ -533,7 +545,10 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                         FX(tid, 3) = cen.x; FX(tid, 4) = cen.y; FX(tid, 5) = cen.z;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) s_epsr[k][tid] = er[k];
-                        if (pass == 0) ++my_ne;
+                        if (pass == 0) {
+                            ++my_ne;
+                            if (g.n_dir > 0) s_plist[atomicAdd(&s_npoly, 1)] = ci;
+                        }
                     }
                 }
                 s_np[tid] = n_poly >= 3 ? n_poly : 0;
@@ -714,6 +729,217 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         }
     }
 
+    // ==== 4b. the evaluation on Dual numbers (regularized items; values above, one partial per direction here) =========
+    // What calcXd! does on MechanismScenario.dual (src/mechanism_scenario.jl:187) for Radau's Jacobian, for the polygons
+    // found above: lane = (polygon, direction) clips in (value, partial) arithmetic -- every branch on values, the value
+    // half of every operation the instruction sequence of the value pass, as in k_narrow_dual -- then the fan triangles are
+    // dealt out one per thread and the partial sums of each direction meet in LDS.
+    if (g.n_dir > 0) {
+        const int n_dir = g.n_dir;
+        __syncthreads();
+        const int n_pd = s_npoly * n_dir;
+        if (tid < 16 * 6) (&s_dacc[0][0])[tid] = 0.0;
+        if (!reg || n_pd > kFuDualMax) {
+            if (contact) status |= kStFusedDualSkip;      // uniform: the host takes the batched Dual path
+        } else if (contact) {
+            if (tid == 0) {
+                s_it.w[0] = I.twist[0]; s_it.w[1] = I.twist[1]; s_it.w[2] = I.twist[2];
+                s_it.v[0] = I.twist[3]; s_it.v[1] = I.twist[4]; s_it.v[2] = I.twist[5];
+                s_it.chi = I.ins.chi; s_it.Ebar = I.ins.Ebar; s_it.mu_s = I.ins.mu_s; s_it.mu_d = I.ins.mu_d; s_it.v_c = I.ins.v_c;
+                s_it.tau = I.ins.tau; s_it.k_bar = I.ins.k_bar; s_it.magic = I.ins.magic; s_it.nq = nq; s_it.model = I.ins.model;
+            }
+            double *dv = S.ring, *dd = S.ring + 8 * 4 * kFuDualLanes;     // value ring, partial ring: [slot][coord][lane]
+#define DV(l, rb, k, c) dv[(((((rb) + (k)) & 7) * 4 + (c)) * kFuDualLanes) + (l)]
+#define DD(l, rb, k, c) dd[(((((rb) + (k)) & 7) * 4 + (c)) * kFuDualLanes) + (l)]
+#define DXV(l, s) dv[((((s) * 4) + 3) * kFuDualLanes) + (l)]
+#define DXD(l, s) dd[((((s) * 4) + 3) * kFuDualLanes) + (l)]
+            for (int base = 0; base < n_pd; base += kFuDualLanes) {
+                __syncthreads();           // rings and fan list of the previous round are free
+                int n_poly = 0, rbase = 0;
+                const int wq = base + tid;
+                const bool lane_on = tid < kFuDualLanes && wq < n_pd;
+                int dir = 0;
+                if (lane_on) {
+                    const int q = wq / n_dir;
+                    dir = wq - q * n_dir;
+                    const int2 cw = cand[s_plist[q]];
+                    const GTetRec *tp = (const GTetRec *)(I.ins.tet + cw.y);
+                    const GTriRec *tr = (const GTriRec *)(I.ins.tri + cw.x);
+                    const double *dp = g.d_pose + ((size_t)item * n_dir + dir) * 24;
+                    Du R21[9], t21[3];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) R21[k] = du(I.pose[k], dp[k]);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t21[k] = du(I.pose[9 + k], dp[9 + k]);
+                    double Z[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
+                    // tri-tet op (non_friction.jl:196-215) on Duals, as k_narrow_dual
+                    Du X[16], z[3][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
+                        X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + du(Z[i + 12]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            z[k][i] = ((X[i] * tr->v[3 * k] + X[i + 4] * tr->v[3 * k + 1]) + X[i + 8] * tr->v[3 * k + 2]) + X[i + 12];
+                    const Du3 nh_in = dmk((R21[0] * tr->n[0] + R21[3] * tr->n[1]) + R21[6] * tr->n[2],
+                                          (R21[1] * tr->n[0] + R21[4] * tr->n[1]) + R21[7] * tr->n[2],
+                                          (R21[2] * tr->n[0] + R21[5] * tr->n[1]) + R21[8] * tr->n[2]);
+                    // clip_in_tet_coordinates (static_clip.jl:7-23,34-201): the value pass kept this candidate, so it is finite
+                    // and not trivially rejected
+                    int n = 3;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { DV(tid, rbase, k, i) = z[k][i].v; DD(tid, rbase, k, i) = z[k][i].d; }
+                    for (int i = 0; i < 4 && n > 0; ++i) {
+                        unsigned nonpos = 0, nonneg = 0;
+                        for (int k = 0; k < n; ++k) {
+                            const double sv = DV(tid, rbase, k, i);
+                            nonpos |= (unsigned)(sv <= 0.0) << k;
+                            nonneg |= (unsigned)(0.0 <= sv) << k;
+                        }
+                        const unsigned full = (1u << n) - 1u;
+                        if (nonpos == full) { n = 0; break; }
+                        if (nonneg == full) continue;
+                        const unsigned nxt = ((nonpos >> 1) | ((nonpos & 1u) << (n - 1))) & full;
+                        const unsigned cand_start = nonpos & ~nxt & full;
+                        if (cand_start == 0) { n = 0; break; }   // the value pass has reported it
+                        const int st = __builtin_ctz(cand_start);
+                        int m = n;
+                        while (m > 3) {
+                            int k2 = st + m - 2; if (k2 >= n) k2 -= n;
+                            if ((nonpos >> k2) & 1u) --m; else break;
+                        }
+                        int k1 = st + 1; if (k1 >= n) k1 -= n;
+                        int kl = st + m - 1; if (kl >= n) kl -= n;
+                        int kp = st + m - 2; if (kp >= n) kp -= n;
+                        const bool inside = (m <= 5) ? (((nonpos >> kl) & 1u) == 0) : (((nonneg >> kl) & 1u) != 0);
+                        Du zs[4], ze[4];
+                        {
+                            const Du w1 = du(DV(tid, rbase, st, i), DD(tid, rbase, st, i)), w2 = du(DV(tid, rbase, k1, i), DD(tid, rbase, k1, i));
+                            const Du sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                zs[c] = c1 * du(DV(tid, rbase, k1, c), DD(tid, rbase, k1, c)) - c2 * du(DV(tid, rbase, st, c), DD(tid, rbase, st, c));
+                        }
+                        {
+                            const int kn = inside ? st : kl, kq = inside ? kl : kp;
+                            const Du w1 = du(DV(tid, rbase, kn, i), DD(tid, rbase, kn, i)), w2 = du(DV(tid, rbase, kq, i), DD(tid, rbase, kq, i));
+                            const Du sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                ze[c] = c1 * du(DV(tid, rbase, kq, c), DD(tid, rbase, kq, c)) - c2 * du(DV(tid, rbase, kn, c), DD(tid, rbase, kn, c));
+                        }
+                        const int ncopy = inside ? (m - 1) : (m - 2);
+                        for (int qq = n - st - 1; qq < ncopy; ++qq) {
+                            const int src = st + 1 + qq - n, dst = st + 1 + qq;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const double tv = DV(tid, rbase, src, c), td = DD(tid, rbase, src, c);
+                                DV(tid, rbase, dst, c) = tv; DD(tid, rbase, dst, c) = td;
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            DV(tid, rbase, st, c) = zs[c].v; DD(tid, rbase, st, c) = zs[c].d;
+                            DV(tid, rbase, st + ncopy + 1, c) = ze[c].v; DD(tid, rbase, st + ncopy + 1, c) = ze[c].d;
+                        }
+                        rbase = (rbase + st) & 7;
+                        n = ncopy + 2;
+                        if (m == 7) break;
+                    }
+                    n_poly = n >= 3 ? n : 0;
+                    if (n_poly) {
+                        // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2), centroid(poly_r2, n̂2) on Duals
+                        double V[12];
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
+                        for (int k = 0; k < n; ++k) {
+                            const Du z0 = du(DV(tid, rbase, k, 0), DD(tid, rbase, k, 0)), z1 = du(DV(tid, rbase, k, 1), DD(tid, rbase, k, 1)),
+                                     z2 = du(DV(tid, rbase, k, 2), DD(tid, rbase, k, 2)), z3 = du(DV(tid, rbase, k, 3), DD(tid, rbase, k, 3));
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const Du rr = ((V[c] * z0 + V[c + 3] * z1) + V[c + 6] * z2) + V[c + 9] * z3;
+                                DV(tid, rbase, k, c) = rr.v; DD(tid, rbase, k, c) = rr.d;
+                            }
+                        }
+#define DVT(k) dmk(du(DV(tid, rbase, k, 0), DD(tid, rbase, k, 0)), du(DV(tid, rbase, k, 1), DD(tid, rbase, k, 1)), du(DV(tid, rbase, k, 2), DD(tid, rbase, k, 2)))
+                        const Du3 a = DVT(0);
+                        Du3 cc = DVT(1);
+                        Du cum_sum = du(0.0);
+                        Du3 cum_prod = dmk(du(0.0), du(0.0), du(0.0));
+                        for (int k = 2; k < n; ++k) {
+                            const Du3 b = cc;
+                            cc = DVT(k);
+                            const Du ar = dtriangle_area(a, b, cc, nh_in);
+                            cum_prod = cum_prod + (((a + b) + cc) * (1.0 / 3.0)) * ar;
+                            cum_sum += ar;
+                        }
+#undef DVT
+                        const Du3 cen = (cum_sum.v == 0.0) ? a : cum_prod / cum_sum;
+                        DXV(tid, 0) = nh_in.x.v; DXV(tid, 1) = nh_in.y.v; DXV(tid, 2) = nh_in.z.v;
+                        DXD(tid, 0) = nh_in.x.d; DXD(tid, 1) = nh_in.y.d; DXD(tid, 2) = nh_in.z.d;
+                        DXV(tid, 3) = cen.x.v; DXV(tid, 4) = cen.y.v; DXV(tid, 5) = cen.z.v;
+                        DXD(tid, 3) = cen.x.d; DXD(tid, 4) = cen.y.d; DXD(tid, 5) = cen.z.d;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) s_epsr[k][tid] = tp->epsr[k];
+                    }
+                }
+                s_np[tid] = n_poly | (dir << 8);
+                s_rb[tid] = rbase;
+                // deal the fan triangles of the round's Dual polygons out, one per thread
+                const int incl = seg_incl_scan(n_poly);
+                if (lane == 63) s_scan[wave] = incl;
+                __syncthreads();
+                int off = incl - n_poly;
+                for (int wv = 0; wv < kFuWaves; ++wv) if (wv < wave) off += s_scan[wv];
+                for (int k = 0; k < n_poly; ++k) fan[off + k] = (unsigned)tid | ((unsigned)k << 16);
+                __syncthreads();
+                const int n_fan = ((s_scan[0] + s_scan[1]) + s_scan[2]) + s_scan[3];
+                for (int wi = tid; wi < n_fan; wi += kFuBlock) {
+                    const unsigned fe = fan[wi];
+                    const int pt = (int)(fe & 0xFFFFu), k = (int)(fe >> 16);
+                    const int n = s_np[pt] & 0xFF, d = s_np[pt] >> 8, rb = s_rb[pt];
+                    const Du3 nh = dmk(du(DXV(pt, 0), DXD(pt, 0)), du(DXV(pt, 1), DXD(pt, 1)), du(DXV(pt, 2), DXD(pt, 2)));
+                    const Du3 cen = dmk(du(DXV(pt, 3), DXD(pt, 3)), du(DXV(pt, 4), DXD(pt, 4)), du(DXV(pt, 5), DXD(pt, 5)));
+                    const double er[4] = {s_epsr[0][pt], s_epsr[1][pt], s_epsr[2][pt], s_epsr[3][pt]};
+                    Du sum[10];
+#pragma unroll
+                    for (int kk = 0; kk < 10; ++kk) sum[kk] = du(0.0);
+                    int nt = 0;
+                    const Du3 zero3 = dmk(du(0.0), du(0.0), du(0.0));
+                    dual_integrate<0>(
+                        [&](int kk) {
+                            return dmk(du(DV(pt, rb, kk, 0), DD(pt, rb, kk, 0)), du(DV(pt, rb, kk, 1), DD(pt, rb, kk, 1)),
+                                       du(DV(pt, rb, kk, 2), DD(pt, rb, kk, 2)));
+                        },
+                        n, nh, cen, er, &s_it, g.d_twist + ((size_t)item * n_dir + d) * 6, true, zero3, zero3, zero3, sum, nt, k, k + 1);
+                    if (nt > 0) {
+#pragma unroll
+                        for (int kk = 0; kk < 6; ++kk) unsafeAtomicAdd(&s_dacc[d][kk], sum[kk].d);
+                    }
+                }
+            }
+#undef DV
+#undef DD
+#undef DXV
+#undef DXD
+        }
+        __syncthreads();
+        // partials of the outputs: regularized items have no bristle state (sdot = 0)
+        if (tid < n_dir * 6) {
+            const int d = tid / 6, k = tid - d * 6;
+            g.d_wrench[((size_t)item * n_dir + d) * 6 + k] = s_dacc[d][k];
+            g.d_sdot[((size_t)item * n_dir + d) * 6 + k] = 0.0;
+        }
+    }
     FSTAMP(6);
     // ==== 5. yes_contact! / no_contact! epilogue (friction.jl:76-81,119-143; non_friction.jl:77-83) ====================
     // status: every thread may have set bits

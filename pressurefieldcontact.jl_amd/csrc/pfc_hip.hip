@@ -262,6 +262,10 @@ struct pfc_context {
     int opt_fused = 1;                 // option "fused"
     int fused_skip = 0;                // evaluations left for which the fused kernel stays off after an item did not fit
     int fused_seq = 0;                 // sequence number of the last fused launch (completion word of the polled path)
+    int dual_fused_skip = 0;           // Dual evaluations left for which the in-kernel Dual passes stay off (an item had too many polygons)
+    const double *fu_dpose = nullptr, *fu_dtwist = nullptr;    // set by eval_dual_fused around enqueue_fused
+    double *fu_dwrench = nullptr, *fu_dsdot = nullptr;
+    int fu_ndir = 0;
     bool pending_fused = false, last_fused = false;
     int opt_split_min = 1024;          // 0: never split
     int opt_poison = 0;                // diagnostic: fill (re)allocated work lists with 0xFF bytes (item index -1)
@@ -658,6 +662,7 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
     }
     if (++h->fused_seq == 0) h->fused_seq = 1;
     a.seq = h->fused_seq;
+    a.n_dir = h->fu_ndir; a.d_pose = h->fu_dpose; a.d_twist = h->fu_dtwist; a.d_wrench = h->fu_dwrench; a.d_sdot = h->fu_dsdot;
     a.stamps = nullptr;
 #ifdef PFC_STAMPS
     HIP_TRY(h, h->stamps.ensure(16));
@@ -708,6 +713,10 @@ int check_fused(pfc_context *h) {
     if (status & kStFusedOvf) {
         h->fused_skip = 64;     // the batched path takes over (and the re-issue), the fused kernel is tried again later
         return fail(h, PFC_ERR_OVERFLOW, "an item has more candidate pairs than the small-scene kernel holds: re-issue (batched path)");
+    }
+    if (status & kStFusedDualSkip) {
+        h->dual_fused_skip = 64;
+        return fail(h, PFC_ERR_OVERFLOW, "an item has more (polygon, direction) pairs than the small-scene kernel's Dual passes hold: re-issue (batched Dual path)");
     }
     return PFC_OK;
 }
@@ -1254,6 +1263,52 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     return PFC_OK;
 }
 
+// Smallest scenes, all instructions regularized (test/boxes.jl and the like): value AND Dual passes inside the fused
+// small-scene kernel -- one launch, results polled from pinned memory.  Returns PFC_ERR_OVERFLOW when an item does not fit
+// (too many candidates / polygons): the caller takes the batched Dual path and this one stays off for a while.
+int eval_dual_fused(pfc_context *h, int n_items, int n_dir, const int *ins_ids, const double *pose, const double *twist,
+                    const double *s, const double *d_pose, const double *d_twist, double *wrench, double *sdot,
+                    double *d_wrench, double *d_sdot, int *counts) {
+    const size_t n = (size_t)n_items, nk = n * n_dir;
+    const size_t in_d = n * 36, in_bytes = in_d * sizeof(double) + n * sizeof(int);
+    const size_t out_d = n * 12, out_bytes = out_d * sizeof(double) + n * 4 * sizeof(int) + n * 8 * sizeof(int);
+    HIP_TRY(h, ensure_pinned(&h->pin_in, &h->pin_in_cap, in_bytes));
+    HIP_TRY(h, ensure_pinned(&h->pin_out, &h->pin_out_cap, out_bytes + 64));
+    HIP_TRY(h, ensure_pinned(&h->pin_din, &h->pin_din_cap, sizeof(double) * nk * 30));
+    HIP_TRY(h, ensure_pinned(&h->pin_dout, &h->pin_dout_cap, sizeof(double) * nk * 12));
+    double *pi = (double *)h->pin_in;
+    std::memcpy(pi, pose, sizeof(double) * n * 24);
+    std::memcpy(pi + n * 24, twist, sizeof(double) * n * 6);
+    if (s) std::memcpy(pi + n * 30, s, sizeof(double) * n * 6); else std::memset(pi + n * 30, 0, sizeof(double) * n * 6);
+    if (ins_ids) std::memcpy(pi + in_d, ins_ids, sizeof(int) * n);
+    double *pdi = (double *)h->pin_din;
+    std::memcpy(pdi, d_pose, sizeof(double) * nk * 24);
+    std::memcpy(pdi + nk * 24, d_twist, sizeof(double) * nk * 6);
+    void *v_in = nullptr, *v_out = nullptr, *v_din = nullptr, *v_dout = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer(&v_in, h->pin_in, 0));
+    HIP_TRY(h, hipHostGetDevicePointer(&v_out, h->pin_out, 0));
+    HIP_TRY(h, hipHostGetDevicePointer(&v_din, h->pin_din, 0));
+    HIP_TRY(h, hipHostGetDevicePointer(&v_dout, h->pin_dout, 0));
+    double *di = (double *)v_in, *dout = (double *)v_out, *ddi = (double *)v_din, *ddo = (double *)v_dout;
+    h->fout_dev = reinterpret_cast<int *>(dout + out_d) + n * 4;
+    h->fout_host = reinterpret_cast<const int *>((const double *)h->pin_out + out_d) + n * 4;
+    h->fu_ndir = n_dir; h->fu_dpose = ddi; h->fu_dtwist = ddi + nk * 24; h->fu_dwrench = ddo; h->fu_dsdot = ddo + nk * 6;
+    int rc = enqueue_fused(h, n_items, ins_ids ? (const int *)(di + in_d) : nullptr, di, di + n * 24, s ? di + n * 30 : nullptr,
+                           dout, dout + n * 6, reinterpret_cast<int *>(dout + out_d), h->stream);
+    h->fu_ndir = 0; h->fu_dpose = h->fu_dtwist = nullptr; h->fu_dwrench = h->fu_dsdot = nullptr;
+    h->fout_dev = nullptr;
+    if (rc == PFC_OK) rc = check_eval(h);
+    h->fout_host = nullptr;
+    if (rc != PFC_OK) return rc;
+    const double *po = (const double *)h->pin_out;
+    std::memcpy(wrench, po, sizeof(double) * n * 6);
+    std::memcpy(sdot, po + n * 6, sizeof(double) * n * 6);
+    if (counts) std::memcpy(counts, po + out_d, sizeof(int) * n * 4);
+    std::memcpy(d_wrench, h->pin_dout, sizeof(double) * nk * 6);
+    std::memcpy(d_sdot, (const double *)h->pin_dout + nk * 6, sizeof(double) * nk * 6);
+    return PFC_OK;
+}
+
 // Small scenes (what Radau evaluates): value pass and Dual passes enqueued back to back, ONE synchronisation, no
 // staging copies (the kernels read and write the pinned blocks), the kept Dual polygons sized from the previous Dual
 // evaluation's pair count.  Returns PFC_ERR_OVERFLOW when the speculation or a work list fell short: the caller then
@@ -1415,6 +1470,16 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
         return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: null buffer");
     // the same argument checks in front of BOTH paths (the one-graph path used to skip them)
     { const int rc = check_eval_args(h, n_items, ins_ids, pose, twist, s, wrench, sdot); if (rc != PFC_OK) return rc; }
+    if (n_items > 0 && !h->any_bristle && fused_ok(h, n_items)) {
+        if (h->dual_fused_skip > 0) {
+            --h->dual_fused_skip;
+        } else {
+            HIP_TRY(h, hipSetDevice(h->device));
+            const int rc_f = eval_dual_fused(h, n_items, n_dir, ins_ids, pose, twist, s, d_pose, d_twist, wrench, sdot, d_wrench,
+                                             d_sdot, counts);
+            if (rc_f != PFC_ERR_OVERFLOW) return rc_f;       // else: an item did not fit -> the batched Dual paths below
+        }
+    }
     if (h->finalized && n_items > 0 && n_items <= 512 && (size_t)n_items * n_dir <= 4096 && h->dual_hint >= 0 && pose && twist &&
         wrench && sdot && !h->opt_debug && !(h->opt_split_min > 0 && n_items >= h->opt_split_min)) {
         HIP_TRY(h, hipSetDevice(h->device));

@@ -152,3 +152,61 @@ def test_fused_errors_and_device_buffers(pfc):
     with pytest.raises(L.PFCError):
         m.debug_stiffness(0)
     m.close()
+
+
+@pytest.mark.parametrize("n_dir", [1, 6, 7, 16])
+def test_fused_dual_regularized(pfc, O, n_dir):
+    """Value AND Dual passes inside the fused kernel (all-regularized small scenes: what Radau's Jacobian evaluations of
+    test/boxes.jl-like scenes go through) against the Dual oracle and against the batched Dual path (option fused = 0)."""
+    from helpers import oracle_ins, oracle_meshes
+    from test_oracle_dual import tangents
+    rng = np.random.default_rng(40 + n_dir)
+    for w in (pfc.configs.c1_boxes(), pfc.configs.c2_box_on_plane(6, montecarlo=True, n_div=3)):
+        n = w.n_items
+        dq = rng.standard_normal((n, n_dir, 6)) * np.array([1, 1, 1, 0.05, 0.05, 0.05])
+        d_twist = rng.standard_normal((n, n_dir, 6)) * np.array([1, 1, 1, 0.1, 0.1, 0.1])
+        d_pose = np.zeros((n, n_dir, 24))
+        for k in range(n):
+            d_pose[k] = tangents(w.pose[k][:9].reshape(3, 3, order="F"), w.pose[k][9:12], dq[k])
+        res = []
+        for fused in (1, 0):
+            m = pfc.configs.build_scenario(w)
+            m.set_option("fused", fused)
+            for _ in range(2):
+                out = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, d_pose, d_twist, None, w.ins_ids)
+            res.append((out, m.last_parts()))
+            m.close()
+        (a, pa), (b, pb) = res
+        assert pb != 0
+        if n_dir <= 7:
+            assert pa == 0, pa                                  # the fused kernel really ran the first variant
+        assert np.array_equal(a[4], b[4])
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-11, atol=1e-11 * np.abs(b[0]).max())
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-9, atol=1e-9 * np.abs(b[2]).max())
+        assert np.all(a[3] == 0.0) and np.all(a[1] == 0.0)
+        om = oracle_meshes(w)
+        for k in range(n):
+            c = w.instructions[int(w.ins_ids[k])]
+            st, rw, rs, rdw, rdsd = O.evaluate_dual(om[c.id_1], om[c.id_2], oracle_ins(pfc, c), w.pose[k], w.twist[k], w.s[k],
+                                                    d_pose[k], d_twist[k], np.zeros((n_dir, 6)))
+            assert st == 0
+            sw = max(np.abs(rdw).max(), 1e-300)
+            assert np.abs(a[2][k] - rdw).max() <= 1e-6 * sw, (k, np.abs(a[2][k] - rdw).max() / sw)
+
+
+def test_fused_dual_falls_back_when_an_item_has_too_many_polygons(pfc):
+    w = pfc.configs.c2_box_on_plane(3, montecarlo=True)          # ~220 polygons x 6 directions per item: past the in-kernel limit
+    n, nd = w.n_items, 6
+    rng = np.random.default_rng(3)
+    d_pose = rng.standard_normal((n, nd, 24)) * 1e-2
+    d_twist = rng.standard_normal((n, nd, 6)) * 0.1
+    m = pfc.configs.build_scenario(w)
+    out = [m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, d_pose, d_twist, None, w.ins_ids) for _ in range(3)]
+    m.close()
+    f = pfc.configs.build_scenario(w)
+    f.set_option("fused", 0)
+    ref = f.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, d_pose, d_twist, None, w.ins_ids)
+    f.close()
+    for o in out:
+        assert np.array_equal(o[4], ref[4])
+        np.testing.assert_allclose(o[2], ref[2], rtol=1e-9, atol=1e-9 * np.abs(ref[2]).max())
