@@ -345,6 +345,11 @@ def main():
                     issue_ms = per_unit * r["units_per_launch"] * cyc / (N_SIMD * CLOCK_HZ) * 1e3
                     r["valu"] = {"wave_instructions_per_unit": per_unit, "issue_bound_ms": issue_ms,
                                  "frac_of_issue_peak": issue_ms / r["ms_per_launch"],
+                                 # SQ_ACTIVE_INST_ANY (quad-cycles, summed over waves) over the SIMD-cycles of a launch: how busy
+                                 # the issue ports are with ALL instruction types (VALU, SALU, LDS, VMEM) of this kernel's waves
+                                 "issue_utilisation": (vj[key.replace("valu_insts", "active_inst_any_cycles")] / parts_n * 4.0 /
+                                                       (N_SIMD * CLOCK_HZ * r["ms_per_launch"] * 1e-3))
+                                 if key.replace("valu_insts", "active_inst_any_cycles") in vj else None,
                                  "note": f"{what}-precision wave64 VALU instruction = {cyc:.0f} cycles on a SIMD-32; 1024 SIMDs, "
                                          f"2.4 GHz; instruction counts from profiles/pmc_valu.json ({vj.get('measured', 'see file')})"}
                 roof_bp["achieved"] = roof_bp["valu"]["wave_instructions_per_unit"] * roof_bp["units_per_launch"] / (bp_ms * 1e-3)

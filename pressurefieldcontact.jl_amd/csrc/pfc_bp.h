@@ -212,6 +212,35 @@ __device__ __forceinline__ NodeF load_nodef(const NodeF *n) {
     return u.f;
 }
 
+// Error radius E of the single-precision test (why 16 u and 192 u; u = 2^-24, round to nearest, |fl(x op y) - (x op y)|
+// <= u |x op y|; S = |v|_1 + sum e_a + sum e_b is formed from the SAME rounded inputs the axes use).
+// The reference evaluates, per axis L, d_ref = |T.L| - (r_a + r_b) in Float64 with abs_R = |R| + 1e-14
+// (src/obb/bb_intersection.jl:10,29-72); its own roundings (~1e-16 S) and the 1e-14 (<= 2e-7 u per unit of extent) are
+// far below one u S and are covered by the slack left below.
+//   Inputs.  v_i = fl32(Float64 centre offset): |dv_i| <= u |v_i|.  e = fl32(extent): relative u.  R_a_b -> Float32:
+//   absolute u per entry (|entry| <= 1).
+//   (a) both boxes axis aligned (identity quaternions; every internal x internal pair): quat_to_R returns I exactly, the
+//       two 3x3 products reproduce R_a_b(float) and v exactly, so R has absolute error <= u per entry and t = v.
+//       Face axis of A:  |t_i| - (e_a,i + sum_j |R_ij| e_b,j): input errors u |t_i| + u e_a,i + (u + u) sum e_b (entry of R,
+//       extent), three fused roundings <= 3 u sum e_b, the sum and the final difference <= 2 u S: below 8 u S.
+//       Face axis of B:  symmetric, with the three-term dot product R(:,j).t: (u + u + 3 u) |t|_1 + ...: below 8 u S.
+//       Edge-edge axes: each of the six products carries two input errors and one rounding (3 u), two of them meet in one
+//       fused operation (+ u), sum and difference (+ 2 u): below 7 u S.
+//       E = 16 u S therefore holds with a factor of two to spare.
+//   (b) a tight-fitted (leaf) box is involved: R_a, R_b come from Float32 unit quaternions.  pfc_add_mesh checks IN FLOAT64
+//       that the stored quaternion reproduces R to 4 u per entry (else exact_only: the pair is never decided here);
+//       quat_to_R adds <= 4 roundings per entry: |dR_a|, |dR_b| <= 8 u.
+//       T = R_a' R_a_b: three terms, each (8 u + u) from its factors, + 3 u of rounding: |dT| <= 30 u.
+//       R = T R_b: sum_k (|dT_ik| |R_b,kj| + |T_ik| |dR_b,kj|) <= (30 u + 8 u) sqrt 3 (rows / columns of a rotation have
+//       1-norm <= sqrt 3) + 3 u of rounding: |dR| <= 69 u < 72 u.
+//       t = R_a' v: (8 u + u) |v|_1 + 3 u |v|_1: |dt_i| <= 12 u |v|_1, and |t|_1 <= sqrt 3 |v|_1.
+//       Worst axis (edge-edge): |t_u R_vj - t_v R_uj| picks up 72 u |t|_1 <= 125 u |v|_1 from dR and 2 x 12 u |v|_1 from
+//       dt; r_a + r_b picks up 72 u (sum e_a + sum e_b) from dR and u from the extents; roundings as in (a) <= 8 u S.
+//       Total below (125 + 24 + 8) u |v|_1 + (72 + 1 + 8) u sum e  <=  157 u S  <  192 u S = E.
+// Hence |d_float - d_ref| < E on every axis: d_float > E proves the reference separates on that axis, d_float < -E on all
+// 15 axes proves it does not separate on any; everything else is settled by the exact Float64 test.  The constants in the
+// code are 9.6e-7 (>= 16 u = 9.54e-7) and 1.15e-5 (>= 192 u = 1.144e-5).  tests/test_gpu_broadphase.py probes touching
+// configurations at 1 -/+ {1e-3, 1e-6, 1e-9, 1e-12} against the oracle for both box kinds.
 // one node pair of k_bp_dfs32: returns 0 = separated, 1 = overlapping, 2 = undecided
 __device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, bool any_leaf, const double *R12,
                                              const float *R12f, const double *t12) {

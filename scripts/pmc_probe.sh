@@ -7,7 +7,7 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 k=0
 for grp in "$@"; do
-  rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/${TAG}_g$k -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 > $R/gpurun_out/${TAG}_g$k.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/${TAG}_g$k -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extras --no-validate --reps 1 > $R/gpurun_out/${TAG}_g$k.log 2>&1
   k=$((k+1))
 done
 echo done
