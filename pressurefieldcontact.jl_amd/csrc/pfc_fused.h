@@ -292,8 +292,9 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             bool hit = false;
             int a0 = 0, a1 = 0, b0 = 0, b1 = 0, la_id = 0, lb_id = 0;
             const bool la = act && e.x < 0, lb = act && e.y < 0;
+            NodeU ua, ub;
+            bool both_aabb = true;
             if (act) {
-                NodeU ua, ub;
                 FU_FETCH(ua, B.na, full1, nc1, I.ins.nodes1, node_index(e.x), la);
                 FU_FETCH(ub, B.nb, full2, nc2, I.ins.nodes2, node_index(e.y), lb);
                 const NodeRec &a = ua.r, &b = ub.r;
@@ -302,12 +303,20 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                 { double keep = a.c[0] + b.c[0] + a.R[4] + b.R[4]; asm volatile("" ::"v"(keep)); }   // the loads have landed
                 STAMP(u1);
 #endif
+                both_aabb = a.aabb && b.aabb;
+            }
+            // The form of the test is chosen per wave, never per lane (a lane-level branch would make a mixed wave run
+            // both): the axis-aligned shortcut only if every active lane holds two merged boxes; the general composition
+            // is exact for identity rotations too.
+            const bool wave_aabb = __all(!act || both_aabb);
+            if (act) {
+                const NodeRec &a = ua.r, &b = ub.r;
                 double R12[9], t12[3];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) R12[k] = s_pose[k];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
-                if (a.aabb && b.aabb) {
+                if (wave_aabb) {
                     double aR12[9];
 #pragma unroll
                     for (int k = 0; k < 9; ++k) aR12[k] = s_aR12[k];
@@ -388,7 +397,66 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     // pass 0: normal wrench (+ regularized friction fused) + cop sums; bristle: pass 1 patch stiffness about the cop,
     // pass 2 friction.  With more than one round of candidates the polygons of earlier rounds are gone from the ring and
     // are clipped again in the later passes.
-    const int n_round = (n_cand + kFuBlock - 1) / kFuBlock;
+    // Items with more than one round of candidates first run ONLY the cheap front of the op on all of them (gather,
+    // x_ζ²_r¹, tet coordinates, the bit-exact trivial reject: the expressions of the clip round below, hence the same
+    // decisions) and compact the survivors in place at the front of the LDS list, so that the expensive clip rounds see
+    // no trivially rejected candidate (C2: 463 candidates -> 254 survivors: one clip round instead of two).
+    int n_list = n_cand;
+    if (n_cand > kFuBlock) {
+        int n_keep = 0;
+        for (int base = 0; base < n_cand; base += kFuBlock) {
+            const int ci = base + tid;
+            bool surv = false;
+            int2 cw = make_int2(0, 0);
+            if (ci < n_cand) {
+                cw = cand[ci];
+                const GTetRec *tp = (const GTetRec *)(I.ins.tet + cw.y);
+                const GTriRec *tr = (const GTriRec *)(I.ins.tri + cw.x);
+                double Z[16], tv[9], R21[9], t21[3], X[16], z[3][4];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) tv[k] = tr->v[k];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) R21[k] = I.pose[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) t21[k] = I.pose[9 + k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
+                    X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + Z[i + 12];
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        z[k][i] = ((X[i] * tv[3 * k] + X[i + 4] * tv[3 * k + 1]) + X[i + 8] * tv[3 * k + 2]) + X[i + 12];
+                bool finite = true;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) finite &= (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
+                if (!finite) status |= kStNonFinite;
+                bool reject = !finite;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0);
+                surv = !reject;
+            }
+            const unsigned long long ms = __ballot(surv);
+            if (lane == 0) s_cnt[wave][0] = __builtin_popcountll(ms);
+            __syncthreads();                 // every entry of this round has been read: the front of the list may be overwritten
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int wv = 0; wv < kFuWaves; ++wv) { const int c = s_cnt[wv][0]; if (wv < wave) off += c; tot += c; }
+            if (surv) cand[n_keep + off + prefix_count(ms)] = cw;     // n_keep + off + ... <= ci: never an entry still to be read
+            n_keep += tot;
+            __syncthreads();
+        }
+        n_list = n_keep;
+    }
+    const int n_round = (n_list + kFuBlock - 1) / kFuBlock;
     int n_nonempty = 0, n_trac = 0;
     double tot10[10];
 #pragma unroll
@@ -410,7 +478,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                 __syncthreads();               // ring / fan of the previous round are free
                 const int ci = rd * kFuBlock + tid;
                 int n_poly = 0, rbase = 0;
-                if (ci < n_cand) {
+                if (ci < n_list) {
                     const int2 cw = cand[ci];
                     const GTetRec *tp = (const GTetRec *)(I.ins.tet + cw.y);
                     const GTriRec *tr = (const GTriRec *)(I.ins.tri + cw.x);
