@@ -130,6 +130,7 @@ union FuScratch {
 // after the conversion to Cartesian coordinates the fourth coordinate of every slot is free: slots 0..5 hold n̂, centroid
 #define FX(t, s) ring[((((s) * 4) + 3) * kFuBlock) + (t)]
 
+template <bool TT>     // TT: the scenario has tet-tet instructions (as k_narrow<TT>)
 __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     __shared__ FuScratch S;
     __shared__ int2 cand[kFuCand];
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     // decisions) and compact the survivors in place at the front of the LDS list, so that the expensive clip rounds see
     // no trivially rejected candidate (C2: 463 candidates -> 254 survivors: one clip round instead of two).
     int n_list = n_cand;
-    if (n_cand > kFuBlock) {
+    if (n_cand > kFuBlock && (!TT || I.ins.tet1 == nullptr)) {      // (tet-tet: the reject comes after the plane / tet polygon)
         int n_keep = 0;
         for (int base = 0; base < n_cand; base += kFuBlock) {
             const int ci = base + tid;
@@ -485,10 +486,16 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                     double Z[16], tv[9], tn[3], V[12], er[4];
 #pragma unroll
                     for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
+                    if (!TT || I.ins.tet1 == nullptr) {
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) tv[k] = tr->v[k];
+                        for (int k = 0; k < 9; ++k) tv[k] = tr->v[k];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) tn[k] = tr->n[k];
+                        for (int k = 0; k < 3; ++k) tn[k] = tr->n[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) tv[k] = 0.0;
+                        tn[0] = tn[1] = tn[2] = 0.0;
+                    }
 #pragma unroll
                     for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
 #pragma unroll
@@ -498,40 +505,139 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                     for (int k = 0; k < 9; ++k) R21[k] = I.pose[k];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) t21[k] = I.pose[9 + k];
-                    // ---- tri-tet op (non_friction.jl:196-215): x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (:204) ----------------
-                    double X[16], z[3][4];
+                    double z[4][4];
+                    int n_in = 3;
+                    V3 nh_in = mk3(0.0, 0.0, 0.0);
+                    if (!TT || I.ins.tet1 == nullptr) {
+                        // ---- tri-tet op (non_friction.jl:196-215): x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (:204) ------------
+                        double X[16];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                        for (int j = 0; j < 3; ++j)
-                            X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
-                        X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + Z[i + 12];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            z[k][i] = ((X[i] * tv[3 * k] + X[i + 4] * tv[3 * k + 1]) + X[i + 8] * tv[3 * k + 2]) + X[i + 12];
-                    const V3 nh_in = mk3((R21[0] * tn[0] + R21[3] * tn[1]) + R21[6] * tn[2],
-                                         (R21[1] * tn[0] + R21[4] * tn[1]) + R21[7] * tn[2],
-                                         (R21[2] * tn[0] + R21[5] * tn[1]) + R21[8] * tn[2]);
-                    bool finite = true;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) finite &= (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
-                    if (!finite) status |= kStNonFinite;
-                    // trivial reject (bit-exact shortcut of static_clip.jl:44, see k_narrow)
-                    bool reject = !finite;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0);
-                    if (!reject) {
-                        // ---- clip_in_tet_coordinates (static_clip.jl:7-23,34-201), in place in the LDS ring ----------
-                        int n = 3;
+                            for (int j = 0; j < 3; ++j)
+                                X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
+                            X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + Z[i + 12];
+                        }
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) FR(tid, rbase, k, i) = z[k][i];
+                            for (int i = 0; i < 4; ++i)
+                                z[k][i] = ((X[i] * tv[3 * k] + X[i + 4] * tv[3 * k + 1]) + X[i + 8] * tv[3 * k + 2]) + X[i + 12];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) z[3][i] = 0.0;
+                        nh_in = mk3((R21[0] * tn[0] + R21[3] * tn[1]) + R21[6] * tn[2],
+                                    (R21[1] * tn[0] + R21[4] * tn[1]) + R21[7] * tn[2],
+                                    (R21[2] * tn[0] + R21[5] * tn[1]) + R21[8] * tn[2]);
+                    } else {
+                    // ---- tet-tet op (non_friction.jl:166-194) -----------------------------------------------------------
+                    const GTetRec *t1 = (const GTetRec *)(I.ins.tet1 + cw.x);
+                    double plane[4];
+                    {
+                        // ϵ_plane_r2 = (Ē2 ϵ2) x_ζ2_r2 - (Ē1 ϵ1) (x_ζ1_r1 x_r1_r2)   (find_plane_tet :164, :174-177)
+                        double R12[9], t12[3], Z1[16], X1[16];
+    #pragma unroll
+                        for (int k = 0; k < 9; ++k) R12[k] = I.pose[12 + k];
+    #pragma unroll
+                        for (int k = 0; k < 3; ++k) t12[k] = I.pose[21 + k];
+    #pragma unroll
+                        for (int k = 0; k < 16; ++k) Z1[k] = t1->xzr[k];
+    #pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+    #pragma unroll
+                            for (int j = 0; j < 3; ++j)
+                                X1[i + 4 * j] = (Z1[i] * R12[3 * j] + Z1[i + 4] * R12[3 * j + 1]) + Z1[i + 8] * R12[3 * j + 2];
+                            X1[i + 12] = ((Z1[i] * t12[0] + Z1[i + 4] * t12[1]) + Z1[i + 8] * t12[2]) + Z1[i + 12];
+                        }
+                        double Ee1[4], Ee2[4];
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            Ee1[j] = I.ins.Ebar1 * ((const gdouble *)I.ins.eps1)[4 * (size_t)cw.x + j];
+                            Ee2[j] = I.ins.Ebar * ((const gdouble *)I.ins.eps2)[4 * (size_t)cw.y + j];
+                        }
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const double p1 = ((Ee1[0] * X1[4 * j] + Ee1[1] * X1[4 * j + 1]) + Ee1[2] * X1[4 * j + 2]) + Ee1[3] * X1[4 * j + 3];
+                            const double p2 = ((Ee2[0] * Z[4 * j] + Ee2[1] * Z[4 * j + 1]) + Ee2[2] * Z[4 * j + 2]) + Ee2[3] * Z[4 * j + 3];
+                            plane[j] = p2 - p1;
+                        }
+                    }
+                    // x_r2_ζ1 = x_r2_r1.mat * x_r1_ζ1: the vertices of tet 1 in frame r2 (:180); proj = plane * tet (:19)
+                    V3 P[4];
+                    double proj[4];
+                    int n_neg = 0, n_pos = 0;
+                    unsigned posm = 0, negm = 0;
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double vx = t1->xrz[3 * j], vy = t1->xrz[3 * j + 1], vz = t1->xrz[3 * j + 2];
+                        P[j] = mk3(((R21[0] * vx + R21[3] * vy) + R21[6] * vz) + t21[0],
+                                   ((R21[1] * vx + R21[4] * vy) + R21[7] * vz) + t21[1],
+                                   ((R21[2] * vx + R21[5] * vy) + R21[8] * vz) + t21[2]);
+                        proj[j] = ((plane[0] * P[j].x + plane[1] * P[j].y) + plane[2] * P[j].z) + plane[3];
+                        if (proj[j] < 0.0) { ++n_neg; negm |= 1u << j; }
+                        if (0.0 < proj[j]) { ++n_pos; posm |= 1u << j; }
+                    }
+                    // clip_plane_tet (plane_tet_intersection.jl:9-106).  weightPoly(v[i1], v[i2], proj[i1], proj[i2]) does
+                    // not depend on the order of (i1, i2) bit for bit, so one edge function serves every case.
+                    V3 q[4];
+                    q[0] = q[1] = q[2] = q[3] = mk3(0.0, 0.0, 0.0);
+                    int n_q = 0;
+    #define PW_(i1, i2) (P[i2] * (proj[i1] / (proj[i1] - proj[i2])) - P[i1] * (proj[i2] / (proj[i1] - proj[i2])))
+                    if (n_pos != 0 && n_neg != 0) {
+                        int lone = -1;
+                        if (n_pos == 1) lone = __builtin_ctz(posm);
+                        else if (n_neg == 1) lone = __builtin_ctz(negm);
+                        if (lone >= 0) {
+                            V3 a, b, c;   // :52-79
+                            if (lone == 0) { a = PW_(1, 0); b = PW_(3, 0); c = PW_(2, 0); }
+                            else if (lone == 1) { a = PW_(0, 1); b = PW_(2, 1); c = PW_(3, 1); }
+                            else if (lone == 2) { a = PW_(0, 2); b = PW_(3, 2); c = PW_(1, 2); }
+                            else { a = PW_(0, 3); b = PW_(1, 3); c = PW_(2, 3); }
+                            double pl = (lone == 0) ? proj[0] : (lone == 1) ? proj[1] : (lone == 2) ? proj[2] : proj[3];
+                            n_q = 3;
+                            if (0.0 < pl) { q[0] = a; q[1] = b; q[2] = c; } else { q[0] = c; q[1] = b; q[2] = a; }
+                        } else {
+                            V3 a, b, c, d;   // :81-106
+                            const bool p0 = (posm & 1u) != 0, p1 = (posm & 2u) != 0, p2 = (posm & 4u) != 0;
+                            if (p0 == p1) { a = PW_(1, 2); b = PW_(1, 3); c = PW_(0, 3); d = PW_(0, 2); }
+                            else if (p0 == p2) { a = PW_(0, 1); b = PW_(0, 3); c = PW_(2, 3); d = PW_(2, 1); }
+                            else { a = PW_(0, 2); b = PW_(0, 1); c = PW_(3, 1); d = PW_(3, 2); }
+                            n_q = 4;
+                            if (0.0 < proj[0]) { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+                            else { q[0] = d; q[1] = c; q[2] = b; q[3] = a; }
+                        }
+                    }
+    #undef PW_
+                    // poly_ζ2 = one_pad_then_mul(x_ζ2_r2, poly_r2), then zero_small_coordinates (:184-187)
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k)
+    #pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const double v = ((Z[i] * q[k].x + Z[i + 4] * q[k].y) + Z[i + 8] * q[k].z) + Z[i + 12];
+                            z[k][i] = v * ((1.0e-14 < __builtin_fabs(v)) ? 1.0 : 0.0);
+                        }
+                    n_in = n_q;
+                    nh_in = normalize(mk3(plane[0], plane[1], plane[2]));   // :190
+                    }
+                    bool finite = true;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) finite &= (k >= n_in) || (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
+                    if (!finite) status |= kStNonFinite;
+                    // trivial reject (bit-exact shortcut of static_clip.jl:44, see k_narrow)
+                    bool reject = !finite || n_in < 3;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0) && (n_in < 4 || z[3][i] <= 0.0);
+                    if (!reject) {
+                        // ---- clip_in_tet_coordinates (static_clip.jl:7-23,34-201), in place in the LDS ring ----------
+                        int n = n_in;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k < n_in) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) FR(tid, rbase, k, i) = z[k][i];
+                            }
                         bool err = false;
                         for (int i = 0; i < 4 && n > 0; ++i) {
                             unsigned nonpos = 0, nonneg = 0;
@@ -807,7 +913,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         __syncthreads();
         const int n_pd = s_npoly * n_dir;
         if (tid < 16 * 6) (&s_dacc[0][0])[tid] = 0.0;
-        if (!reg || n_pd > kFuDualMax) {
+        if (!reg || n_pd > kFuDualMax || (TT && I.ins.tet1 != nullptr)) {
             if (contact) status |= kStFusedDualSkip;      // uniform: the host takes the batched Dual path
         } else if (contact) {
             if (tid == 0) {

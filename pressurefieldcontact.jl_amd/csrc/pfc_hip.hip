@@ -641,7 +641,7 @@ constexpr int kFusedMaxItems = 256;      // one workgroup (one CU) per item
 constexpr int kFusedMaxLeaves = 6144;    // n_leaf(mesh_1) + n_leaf(mesh_2): above this one workgroup's descent is the slower one
 
 bool fused_ok(const pfc_context *h, int n_items) {
-    return h->opt_fused && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv && !h->any_tet_tet &&
+    return h->opt_fused && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv &&
            !h->is_twin && h->d_insfull && n_items <= kFusedMaxItems && h->max_leaves <= kFusedMaxLeaves;
 }
 
@@ -668,7 +668,9 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
     HIP_TRY(h, h->stamps.ensure(16));
     a.stamps = h->stamps.p;
 #endif
-    hipLaunchKernelGGL(k_fused, dim3(n_items), dim3(kFuBlock), 0, st, a);   // a direct launch: cheaper than a graph replay
+    // a direct launch: cheaper than a graph replay
+    if (h->any_tet_tet) hipLaunchKernelGGL((k_fused<true>), dim3(n_items), dim3(kFuBlock), 0, st, a);
+    else hipLaunchKernelGGL((k_fused<false>), dim3(n_items), dim3(kFuBlock), 0, st, a);
     HIP_TRY(h, hipGetLastError());
     h->last_n_items = n_items; h->pending = true; h->pending_fused = true; h->last_stream = st; h->ev_valid = false;
     h->last_bfs_levels = 0; h->split_n0 = 0;
