@@ -60,6 +60,13 @@ struct FuArgs {
     int n_dir;
     const double *d_pose, *d_twist;     // (item, dir) x 24 / x 6 partials of the inputs
     double *d_wrench, *d_sdot;          // OUT (item, dir) x 6
+    // Hand-over to the batched Dual passes (k_narrow_dual ...) for scenes the in-kernel Dual passes do not take (bristle
+    // items, many polygons): the item record, the per-item counters and the list of candidates that gave a polygon, in
+    // the formats of the batched value pass.  emit_ctr[0] (zero on entry) ends as the number of listed pairs.
+    ItemRec *emit_items;
+    WorkRec *emit_cand;
+    int *emit_surv, *emit_icnt, *emit_ctr;
+    int emit_cap;
     unsigned long long *stamps;   // diagnostic builds (-DPFC_STAMPS): block 0 leaves wall-clock stamps (10 ns ticks) of its phases
 };
 
@@ -721,7 +728,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                         for (int k = 0; k < 4; ++k) s_epsr[k][tid] = er[k];
                         if (pass == 0) {
                             ++my_ne;
-                            if (g.n_dir > 0) s_plist[atomicAdd(&s_npoly, 1)] = ci;
+                            if (g.n_dir > 0 || g.emit_items) s_plist[atomicAdd(&s_npoly, 1)] = ci;
                         }
                     }
                 }
@@ -903,6 +910,46 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         }
     }
 
+    // ==== 4a. hand-over to the batched Dual passes ======================================================================
+    if (g.emit_items) {
+        __shared__ int s_cbase;
+        __syncthreads();
+        const int n_pl = s_npoly;
+        if (tid == 0) {
+            ItemRec &r = s_it;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { r.R21[k] = I.pose[k]; r.R12[k] = I.pose[12 + k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { r.t21[k] = I.pose[9 + k]; r.t12[k] = I.pose[21 + k]; r.w[k] = I.twist[k]; r.v[k] = I.twist[3 + k]; }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) r.s[k] = (I.ins.model == PFC_BRISTLE) ? I.s[k] : 0.0;
+            r.chi = I.ins.chi; r.Ebar = I.ins.Ebar; r.mu_s = I.ins.mu_s; r.mu_d = I.ins.mu_d; r.v_c = I.ins.v_c; r.tau = I.ins.tau;
+            r.k_bar = I.ins.k_bar; r.magic = I.ins.magic; r.nodes1 = I.ins.nodes1; r.nodes2 = I.ins.nodes2; r.nf1 = I.ins.nf1;
+            r.nf2 = I.ins.nf2; r.tri = I.ins.tri; r.tet = I.ins.tet; r.tet1 = I.ins.tet1; r.eps1 = I.ins.eps1; r.eps2 = I.ins.eps2;
+            r.Ebar1 = I.ins.Ebar1; r.model = I.ins.model; r.nq = nq; r.ins = id; r.pad = 0;
+            s_cbase = n_pl ? atomicAdd(g.emit_ctr, n_pl) : 0;
+        }
+        __syncthreads();
+        constexpr int nw = (int)(sizeof(ItemRec) / sizeof(int));
+        for (int k = tid; k < nw; k += kFuBlock)
+            reinterpret_cast<int *>(g.emit_items + item)[k] = reinterpret_cast<const int *>(&s_it)[k];
+        const int cbase = s_cbase;
+        if (cbase + n_pl > g.emit_cap) {
+            status |= kStCandOvf;          // uniform: the host re-issues on the batched path
+        } else {
+            for (int j = tid; j < n_pl; j += kFuBlock) {
+                const int2 cw = cand[s_plist[j]];
+                WorkRec c;
+                c.item = item; c.a = cw.x; c.b = cw.y; c.pad = 0;
+                g.emit_cand[cbase + j] = c;
+                g.emit_surv[cbase + j] = cbase + j;
+            }
+        }
+        if (tid == 0) {
+            int *ic = g.emit_icnt + 4 * (size_t)item;
+            ic[0] = n_test; ic[1] = n_cand; ic[2] = n_nonempty; ic[3] = n_trac;
+        }
+    }
     // ==== 4b. the evaluation on Dual numbers (regularized items; values above, one partial per direction here) =========
     // What calcXd! does on MechanismScenario.dual (src/mechanism_scenario.jl:187) for Radau's Jacobian, for the polygons
     // found above: lane = (polygon, direction) clips in (value, partial) arithmetic -- every branch on values, the value

@@ -262,6 +262,9 @@ struct pfc_context {
     int opt_fused = 1;                 // option "fused"
     int fused_skip = 0;                // evaluations left for which the fused kernel stays off after an item did not fit
     int fused_seq = 0;                 // sequence number of the last fused launch (completion word of the polled path)
+    DevBuf<int> emit_ctr;              // pair counter of the fused kernel's hand-over to the batched Dual passes
+    int *h_emit = nullptr;             // pinned mirror
+    bool fu_emit = false;              // set by eval_dual_hybrid around enqueue_fused
     int dual_fused_skip = 0;           // Dual evaluations left for which the in-kernel Dual passes stay off (an item had too many polygons)
     const double *fu_dpose = nullptr, *fu_dtwist = nullptr;    // set by eval_dual_fused around enqueue_fused
     double *fu_dwrench = nullptr, *fu_dsdot = nullptr;
@@ -663,6 +666,11 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
     if (++h->fused_seq == 0) h->fused_seq = 1;
     a.seq = h->fused_seq;
     a.n_dir = h->fu_ndir; a.d_pose = h->fu_dpose; a.d_twist = h->fu_dtwist; a.d_wrench = h->fu_dwrench; a.d_sdot = h->fu_dsdot;
+    a.emit_items = nullptr; a.emit_cand = nullptr; a.emit_surv = nullptr; a.emit_icnt = nullptr; a.emit_ctr = nullptr; a.emit_cap = 0;
+    if (h->fu_emit) {
+        a.emit_items = h->items.p; a.emit_cand = h->cand.p; a.emit_surv = h->surv.p; a.emit_icnt = h->icnt.p;
+        a.emit_ctr = h->emit_ctr.p; a.emit_cap = (int)h->ccap;
+    }
     a.stamps = nullptr;
 #ifdef PFC_STAMPS
     HIP_TRY(h, h->stamps.ensure(16));
@@ -691,13 +699,17 @@ int check_fused(pfc_context *h) {
         const volatile int *vf = fo;
         const int seq = h->fused_seq;
         bool done = false;
-        for (int spin = 0; spin < 200000 && !done; ++spin) {
+        static const bool no_poll = std::getenv("PFC_FUSED_SYNC") != nullptr;     // A/B knob: synchronise instead of polling
+        for (int spin = 0; spin < 200000 && !done && !no_poll; ++spin) {
             done = true;
             for (int i = n - 1; i >= 0; --i)
                 if (vf[8 * i + 5] != seq) { done = false; break; }
         }
         if (done) std::atomic_thread_fence(std::memory_order_acquire);
-        else HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+        else {
+            if (std::getenv("PFC_LOG_POLL")) std::fprintf(stderr, "pfc: completion poll timed out, synchronising\n");
+            HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+        }
     }
     h->pending = false; h->pending_fused = false; h->last_parts = 1; h->last_fused = true;
     unsigned status = 0;
@@ -805,6 +817,8 @@ void pfc_destroy(pfc_handle h) {
     if (h->d_ins) (void)hipFree(h->d_ins);
     if (h->d_insfull) (void)hipFree(h->d_insfull);
     if (h->h_fout) (void)hipHostFree(h->h_fout);
+    if (h->h_emit) (void)hipHostFree(h->h_emit);
+    h->emit_ctr.release();
     h->fout.release();
     h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
     h->clip_n.release(); h->icnt.release(); h->trac_item.release(); h->acc.release(); h->res.release();
@@ -1231,7 +1245,7 @@ namespace {
 // the kept Dual polygons (the kernels take the actual count from the tail and guard against the capacity).
 int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const double *dp, const double *dt,
                 const double *dsd, double *dw, double *dsdot, size_t n_pairs_bound, hipStream_t st, size_t *dpcap_out,
-                bool acc_cleared = false) {
+                bool acc_cleared = false, const int *pair_count = nullptr) {
     const size_t nk = (size_t)n_items * n_dir;
     HIP_TRY(h, ensure_dual(h, h->dual_acc, nk * kDaStride));
     HIP_TRY(h, ensure_dual(h, h->dual_res, nk * kDrStride));
@@ -1239,6 +1253,7 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     DualArgs a;
     a.items = h->items.p; a.cand = h->cand.p; a.ccount = tail + 12; a.ccap = (int)h->ccap;   // packed copy of the counters
     a.surv = h->surv.p; a.scount = tail + 12 + (((h->last_levels + 9) & ~1) + 1);
+    if (pair_count) a.ccount = a.scount = pair_count;       // hand-over from the fused small-scene kernel: one list, one count
     a.n_items = n_items; a.n_dir = n_dir; a.d_pose = dp; a.d_twist = dt; a.d_s = dsd; a.icnt = h->icnt.p;
     a.dacc = h->dual_acc.p; a.dres = h->dual_res.p; a.d_wrench = dw; a.d_sdot = dsdot;
     a.status = h->status.p;
@@ -1302,6 +1317,87 @@ int eval_dual_fused(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     if (rc == PFC_OK) rc = check_eval(h);
     h->fout_host = nullptr;
     if (rc != PFC_OK) return rc;
+    const double *po = (const double *)h->pin_out;
+    std::memcpy(wrench, po, sizeof(double) * n * 6);
+    std::memcpy(sdot, po + n * 6, sizeof(double) * n * 6);
+    if (counts) std::memcpy(counts, po + out_d, sizeof(int) * n * 4);
+    std::memcpy(d_wrench, h->pin_dout, sizeof(double) * nk * 6);
+    std::memcpy(d_sdot, (const double *)h->pin_dout + nk * 6, sizeof(double) * nk * 6);
+    return PFC_OK;
+}
+
+// Small scenes the in-kernel Dual passes do not take (bristle items, many polygons per item): the fused kernel evaluates
+// the values and hands the item records, counters and the list of candidates with a polygon to the batched Dual passes
+// (k_narrow_dual ..., many workgroups), enqueued right behind it; one synchronisation.  Returns PFC_ERR_OVERFLOW when an
+// item does not fit the fused kernel or the speculative size of the kept Dual polygons fell short (the caller then takes
+// the batched paths).
+int eval_dual_hybrid(pfc_context *h, int n_items, int n_dir, const int *ins_ids, const double *pose, const double *twist,
+                     const double *s, const double *d_pose, const double *d_twist, const double *d_s, double *wrench,
+                     double *sdot, double *d_wrench, double *d_sdot, int *counts) {
+    const size_t n = (size_t)n_items, nk = n * n_dir;
+    const size_t in_d = n * 36, in_bytes = in_d * sizeof(double) + n * sizeof(int);
+    const size_t out_d = n * 12, out_bytes = out_d * sizeof(double) + n * 4 * sizeof(int) + n * 8 * sizeof(int);
+    HIP_TRY(h, ensure_work(h, n_items));
+    HIP_TRY(h, ensure_pinned(&h->pin_in, &h->pin_in_cap, in_bytes));
+    HIP_TRY(h, ensure_pinned(&h->pin_out, &h->pin_out_cap, out_bytes + 64));
+    HIP_TRY(h, ensure_pinned(&h->pin_din, &h->pin_din_cap, sizeof(double) * nk * 36));
+    HIP_TRY(h, ensure_pinned(&h->pin_dout, &h->pin_dout_cap, sizeof(double) * nk * 12));
+    HIP_TRY(h, h->emit_ctr.ensure(4));
+    if (!h->h_emit) HIP_TRY(h, hipHostMalloc((void **)&h->h_emit, sizeof(int) * 4));
+    double *pi = (double *)h->pin_in;
+    std::memcpy(pi, pose, sizeof(double) * n * 24);
+    std::memcpy(pi + n * 24, twist, sizeof(double) * n * 6);
+    if (s) std::memcpy(pi + n * 30, s, sizeof(double) * n * 6); else std::memset(pi + n * 30, 0, sizeof(double) * n * 6);
+    if (ins_ids) std::memcpy(pi + in_d, ins_ids, sizeof(int) * n);
+    double *pdi = (double *)h->pin_din;
+    std::memcpy(pdi, d_pose, sizeof(double) * nk * 24);
+    std::memcpy(pdi + nk * 24, d_twist, sizeof(double) * nk * 6);
+    if (d_s) std::memcpy(pdi + nk * 30, d_s, sizeof(double) * nk * 6); else std::memset(pdi + nk * 30, 0, sizeof(double) * nk * 6);
+    void *v_in = nullptr, *v_out = nullptr, *v_din = nullptr, *v_dout = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer(&v_in, h->pin_in, 0));
+    HIP_TRY(h, hipHostGetDevicePointer(&v_out, h->pin_out, 0));
+    HIP_TRY(h, hipHostGetDevicePointer(&v_din, h->pin_din, 0));
+    HIP_TRY(h, hipHostGetDevicePointer(&v_dout, h->pin_dout, 0));
+    double *di = (double *)v_in, *dout = (double *)v_out;
+    hipStream_t st = h->stream;
+    // seeds / results of up to 512 (item, direction) pairs are read / written in place by the kernels, larger ones staged
+    const bool zc = nk <= 512;
+    if (!zc) {
+        HIP_TRY(h, ensure_dual(h, h->dual_in, nk * 36));
+        HIP_TRY(h, ensure_dual(h, h->dual_out, nk * 12));
+        HIP_TRY(h, hipMemcpyAsync(h->dual_in.p, h->pin_din, sizeof(double) * nk * 36, hipMemcpyHostToDevice, st));
+    }
+    double *ddi = zc ? (double *)v_din : h->dual_in.p, *ddo = zc ? (double *)v_dout : h->dual_out.p;
+    size_t bound = 64;
+    while (bound < (size_t)(h->dual_hint > 0 ? h->dual_hint : 0) * 2 + 64) bound *= 2;
+    HIP_TRY(h, ensure_dual(h, h->dual_acc, nk * kDaStride));
+    HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
+    HIP_TRY(h, hipMemsetAsync(h->emit_ctr.p, 0, sizeof(int) * 4, st));
+    h->fout_dev = reinterpret_cast<int *>(dout + out_d) + n * 4;
+    h->fout_host = nullptr;           // this path synchronises (the Dual kernels run behind the fused one)
+    h->fu_emit = true;
+    int rc = enqueue_fused(h, n_items, ins_ids ? (const int *)(di + in_d) : nullptr, di, di + n * 24, s ? di + n * 30 : nullptr,
+                           dout, dout + n * 6, reinterpret_cast<int *>(dout + out_d), st);
+    h->fu_emit = false; h->fout_dev = nullptr;
+    if (rc != PFC_OK) return rc;
+    size_t dpcap = 0;
+    h->last_levels = eff_levels(h);
+    rc = launch_dual(h, n_items, n_dir, h->tail.p, ddi, ddi + nk * 24, ddi + nk * 30, ddo, ddo + nk * 6, bound, st, &dpcap, true,
+                     h->emit_ctr.p);
+    if (rc != PFC_OK) return rc;
+    if (!zc) HIP_TRY(h, hipMemcpyAsync(h->pin_dout, ddo, sizeof(double) * nk * 12, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(h->h_emit, h->emit_ctr.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    h->fout_host = reinterpret_cast<const int *>((const double *)h->pin_out + out_d) + n * 4;
+    // check_fused would poll; here the stream is synchronised (the completion words of the fused kernel are long written)
+    HIP_TRY(h, hipStreamSynchronize(st));
+    rc = check_eval(h);
+    h->fout_host = nullptr;
+    if (rc != PFC_OK) return rc;
+    if (h->stats[6] & kStCandOvf) return fail(h, PFC_ERR_OVERFLOW, "hand-over list of the small-scene kernel overflowed: batched path");
+    const long long pairs = h->h_emit[0];
+    h->dual_hint = pairs;
+    const int cpw = 64 / n_dir;
+    if (h->any_bristle && (size_t)((pairs + cpw - 1) / cpw) * 64 + 64 > dpcap) return PFC_ERR_OVERFLOW;
     const double *po = (const double *)h->pin_out;
     std::memcpy(wrench, po, sizeof(double) * n * 6);
     std::memcpy(sdot, po + n * 6, sizeof(double) * n * 6);
@@ -1481,6 +1577,13 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
                                              d_sdot, counts);
             if (rc_f != PFC_ERR_OVERFLOW) return rc_f;       // else: an item did not fit -> the batched Dual paths below
         }
+    }
+    if (n_items > 0 && fused_ok(h, n_items) && h->dual_hint >= 0 && (size_t)n_items * n_dir <= 4096 &&
+        std::getenv("PFC_NO_HYBRID") == nullptr) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        const int rc_h = eval_dual_hybrid(h, n_items, n_dir, ins_ids, pose, twist, s, d_pose, d_twist, d_s, wrench, sdot, d_wrench,
+                                          d_sdot, counts);
+        if (rc_h != PFC_ERR_OVERFLOW) return rc_h;           // else: batched paths below (lists grown / speculation short)
     }
     if (h->finalized && n_items > 0 && n_items <= 512 && (size_t)n_items * n_dir <= 4096 && h->dual_hint >= 0 && pose && twist &&
         wrench && sdot && !h->opt_debug && !(h->opt_split_min > 0 && n_items >= h->opt_split_min)) {

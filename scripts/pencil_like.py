@@ -1,0 +1,28 @@
+"""Latency of a pencil.jl-sized bristle scene (test/pencil.jl: sphere pads of 320 tets against a < 100-triangle pencil surface,
+bristle friction): 8 instructions, value and Dual(6) evaluations through host buffers."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, pfc_pkg
+pfc = pfc_pkg.load()
+w = pfc.configs.c3_blob_tool(8, seed=3, n_div_blob=4, n_div_tool=2, distance=0.195)
+for fused in (1, 0):
+    m = pfc.configs.build_scenario(w)
+    m.set_option("fused", fused)
+    nd = 6
+    dz = (np.zeros((w.n_items, nd, 24)), np.zeros((w.n_items, nd, 6)), np.zeros((w.n_items, nd, 6)))
+    for _ in range(10):
+        m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *dz, w.ins_ids)
+    def med(f, blocks=8, per=25):        # median over blocks: a process sees one ~36 ms runtime stall early on
+        ts = []
+        for _ in range(blocks):
+            t0 = time.perf_counter()
+            for _ in range(per):
+                r = f()
+            ts.append((time.perf_counter() - t0) / per)
+        return float(np.median(ts)), r
+    tv, out = med(lambda: m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids))
+    pv = m.last_parts()
+    td, _ = med(lambda: m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *dz, w.ins_ids))
+    print(f"fused={fused}: value {tv*1e6:.1f} us (path {pv}), Dual(6) {td*1e6:.1f} us (path {m.last_parts()}); counts {out[2].sum(axis=0)}")
+    m.close()
