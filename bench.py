@@ -130,10 +130,13 @@ def small_scene_latencies(pfc, reps: int = 200):
         m = pfc.configs.build_scenario(w)
         for _ in range(10):
             m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
-        dt = (time.perf_counter() - t0) / reps
+        blocks = []
+        for _ in range(max(reps // 25, 1)):          # median over blocks of 25 calls (one-off runtime stalls)
+            t0 = time.perf_counter()
+            for _ in range(25):
+                wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+            blocks.append((time.perf_counter() - t0) / 25)
+        dt = statistics.median(blocks)
         out[name] = {"us_per_eval": dt * 1e6, "ops": int(ct[:, 1].sum()), "ops_per_s": float(ct[:, 1].sum()) / dt,
                      "path": {0: "fused", 1: "batched", 2: "batched, two halves"}[m.last_parts()]}
         m.close()
@@ -334,24 +337,43 @@ def main():
                    "unit": "wave-instructions/s", "traffic": None, "ms_per_launch": bp_ms,
                    "units_per_launch": st_prof["node_tests"] / parts_n,
                    "algorithmic_gbs_cache_served": BYTES_PER_NODE_TEST * st_prof["node_tests"] / parts_n / (bp_ms * 1e-3) / 1e9,
-                   "peak": N_SIMD * CLOCK_HZ / 2.0}
+                   "peak": N_SIMD * CLOCK_HZ / 2.4}
         pv = os.path.join(ROOT, "profiles", "pmc_valu.json")      # counters were measured on the C3 default workload
         if os.path.exists(pv) and args.config == "C3":
             try:
                 vj = json.load(open(pv))
-                for r, key, unit_key, cyc, what in ((roof_bp, "k_bp_dfs32_valu_insts", "node_tests", 2.0, "single"),
-                                                    (roof_np, "k_narrow_valu_insts", "candidates", 4.0, "double")):
-                    per_unit = vj[key] / vj[unit_key]
+                # Issue cost of a wave64 VALU instruction by type, measured on this chip at >= 2 waves per SIMD
+                # (scripts/micro/valu_rate.hip, profiles/r02_valu_rate.txt): Float32 add/mul/fma 2.4 cycles, Float64 4.2,
+                # v_pk_fma_f32 4.2, the integer add/logic/shift mix 3.4 (taken for every instruction the mix counters do not
+                # classify: moves, selects, compares, conversions).  Mix from SQ_INSTS_VALU_{ADD,MUL,FMA}_F32/F64 (pmc_valu.json).
+                CYC_F32, CYC_F64, CYC_OTHER = 2.4, 4.2, 3.4
+                for r, kname, unit_key in ((roof_bp, "k_bp_dfs32", "node_tests"), (roof_np, "k_narrow", "candidates")):
+                    key = kname + "_valu_insts"
+                    n_valu = vj[key]
+                    f32 = sum(vj.get(f"{kname}_valu_{t}_f32", 0) for t in ("add", "mul", "fma"))
+                    f64 = sum(vj.get(f"{kname}_valu_{t}_f64", 0) for t in ("add", "mul", "fma", "trans"))
+                    have_mix = (kname + "_valu_fma_f64") in vj
+                    if have_mix:
+                        cyc = (f32 * CYC_F32 + f64 * CYC_F64 + (n_valu - f32 - f64) * CYC_OTHER) / n_valu
+                    else:
+                        cyc = CYC_F32 if kname == "k_bp_dfs32" else CYC_F64
+                    per_unit = n_valu / vj[unit_key]
                     issue_ms = per_unit * r["units_per_launch"] * cyc / (N_SIMD * CLOCK_HZ) * 1e3
-                    r["valu"] = {"wave_instructions_per_unit": per_unit, "issue_bound_ms": issue_ms,
-                                 "frac_of_issue_peak": issue_ms / r["ms_per_launch"],
-                                 # SQ_ACTIVE_INST_ANY (quad-cycles, summed over waves) over the SIMD-cycles of a launch: how busy
-                                 # the issue ports are with ALL instruction types (VALU, SALU, LDS, VMEM) of this kernel's waves
-                                 "issue_utilisation": (vj[key.replace("valu_insts", "active_inst_any_cycles")] / parts_n * 4.0 /
-                                                       (N_SIMD * CLOCK_HZ * r["ms_per_launch"] * 1e-3))
-                                 if key.replace("valu_insts", "active_inst_any_cycles") in vj else None,
-                                 "note": f"{what}-precision wave64 VALU instruction = {cyc:.0f} cycles on a SIMD-32; 1024 SIMDs, "
-                                         f"2.4 GHz; instruction counts from profiles/pmc_valu.json ({vj.get('measured', 'see file')})"}
+                    aia = kname + "_active_inst_any_cycles"
+                    r["valu"] = {"wave_instructions_per_unit": per_unit, "cycles_per_instruction": cyc,
+                                 "mix": {"f32": f32 / n_valu, "f64": f64 / n_valu, "other": 1.0 - (f32 + f64) / n_valu} if have_mix else None,
+                                 "active_lanes_per_instruction": (vj[kname + "_valu_thread_cycles"] / n_valu
+                                                                  if (kname + "_valu_thread_cycles") in vj else None),
+                                 "issue_bound_ms": issue_ms, "frac_of_issue_peak": issue_ms / r["ms_per_launch"],
+                                 # SQ_ACTIVE_INST_ANY (quad-cycles, summed over WAVES) over the SIMD-cycles of a launch: the mean
+                                 # number of this kernel's waves per SIMD that have an instruction of any type (VALU, SALU, LDS,
+                                 # VMEM) in flight; it is a sum over resident waves, so it is not capped at 1
+                                 "waves_with_inst_in_flight_per_simd": (vj[aia] / parts_n * 4.0 /
+                                                                        (N_SIMD * CLOCK_HZ * r["ms_per_launch"] * 1e-3)) if aia in vj else None,
+                                 "note": "issue cost per wave64 VALU instruction weighted by the measured instruction mix (Float32 2.4, "
+                                         "Float64 4.2, other 3.4 cycles: profiles/r02_valu_rate.txt); 1024 SIMDs, 2.4 GHz; counts from "
+                                         f"profiles/pmc_valu.json ({vj.get('measured', 'see file')})"}
+                roof_bp["peak"] = N_SIMD * CLOCK_HZ / roof_bp["valu"]["cycles_per_instruction"]
                 roof_bp["achieved"] = roof_bp["valu"]["wave_instructions_per_unit"] * roof_bp["units_per_launch"] / (bp_ms * 1e-3)
                 roof_bp["frac"] = roof_bp["achieved"] / roof_bp["peak"]
             except Exception:

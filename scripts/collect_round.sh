@@ -12,7 +12,8 @@ cd $R
 timeout 300 python scripts/latency.py 2>&1 | grep -v amdgpu > $O/r02_latency.txt
 timeout 300 python scripts/crossover.py 2>&1 | grep -v amdgpu > $O/r02_crossover.txt
 gcc -O2 -I include examples/box_on_plane.c -L pressurefieldcontact.jl_amd/csrc -lpfc_hip -Wl,-rpath,$PWD/pressurefieldcontact.jl_amd/csrc -lm -o /tmp/box_on_plane && timeout 60 /tmp/box_on_plane 5000 > $O/r02_c_example.txt 2>&1
-(export PFC_LIB=$PWD/pressurefieldcontact.jl_amd/csrc/exp/stamps.so PFC_ALLOW_DIAGNOSTIC=1; for c in c1 c2 c4 c3r; do timeout 120 python scripts/small_scene.py $c 300 1; done) 2>&1 | grep -v amdgpu > $O/r02_fused_phases.txt
+(export PFC_LIB=$PWD/pressurefieldcontact.jl_amd/csrc/exp/stamps.so PFC_ALLOW_DIAGNOSTIC=1; for c in c1 c2 c4 c3r pencil; do timeout 120 python scripts/small_scene.py $c 300 1; done) 2>&1 | grep -v amdgpu > $O/r02_fused_phases.txt
 cd /tmp && export TMPDIR=/tmp
 for c in c1 c2 c4; do rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_small_$c -- python3 $R/scripts/small_scene.py $c 300 1 > $O/r02_small_$c.log 2>&1; done
+cd $R; timeout 200 python scripts/pencil_like.py 2>&1 | grep -v amdgpu > $O/r02_pencil_like.txt
 echo collected

@@ -13,11 +13,13 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
     m = pfc.configs.build_scenario(w)
     for _ in range(5):
         m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
-    n = 50
-    t0 = time.perf_counter()
-    for _ in range(n):
-        m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
-    t_gpu = (time.perf_counter() - t0) / n
+    ts = []
+    for _ in range(8):            # median over blocks (one-off runtime stalls, see scripts/latency.py)
+        t0 = time.perf_counter()
+        for _ in range(25):
+            m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        ts.append((time.perf_counter() - t0) / 25)
+    t_gpu = float(np.median(ts))
     m.close()
     # the CPU side as bench.py times it: one C call evaluating all items serially (pfo_eval_batch)
     from oracle import oracle as O

@@ -15,10 +15,19 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
     for _ in range(5):
         m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
     n = 100
-    t0 = time.perf_counter()
-    for _ in range(n):
-        wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
-    dt = (time.perf_counter() - t0) / n
+
+    def med(f, blocks=8, per=25):
+        """Median over blocks of calls: a process sees ONE ~36 ms stall some 100-150 launches in (runtime / power-state
+        housekeeping, with polling and with hipStreamSynchronize alike); a plain mean over a few hundred calls smears it."""
+        ts = []
+        for _ in range(blocks):
+            t0 = time.perf_counter()
+            for _ in range(per):
+                r = f()
+            ts.append((time.perf_counter() - t0) / per)
+        return float(np.median(ts)), r
+
+    dt, (wr, sd, ct) = med(lambda: m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids))
     st = m.stats()
     print(f"{name:45s} {dt*1e6:9.1f} us/eval   ops {st['candidates']:8d}  node tests {st['node_tests']:9d}  "
           f"-> {st['candidates']/dt:.3g} ops/s, {w.n_items/dt:.3g} contact pairs/s")
@@ -28,11 +37,10 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
     dz = (np.zeros((w.n_items, nd, 24)), np.zeros((w.n_items, nd, 6)), np.zeros((w.n_items, nd, 6)))
     for _ in range(3):
         m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *dz, w.ins_ids)
-    t0 = time.perf_counter()
-    for _ in range(n // 2):
+    def pair():
         m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *dz, w.ins_ids)
-        m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
-    dd = (time.perf_counter() - t0) / (n // 2) - dt
+        return m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    dd = med(pair, blocks=6, per=10)[0] - dt
     print(f"{'':45s} {dd*1e6:9.1f} us/Dual eval (6 partials)")
     # device-resident Dual evaluation (pfc_eval_dual_device + pfc_check): what the host-buffer figure above pays on top is
     # 288 B per (item, direction) of seeds over PCIe and the staging copies
@@ -53,10 +61,7 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
                     return
         for _ in range(5):
             dual_dev()
-        t0 = time.perf_counter()
-        for _ in range(n // 2):
-            dual_dev()
-        print(f"{'':45s} {(time.perf_counter() - t0) / (n // 2) * 1e6:9.1f} us/Dual eval (6 partials), device-resident buffers")
+        print(f"{'':45s} {med(dual_dev, blocks=6, per=10)[0] * 1e6:9.1f} us/Dual eval (6 partials), device-resident buffers")
     except ImportError:
         pass
     m.close()

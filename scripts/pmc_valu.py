@@ -1,13 +1,20 @@
 """profiles/pmc_valu.json from the counter groups of scripts/pmc_probe.sh (SQ_INSTS_VALU, wait and L2 counters) and the
-unit counts of a bench line.  usage: python scripts/pmc_valu.py <tag> <bench.json>
+unit counts of a bench line.  usage: python scripts/pmc_valu.py <tag>[,<tag2>...] <bench.json>
 Values are PER STEP: parts x the per-launch averages (a split step launches every kernel once per half)."""
 import csv, glob, json, os, re, sys, collections
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, bench = sys.argv[1], json.load(open(sys.argv[2]))
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(root, "gpurun_out", tag + "_g*", "**", "*counter_collection.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
-        vals[re.sub(r"\(.*", "", row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for tg in tag.split(","):
+    seen = set()       # a counter that several groups of one tag collected is taken from the first group only
+    for f in sorted(glob.glob(os.path.join(root, "gpurun_out", tg + "_g*", "**", "*counter_collection.csv"), recursive=True)):
+        mine = set()
+        for row in csv.DictReader(open(f)):
+            if (tg, row["Counter_Name"]) in seen:
+                continue
+            mine.add((tg, row["Counter_Name"]))
+            vals[re.sub(r"\(.*", "", row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        seen |= mine
 
 
 def steady(v):
@@ -28,7 +35,12 @@ out = {"source": "rocprofv3 --pmc (scripts/pmc_probe.sh, one counter group per p
 for kern, name in (("pfc::k_bp_dfs32", "k_bp_dfs32"), ("void pfc::k_narrow<false>", "k_narrow"), ("pfc::k_fric", "k_fric")):
     for ctr, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAIT_ANY", "wait_any_cycles"),
                      ("SQ_WAIT_INST_ANY", "wait_inst_any_cycles"), ("SQ_ACTIVE_INST_ANY", "active_inst_any_cycles"),
-                     ("SQ_INSTS_SALU", "salu_insts"), ("SQ_INSTS_LDS", "lds_insts"), ("TCC_HIT_sum", "tcc_hit"), ("TCC_MISS_sum", "tcc_miss")):
+                     ("SQ_INSTS_SALU", "salu_insts"), ("SQ_INSTS_LDS", "lds_insts"), ("TCC_HIT_sum", "tcc_hit"), ("TCC_MISS_sum", "tcc_miss"),
+                     # instruction mix (scripts/pmc_groups.sh r02x): the issue cost of a wave64 instruction depends on its type
+                     ("SQ_INSTS_VALU_ADD_F32", "valu_add_f32"), ("SQ_INSTS_VALU_MUL_F32", "valu_mul_f32"), ("SQ_INSTS_VALU_FMA_F32", "valu_fma_f32"),
+                     ("SQ_INSTS_VALU_ADD_F64", "valu_add_f64"), ("SQ_INSTS_VALU_MUL_F64", "valu_mul_f64"), ("SQ_INSTS_VALU_FMA_F64", "valu_fma_f64"),
+                     ("SQ_INSTS_VALU_TRANS_F64", "valu_trans_f64"), ("SQ_INSTS_VALU_IOPS", "valu_int"), ("SQ_INSTS_VALU_CVT", "valu_cvt"),
+                     ("SQ_THREAD_CYCLES_VALU", "valu_thread_cycles"), ("SQ_INSTS_BRANCH", "branch_insts"), ("SQ_INSTS_VMEM", "vmem_insts")):
         m = steady(vals[kern][ctr])
         if m is not None:
             out[f"{name}_{key}"] = round(parts * m)
