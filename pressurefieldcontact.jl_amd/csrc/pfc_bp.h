@@ -179,10 +179,11 @@ __device__ __forceinline__ int next_ticket(int *ctr) {
 // third of the registers and a third of the cache-line requests, and is exact in the following sense.
 //
 // For a node pair it forms v = R_a_b c_b + (t_a_b - c_a) in Float64 (the centre offset, of the order of the box
-// sizes), everything else in Float32: R_a, R_b from unit quaternions (|err| <= 8 u per entry, u = 2^-24, checked on
-// the host when the quaternion is made), T = R_a' R_a_b, t = R_a' v, R = T R_b, then the 15 axes
-// d = |T.L| - (r_a + r_b).  The error of R is below 72 u, so |d_float - d_reference| < 192 u S with
-// S = |v|_1 + sum e_a + sum e_b (internal-internal pairs carry no quaternion error: 16 u S).  d > E proves
+// sizes), everything else in Float32 on unit quaternions: q = conj(q_a) (x) q_a_b (x) q_b (q_a, q_b from the node
+// records, q_a_b formed once per seed from the item's pose; each is checked in Float64 to reproduce its matrix to 4 u per
+// entry, u = 2^-24), R = matrix of q, t = R_a' v by the rotation formula, then the 15 axes d = |T.L| - (r_a + r_b).
+// The error of R is below 142 u, so |d_float - d_reference| < 320 u S with S = |v|_1 + sum e_a + sum e_b
+// (internal-internal pairs carry identity quaternions and only the pose's error: 24 u S).  d > E proves
 // separation, d < -E on all 15 axes proves overlap; an undecided pair (~1e-5 of its margin scale) is NOT decided by
 // this test: it is parked in LDS and settled at the top of the next iteration by the exact Float64 test.  The
 // candidate set and the node-test counts therefore equal the reference's bit for bit (tests/test_gpu_*.py).
@@ -212,66 +213,97 @@ __device__ __forceinline__ NodeF load_nodef(const NodeF *n) {
     return u.f;
 }
 
-// Error radius E of the single-precision test (why 16 u and 192 u; u = 2^-24, round to nearest, |fl(x op y) - (x op y)|
-// <= u |x op y|; S = |v|_1 + sum e_a + sum e_b is formed from the SAME rounded inputs the axes use).
-// The reference evaluates, per axis L, d_ref = |T.L| - (r_a + r_b) in Float64 with abs_R = |R| + 1e-14
+// Error radius E of the single-precision test (why 24 u and 320 u; u = 2^-24, round to nearest, |fl(x op y) - (x op y)|
+// <= u |x op y|, a fused multiply-add rounds once; S = |v|_1 + sum e_a + sum e_b is formed from the SAME rounded inputs
+// the axes use).  The reference evaluates, per axis L, d_ref = |T.L| - (r_a + r_b) in Float64 with abs_R = |R| + 1e-14
 // (src/obb/bb_intersection.jl:10,29-72); its own roundings (~1e-16 S) and the 1e-14 (<= 2e-7 u per unit of extent) are
 // far below one u S and are covered by the slack left below.
-//   Inputs.  v_i = fl32(Float64 centre offset): |dv_i| <= u |v_i|.  e = fl32(extent): relative u.  R_a_b -> Float32:
-//   absolute u per entry (|entry| <= 1).
-//   (a) both boxes axis aligned (identity quaternions; every internal x internal pair): quat_to_R returns I exactly, the
-//       two 3x3 products reproduce R_a_b(float) and v exactly, so R has absolute error <= u per entry and t = v.
-//       Face axis of A:  |t_i| - (e_a,i + sum_j |R_ij| e_b,j): input errors u |t_i| + u e_a,i + (u + u) sum e_b (entry of R,
-//       extent), three fused roundings <= 3 u sum e_b, the sum and the final difference <= 2 u S: below 8 u S.
-//       Face axis of B:  symmetric, with the three-term dot product R(:,j).t: (u + u + 3 u) |t|_1 + ...: below 8 u S.
-//       Edge-edge axes: each of the six products carries two input errors and one rounding (3 u), two of them meet in one
-//       fused operation (+ u), sum and difference (+ 2 u): below 7 u S.
-//       E = 16 u S therefore holds with a factor of two to spare.
-//   (b) a tight-fitted (leaf) box is involved: R_a, R_b come from Float32 unit quaternions.  pfc_add_mesh checks IN FLOAT64
-//       that the stored quaternion reproduces R to 4 u per entry (else exact_only: the pair is never decided here);
-//       quat_to_R adds <= 4 roundings per entry: |dR_a|, |dR_b| <= 8 u.
-//       T = R_a' R_a_b: three terms, each (8 u + u) from its factors, + 3 u of rounding: |dT| <= 30 u.
-//       R = T R_b: sum_k (|dT_ik| |R_b,kj| + |T_ik| |dR_b,kj|) <= (30 u + 8 u) sqrt 3 (rows / columns of a rotation have
-//       1-norm <= sqrt 3) + 3 u of rounding: |dR| <= 69 u < 72 u.
-//       t = R_a' v: (8 u + u) |v|_1 + 3 u |v|_1: |dt_i| <= 12 u |v|_1, and |t|_1 <= sqrt 3 |v|_1.
-//       Worst axis (edge-edge): |t_u R_vj - t_v R_uj| picks up 72 u |t|_1 <= 125 u |v|_1 from dR and 2 x 12 u |v|_1 from
-//       dt; r_a + r_b picks up 72 u (sum e_a + sum e_b) from dR and u from the extents; roundings as in (a) <= 8 u S.
-//       Total below (125 + 24 + 8) u |v|_1 + (72 + 1 + 8) u sum e  <=  157 u S  <  192 u S = E.
+//   Notation.  R(q) is the polynomial map of quat_to_R (1 - 2(y^2 + z^2), 2(xy - wz), ...); it satisfies
+//   R(p (x) q) = R(p) R(q) for UNIT quaternions and R(s q) = I + s^2 (R(q) - I) for a scaled one.
+//   Inputs.  v_i = fl32(Float64 centre offset): |dv_i| <= u |v_i|.  e = fl32(extent): relative u.  Every quaternion used
+//   here (q_a, q_b: pfc_add_mesh; q_a_b: pose_quat) has passed, IN FLOAT64, the check |R(q_f) - R_ref|_max <= 4 u and
+//   | |q_f|^2 - 1 | <= 2.25 u; a node / pose that fails is exact_only and never decided here.
+//   (1) Representation.  With q^ = q_f / |q_f|: |R(q^) - R(q_f)| = |1/|q_f|^2 - 1| |R(q_f) - I| <= 2.26 u x 2, so
+//       |R(q^) - R_ref| <= rho = 8.6 u for each of the three rotations.  For unit quaternions
+//       R(conj q_a^ (x) q_ab^ (x) q_b^) = R(q_a^)' R(q_ab^) R(q_b^) exactly; against R_a' R_a_b R_b the three error matrices
+//       contribute (sqrt 3 + 3 + sqrt 3) rho = 55.6 u (rows / columns of a rotation have 1-norm <= sqrt 3).  The exact
+//       product Q of the three STORED quaternions has |Q|^2 within 6.8 u of 1: |R(Q) - R(Q^)| <= 13.6 u.  Together 69.2 u.
+//   (2) Arithmetic.  quat_mul evaluates each component as a four-term dot product with four roundings of partial sums
+//       bounded by |a| |b| <= 1 + 3 u: |dp_i| <= 4 u after the first product; the second product carries it with a factor
+//       |q_b|_1 <= 2 and adds its own 4 u: the computed q is Q + e with |e_i| <= 12 u.  R is quadratic in q: a diagonal
+//       entry moves by 4 (|y| |e_y| + |z| |e_z|) <= 48 sqrt 2 u = 68 u, an off-diagonal one by 2 (|x| + |y| + |w| + |z|) 12 u
+//       <= 48 u (second order: < 1e-3 u).  quat_to_R itself: <= 5 u (diagonal: two products of magnitude <= 2, their sum,
+//       the difference from 1).
+//       |dR| <= 69.2 + 68 + 5 < 143 u per entry.
+//   (3) t = R(q_a_f)' v by quat_rot_inv, exact in real arithmetic (polynomial identity, no unit assumption): 4 u |v|_1 from the
+//       representation, u |v_i| from the input; c = u x v - w v: three roundings of partial sums <= |v|_2: 3 u |v|_1;
+//       d = u x c (|c|_2 <= |v|_2): sqrt 2 x 3 u + 2 u = 6.3 u |v|_1; t = v + 2 d: 12.6 u + u.  |dt_i| <= 19 u |v|_1, and
+//       |t|_2 <= |v|_2 (1 + 1e-6).
+//   (4) Axes, leaf involved.  Face axis of B, |sum_i R_ij t_i| - (sum_i |R_ij| e_a,i + e_b,j), is the worst: dR against
+//       |t|_1 <= sqrt 3 |v|_1: 248 u |v|_1; dt against a column of R: 33 u |v|_1; three fused roundings 5 u |v|_1; r_a: (143 +
+//       1 + 3) u sum e_a; e_b,j: u; sum and difference 2 u S: below 290 u S.  Edge-edge axes: dR (|t_u| + |t_v|) <= 143 sqrt 2
+//       u |v|_1 = 203 u, dt 27 u, roundings 3 u; r_a + r_b: 146 u sum e; + 2 u S: below 236 u S.  Face axis of A: below 150 u S.
+//       E = 320 u S holds with 10 % to spare.
+//   (5) Axes, both boxes axis aligned (identity quaternions; every internal x internal pair): the two quaternion products
+//       return q_a_b(float) exactly (factors 1 and 0), quat_rot_inv returns v exactly, so |dR| <= 4 u + 5 u and t = v.
+//       Face axis of A: u |t_i| + u e_a,i + (9 + 1 + 3) u sum e_b + 2 u S <= 15 u S; face axis of B: (9 + 1 + 3) u |v|_1 +
+//       13 u sum e_a + u e_b,j + 2 u S <= 15 u S; edge-edge: (9 + 1) u on each product + 2 u of fused rounding, + 2 u S:
+//       <= 14 u S.  E = 24 u S.
 // Hence |d_float - d_ref| < E on every axis: d_float > E proves the reference separates on that axis, d_float < -E on all
 // 15 axes proves it does not separate on any; everything else is settled by the exact Float64 test.  The constants in the
-// code are 9.6e-7 (>= 16 u = 9.54e-7) and 1.15e-5 (>= 192 u = 1.144e-5).  tests/test_gpu_broadphase.py probes touching
-// configurations at 1 -/+ {1e-3, 1e-6, 1e-9, 1e-12} against the oracle for both box kinds.
+// code are 1.44e-6 (>= 24 u = 1.4305e-6) and 1.92e-5 (>= 320 u = 1.9073e-5).  tests/test_gpu_broadphase.py probes touching
+// configurations at 1 -/+ {1e-3, 1e-6, 1e-9, 1e-12} against the oracle for both box kinds; tests/test_bp_error_bound.py
+// samples a NumPy Float32 emulation of this function against these bounds (worst observed: |dR| 13 u, |d_float - d_ref| 8 u S).
 // one node pair of k_bp_dfs32: returns 0 = separated, 1 = overlapping, 2 = undecided
 __device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, bool any_leaf, const double *R12,
-                                             const float *R12f, const double *t12) {
+                                             const float *q12, const double *t12) {
     // centre offset in Float64, then everything in Float32
     float v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         // fused: the rounding of this Float64 offset is far inside the error radius E of the Float32 test
         v[i] = (float)__builtin_fma(R12[i + 6], b.c[2], __builtin_fma(R12[i + 3], b.c[1], __builtin_fma(R12[i], b.c[0], t12[i] - a.c[i])));
-    float Ra[9], Rb[9], T[9], R[9], t[3];
-    quat_to_R(a.q, Ra);
-    quat_to_R(b.q, Rb);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float r0 = Ra[3 * i], r1 = Ra[3 * i + 1], r2 = Ra[3 * i + 2];   // row i of R_a' = column i of R_a
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            T[i + 3 * j] = __builtin_fmaf(r2, R12f[3 * j + 2], __builtin_fmaf(r1, R12f[3 * j + 1], r0 * R12f[3 * j]));
-        t[i] = __builtin_fmaf(r2, v[2], __builtin_fmaf(r1, v[1], r0 * v[0]));
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            R[i + 3 * j] = __builtin_fmaf(T[i + 6], Rb[3 * j + 2], __builtin_fmaf(T[i + 3], Rb[3 * j + 1], T[i] * Rb[3 * j]));
+    // R = R_a' R_a_b R_b as ONE rotation: q = conj(q_a) (x) q_a_b (x) q_b, then its matrix; t = R_a' v by the quaternion
+    // rotation formula: 32 + 24 + 18 instructions instead of 2 x 24 (two matrices) + 27 + 9 + 27 (two 3x3 products)
+    float p[4], q[4], R[9], t[3];
+    quat_mul<true>(a.q, q12, p);
+    quat_mul<false>(p, b.q, q);
+    quat_to_R(q, R);
+    quat_rot_inv(a.q, v, t);
     const float S = ((__builtin_fabsf(v[0]) + __builtin_fabsf(v[1])) + __builtin_fabsf(v[2])) +
                     ((a.e[0] + a.e[1]) + a.e[2]) + ((b.e[0] + b.e[1]) + b.e[2]);
-    const float E = (any_leaf ? 1.15e-5f : 9.6e-7f) * S;   // 192 u, 16 u
+    const float E = (any_leaf ? 1.92e-5f : 1.44e-6f) * S;   // 320 u, 24 u
     int verdict = sat15_f32_core(a.e, b.e, t, R, E);
-    if (a.exact_only | b.exact_only) verdict = 2;
+    // huge or non-finite inputs are not for this filter (sat15_f32_core): !(S < 1e18) also catches NaN
+    if ((a.exact_only | b.exact_only) || !(S < 1.0e18f)) verdict = 2;
     return verdict;
+}
+
+// Unit quaternion (Float32) of the item's R_a_b, formed in Float64 (largest of 4w^2, 4x^2, 4y^2, 4z^2 as pivot, no
+// square root before the normalisation), and the check the error bound above rests on, IN FLOAT64: the rounded quaternion
+// reproduces R_a_b to 4 u per entry and has |q|^2 within 2.25 u of 1.  A pose that fails it (not a proper rotation) returns
+// false: every node test of the item then goes to the exact Float64 test.
+__device__ __forceinline__ bool pose_quat(const double *R, float *qf) {
+    const double d0 = ((1.0 + R[0]) + R[4]) + R[8], d1 = ((1.0 + R[0]) - R[4]) - R[8];
+    const double d2 = ((1.0 - R[0]) + R[4]) - R[8], d3 = ((1.0 - R[0]) - R[4]) + R[8];
+    double q0, q1, q2, q3;
+    if (d0 >= d1 && d0 >= d2 && d0 >= d3) { q0 = d0; q1 = R[5] - R[7]; q2 = R[6] - R[2]; q3 = R[1] - R[3]; }
+    else if (d1 >= d2 && d1 >= d3) { q0 = R[5] - R[7]; q1 = d1; q2 = R[3] + R[1]; q3 = R[6] + R[2]; }
+    else if (d2 >= d3) { q0 = R[6] - R[2]; q1 = R[3] + R[1]; q2 = d2; q3 = R[7] + R[5]; }
+    else { q0 = R[1] - R[3]; q1 = R[6] + R[2]; q2 = R[7] + R[5]; q3 = d3; }
+    const double qn = __builtin_sqrt(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
+    qf[0] = (float)(q0 / qn); qf[1] = (float)(q1 / qn); qf[2] = (float)(q2 / qn); qf[3] = (float)(q3 / qn);
+    const double w = qf[0], x = qf[1], y = qf[2], z = qf[3];
+    const double Rq[9] = {1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w),
+                          2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w),
+                          2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)};
+    double worst = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) worst = fmax(worst, __builtin_fabs(Rq[j] - R[j]));
+    const double n2 = ((w * w + x * x) + y * y) + z * z;
+    const double u = 5.9604644775390625e-8;
+    // written so that a NaN anywhere fails the check
+    return (worst <= 4.0 * u) && (__builtin_fabs(n2 - 1.0) <= 2.25 * u);
 }
 
 constexpr int kDfsBlock = 256;
@@ -396,7 +428,8 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
     __shared__ double xs[(kDfsBlock / 16) * 33];
     __shared__ int s_seed, s_base, s_def[2];   // s_def: parked-pair counters, alternating by iteration parity
     __shared__ double s_pose[12];         // R_a_b (9, column-major), t_a_b (3) of the current seed's item
-    __shared__ float s_posef[12];         // R_a_b rounded to Float32 once per seed
+    __shared__ float s_q12[4];            // unit quaternion of R_a_b (Float32), formed once per seed
+    __shared__ int s_pose_exact;          // the pose failed pose_quat's check: every test of the seed is settled exactly
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n_seed = *g.n_seed;
     if (n_seed > g.seed_cap) n_seed = g.seed_cap;
@@ -413,8 +446,17 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
         const ItemRec *it = g.items + item;
         // the item's pose lives in LDS (broadcast reads inside the iteration) rather than in 33 registers that would
         // stay live across the call of the exact test
-        if (tid < 9) { const double r = it->R12[tid]; s_pose[tid] = r; s_posef[tid] = (float)r; }
+        if (tid < 9) s_pose[tid] = it->R12[tid];
         else if (tid < 12) s_pose[tid] = it->t12[tid - 9];
+        else if (tid == 64) {   // first lane of wave 1: runs beside wave 0's loads
+            double R[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R[k] = it->R12[k];
+            float qf[4];
+            const bool ok = pose_quat(R, qf);
+            s_q12[0] = qf[0]; s_q12[1] = qf[1]; s_q12[2] = qf[2]; s_q12[3] = qf[3];
+            s_pose_exact = ok ? 0 : 1;
+        }
         const NodeF *n1 = it->nf1, *n2 = it->nf2;
         int sp = 1, n_out = 0, n_test = 0, n_cand = 0, n_def = 0, n_und = 0;
         if (tid == 0) {
@@ -464,12 +506,15 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
 #endif
                 if (!settle) {
                     double R12[9], t12[3];
-                    float R12f[9];
+                    float q12[4];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) { R12[k] = s_pose[k]; R12f[k] = s_posef[k]; }
+                    for (int k = 0; k < 9; ++k) R12[k] = s_pose[k];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
-                    verdict = test_pair_f32(a, b, la || lb, R12, R12f, t12);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q12[k] = s_q12[k];
+                    verdict = test_pair_f32(a, b, la || lb, R12, q12, t12);
+                    if (s_pose_exact) verdict = 2;
                 }
             }
             STAMP(u2);

@@ -957,7 +957,8 @@ int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int
         }
         const double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
         for (int j = 0; j < 4; ++j) f.q[j] = (float)(q[j] / qn);
-        // host check of the bound the device relies on: the Float32 quaternion must reproduce R to 8 u per entry
+        // host check of what the device's error bound relies on (pfc_bp.h, "Error radius E"): in Float64, the Float32
+        // quaternion reproduces R to 4 u per entry and |q|^2 is within 2.25 u of 1 (u = 2^-24)
         {
             const double w = f.q[0], x = f.q[1], y = f.q[2], z = f.q[3];
             const double Rq[9] = {1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w),
@@ -965,7 +966,8 @@ int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int
                                   2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)};
             double worst = 0.0;
             for (int j = 0; j < 9; ++j) worst = std::fmax(worst, std::fabs(Rq[j] - R[j]));
-            f.exact_only = (std::isfinite(qn) && worst <= 4.0 * 5.9604644775390625e-8) ? 0 : 1;
+            const double n2 = w * w + x * x + y * y + z * z, u = 5.9604644775390625e-8;
+            f.exact_only = (std::isfinite(qn) && worst <= 4.0 * u && std::fabs(n2 - 1.0) <= 2.25 * u) ? 0 : 1;
         }
         if (r.leaf == kInternal) { f.link0 = r.child0; f.link1 = r.child1; }
         else { f.link0 = r.leaf; f.link1 = -1; }

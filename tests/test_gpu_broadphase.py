@@ -1,8 +1,8 @@
 """The reference's OBB separating-axis tests (test/test_obb/test_intersection.jl:39-104) run through the device
 broadphase itself: pfc_eval on host-supplied trees whose root boxes are the test's boxes.
 
-A one-node tree makes the root pair leaf x leaf (Float32 filter radius 192 u S, quaternion path); a three-node tree
-(root + two tiny leaves at the centre) makes it internal x internal (radius 16 u S, axis-aligned shortcut).  The
+A one-node tree makes the root pair leaf x leaf (Float32 filter radius 320 u S, quaternion path); a three-node tree
+(root + two tiny leaves at the centre) makes it internal x internal (radius 24 u S, identity quaternions).  The
 verdict of the root pair is read from the item's counters: leaf trees -> candidates (1 / 0), internal trees -> node
 tests (5 = root hit + its 4 child pairs, 1 = root separated).  Touching configurations are probed at 1 -/+ tol for
 tol = 1e-3 (decided by the Float32 filter), 1e-6 (the reference's tolerance), 1e-9 and 1e-12 (inside the filter's
@@ -177,3 +177,54 @@ def test_filtered_and_exact_broadphase_agree_on_a_contact_scene(pfc):
         for nf in (0, 1):
             assert np.array_equal(res[nf][2][k][0], rp) and np.array_equal(res[nf][2][k][1], rc)
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-9, atol=1e-9 * np.abs(res[0][0]).max())
+
+
+def test_poses_that_are_not_rotations_are_settled_exactly(pfc):
+    """The Float32 filter composes the pose as a quaternion, which only represents proper rotations.  A pose whose 3x3
+    block is scaled, sheared or a reflection fails the per-item check (pose_quat) and every node test of that item goes
+    to the exact Float64 test, which uses the matrix as given -- like the reference's BB_BB_intersect
+    (src/obb/bb_intersection.jl:2-12), whose verdict the oracle supplies."""
+    ea, eb = np.array([1.0, 2.0, 3.0]), np.array([2.1, 2.2, 2.3])
+    tri, tet = _meshes(pfc, 1)
+    S = pfc.scenario
+    m = S.MechanismScenario()
+    i1 = m.add_contact("a", tri, tree=_tree(pfc, ea, False))
+    i2 = m.add_contact("b", tet, c_prop=S.ContactProperties(1.0e6), tree=_tree(pfc, eb, False))
+    m.add_friction_regularize(i1, i2, mu_d=0.3)
+    m.finalize()
+    m.set_option("bfs_levels", 0)
+    rng = np.random.default_rng(11)
+    Rs, ts = [], []
+    for k in range(400):
+        R = _axis_angle(rng.random() * 2 * np.pi, rng.standard_normal(3))
+        kind = k % 4
+        if kind == 0:
+            R = R * (1.0 + 10.0 ** rng.uniform(-6, -1))              # scaled
+        elif kind == 1:
+            R = R @ np.diag([1.0, 1.0, -1.0])                          # reflection
+        elif kind == 2:
+            R = R + 10.0 ** rng.uniform(-6, -2) * rng.standard_normal((3, 3))   # sheared
+        # kind 3: proper rotation (control: decided by the filter)
+        d = rng.standard_normal(3); d /= np.linalg.norm(d)
+        Rs.append(R); ts.append(d * rng.uniform(2.0, 7.5))
+    n = len(Rs)
+    pose = np.zeros((n, 24))
+    for k in range(n):
+        pose[k, 12:21] = Rs[k].reshape(-1, order="F"); pose[k, 21:24] = ts[k]
+        Ri = np.linalg.inv(Rs[k])
+        pose[k, 0:9] = Ri.reshape(-1, order="F"); pose[k, 9:12] = -(Ri @ ts[k])
+    wrench, sdot, counts = m.force_all_elastic_intersections(pose, np.zeros((n, 6)), np.zeros((n, 6)), np.zeros(n, dtype=np.int32))
+    L = Orc.lib()
+    dp = C.POINTER(C.c_double)
+    P = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+    z, I = np.zeros(3), np.eye(3).reshape(-1)
+    n_hit = 0
+    for k in range(n):
+        ref = L.pfo_bb_bb_intersect(P(z), P(ea), P(I), P(z), P(eb), P(I), P(Rs[k].reshape(-1, order="F")), P(ts[k]))
+        assert bool(counts[k, 1] == 1) == bool(ref), (k, k % 4, counts[k])
+        n_hit += bool(ref)
+    assert 0 < n_hit < n
+    out = (C.c_longlong * 16)()
+    assert pfc._lib.lib().pfc_debug_stamps(m._h, out) == 0
+    assert out[7] >= 3 * (n // 4), out[7]          # the three non-rotation kinds went to the exact test
+    m.close()
