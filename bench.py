@@ -326,7 +326,7 @@ def main():
         parts_n = parts_prof
         # SURVEY §8(d) accounting: algorithmic bytes / kernel time against the HBM peak (well below 1: these kernels re-read
         # their 64..256-byte records from L2 / Infinity Cache and are bound by vector issue, see "valu").
-        roof_np = {"kernel": "k_narrow<false>", "bound": "hbm",
+        roof_np = {"kernel": "k_narrow<false, false>", "bound": "hbm",
                    "achieved": BYTES_PER_OP * st_prof["candidates"] / parts_n / (np_ms * 1e-3) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms_per_launch": np_ms,
                    "units_per_launch": st_prof["candidates"] / parts_n, "bytes_per_unit": BYTES_PER_OP}

@@ -495,8 +495,13 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     np.poly_item = h->poly_item.p; np.poly = h->poly.p; np.pcap = (int)poly_cap(h->ccap); np.rp_cap = np.pcap / kRgn;
     np.surv = h->want_surv ? h->surv.p : nullptr; np.scount = pcount + 1;
     const int np_grid = grid_for(h->ccap, kNpBlock, kNpMaxBlocks);
-    if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
-    else hipLaunchKernelGGL((k_narrow<false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+    if (h->opt_debug) {
+        if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        else hipLaunchKernelGGL((k_narrow<false, true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+    } else {
+        if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        else hipLaunchKernelGGL((k_narrow<false, false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+    }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_NP], st));
 
     BrArgs br;

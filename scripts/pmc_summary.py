@@ -32,7 +32,7 @@ def per_launch(name):
                      raw["WRITE_SIZE"].get(name, {}).get("per_call_KB", 0.0))
 
 out = {"k_bp_dfs32_bytes_per_launch": per_launch("pfc::k_bp_dfs32") + per_launch("pfc::k_bp_dfs") + per_launch("pfc::k_bp_expand"),
-       "k_narrow0_bytes_per_launch": per_launch("void pfc::k_narrow<false>"),
+       "k_narrow0_bytes_per_launch": per_launch("void pfc::k_narrow<false, false>"),
        "k_fric_bytes_per_launch": per_launch("pfc::k_fric"),
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch of bench.py's default workload "
                "(8192 poses as two concurrent 4096-pose halves: a launch covers one half); bytes = 1024 x (2 x FETCH_SIZE "

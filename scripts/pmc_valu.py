@@ -32,7 +32,7 @@ out = {"source": "rocprofv3 --pmc (scripts/pmc_probe.sh, one counter group per p
                  f"({int(bench['config'].get('items_per_step', bench['config'].get('poses_per_gpu', 0)))} poses as {parts} concurrent part(s)); PER STEP = {parts} x the per-launch averages",
        "measured": "round 2",
        "node_tests": int(bench["config"]["node_tests_per_step"]), "candidates": int(bench["config"]["ops_per_step"])}
-for kern, name in (("pfc::k_bp_dfs32", "k_bp_dfs32"), ("void pfc::k_narrow<false>", "k_narrow"), ("pfc::k_fric", "k_fric")):
+for kern, name in (("pfc::k_bp_dfs32", "k_bp_dfs32"), ("void pfc::k_narrow<false, false>", "k_narrow"), ("pfc::k_fric", "k_fric")):
     for ctr, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAIT_ANY", "wait_any_cycles"),
                      ("SQ_WAIT_INST_ANY", "wait_inst_any_cycles"), ("SQ_ACTIVE_INST_ANY", "active_inst_any_cycles"),
                      ("SQ_INSTS_SALU", "salu_insts"), ("SQ_INSTS_LDS", "lds_insts"), ("TCC_HIT_sum", "tcc_hit"), ("TCC_MISS_sum", "tcc_miss"),
