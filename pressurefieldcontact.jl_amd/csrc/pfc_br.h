@@ -87,7 +87,8 @@ __global__ void __launch_bounds__(64) k_shift(ShiftArgs g) {
             for (int k = 0; k < 6; ++k) {
                 const int ii = u6[k] % 3, j = u6[k] / 3;
                 o[15 + k] = Saa[u6[k]] + Sd[ii + 3 * j] + Sd[j + 3 * ii] + dSd[u6[k]];
-                o[21 + k] = Srr[u6[k]] + W * d[ii] * d[j];
+                // sum w (x + d)(x + d)' = Srr + m1 d' + d m1' + W d d'  (m1 = sum w x about the record's reference point)
+                o[21 + k] = Srr[u6[k]] + (r[32 + ii] * d[j] + d[ii] * r[32 + j]) + W * d[ii] * d[j];
             }
             items[lane] = item;
         }

@@ -86,21 +86,6 @@ struct FuItem {
     double s[6];
 };
 
-// wave total of a double on DPP (row_shr 1/2/4/8, row_bcast 15/31), returned as a uniform value
-__device__ __forceinline__ double wave_total(double v, int lane) {
-    double t;
-    t = dpp_move<0x111, 0xF>(v); v += t;
-    t = dpp_move<0x112, 0xF>(v); v += t;
-    t = dpp_move<0x114, 0xF>(v); v += t;
-    t = dpp_move<0x118, 0xF>(v); v += t;
-    t = dpp_move<0x142, 0xA>(v); v += (lane & 16) ? t : 0.0;
-    t = dpp_move<0x143, 0xC>(v); v += (lane >= 32) ? t : 0.0;
-    return readlane_f64(v, 63);
-}
-__device__ __forceinline__ int wave_total_i(int v, int lane) {
-    return __builtin_amdgcn_readlane(seg_incl_scan(v), 63);
-}
-
 // block totals of N per-thread values: wave totals on DPP, then the four wave totals meet in LDS; every thread returns
 // the same N totals in out[] (same summation order in every thread).  red: kFuWaves x 32 doubles.
 template <int N>

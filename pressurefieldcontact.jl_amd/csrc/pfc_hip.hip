@@ -241,7 +241,7 @@ struct pfc_context {
     DevBuf<int> scat_i;
     DevBuf<int> surv;                                       // candidate indices of contributing pairs
     DevBuf<int> rgn;                                        // region counters of the polygon / record lists
-    DevBuf<int> poly_item;                                  // kept polygons of bristle pairs (k_narrow -> k_fric)
+    DevBuf<int> poly_item, pcnt, poly_cand;                 // kept polygons (k_narrow -> k_integ, k_fric): keys, count per chunk, candidate index (Dual list)
     DevBuf<double> poly;
     long long last_undecided = 0;      // node pairs the Float32 broadphase settled with the exact Float64 test
     long long last_tslots = 0;         // traction slots used by the last evaluation (>= traction points)
@@ -271,6 +271,7 @@ struct pfc_context {
     int fu_ndir = 0;
     bool pending_fused = false, last_fused = false;
     int opt_split_min = 1024;          // 0: never split
+    int opt_clip_min = 256;            // items from which the narrowphase runs as clip-only kernel + k_integ; 0: never
     int opt_poison = 0;                // diagnostic: fill (re)allocated work lists with 0xFF bytes (item index -1)
     int split_n0 = 0;                  // items in the first half of the pending evaluation (0: not split)
     int last_parts = 1;                // 2 if the last checked evaluation ran as two halves
@@ -322,16 +323,17 @@ int grid_for(size_t n, int block, int max_blocks) {
     return (int)b;
 }
 
-// Kept-polygon slots: kRgn regions, each able to hold every candidate its workgroups can see (workgroup b of the
-// narrowphase appends to region b % kRgn and reads candidates b*64 + round*stride): (ccap + stride) / kRgn per region.
+// Kept-polygon slots: chunk ch of the candidate list owns slots [ch C, ch C + C) (pfc_np.h, np_chunk): the candidate
+// capacity rounded up to a whole chunk.
 constexpr int kNpMaxBlocks = 256 * 16;
-size_t poly_cap(size_t ccap) { return ccap + (size_t)grid_for(ccap, 64, kNpMaxBlocks) * 64; }
+constexpr int kNpChunkSwitch = 2048;   // a batch is cut into at least this many chunks before the chunks grow beyond a wave round
+size_t poly_cap(size_t ccap) { return (ccap + kNpChunkBig - 1) / kNpChunkBig * kNpChunkBig; }
 
 hipError_t ensure_work(pfc_context *h, int n_items) {
     hipError_t e;
     const size_t caps0[] = {h->items.cap, h->acc.cap, h->res.cap, h->icnt.cap, h->ctr.cap, h->frontier[0].cap,
                             h->frontier[1].cap, h->cand.cap, h->clip_n.cap, h->trac_item.cap, h->trac_d.cap, h->rec.cap,
-                            h->tail.cap};
+                            h->tail.cap, h->poly_item.cap, h->poly.cap, h->pcnt.cap, h->poly_cand.cap};
     if ((e = h->items.ensure(n_items)) != hipSuccess) return e;
     if ((e = h->acc.ensure((size_t)n_items * kAccStride)) != hipSuccess) return e;
     if ((e = h->res.ensure((size_t)n_items * kResStride)) != hipSuccess) return e;
@@ -365,10 +367,12 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     if ((e = h->cand.ensure(c)) != hipSuccess) return e;
     if ((e = h->clip_n.ensure(c)) != hipSuccess) return e;
     if ((e = h->surv.ensure(c)) != hipSuccess) return e;
-    if (h->any_bristle) {
+    {   // kept polygons: bristle items always (friction pass), every item when the clip-only narrowphase + k_integ run
         const size_t pc = poly_cap(c);
         if ((e = h->poly_item.ensure(pc)) != hipSuccess) return e;
         if ((e = h->poly.ensure(pc * 34)) != hipSuccess) return e;
+        if ((e = h->pcnt.ensure(pc / kNpBlock + 1)) != hipSuccess) return e;
+        if (h->want_surv && (e = h->poly_cand.ensure(pc)) != hipSuccess) return e;
     }
     if ((e = h->trac_item.ensure(t)) != hipSuccess) return e;
     if ((e = h->trac_d.ensure(t * 8)) != hipSuccess) return e;
@@ -381,7 +385,7 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     }
     const size_t caps1[] = {h->items.cap, h->acc.cap, h->res.cap, h->icnt.cap, h->ctr.cap, h->frontier[0].cap,
                             h->frontier[1].cap, h->cand.cap, h->clip_n.cap, h->trac_item.cap, h->trac_d.cap, h->rec.cap,
-                            h->tail.cap};
+                            h->tail.cap, h->poly_item.cap, h->poly.cap, h->pcnt.cap, h->poly_cand.cap};
     for (size_t k = 0; k < sizeof caps0 / sizeof caps0[0]; ++k)
         if (caps0[k] != caps1[k]) { ++h->epoch; break; }
     if (h->opt_poison) {    // every evaluation starts from lists full of entries that must never be followed
@@ -492,15 +496,26 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     np.tcount = tcount; np.tcap = (int)h->tcap; np.status = h->status.p; np.debug = h->opt_debug;
     np.stamps = h->stamps.p;
     np.rec = h->rec.p; np.rgn = h->rgn.p; np.rr_cap = (int)(h->rcap / kRgn);
-    np.poly_item = h->poly_item.p; np.poly = h->poly.p; np.pcap = (int)poly_cap(h->ccap); np.rp_cap = np.pcap / kRgn;
+    np.poly_item = h->poly_item.p; np.poly = h->poly.p; np.pcap = (int)poly_cap(h->ccap);
+    np.pcnt = h->pcnt.p; np.chunk_switch = kNpChunkSwitch; np.poly_cand = h->want_surv ? h->poly_cand.p : nullptr;
     np.surv = h->want_surv ? h->surv.p : nullptr; np.scount = pcount + 1;
     const int np_grid = grid_for(h->ccap, kNpBlock, kNpMaxBlocks);
-    if (h->opt_debug) {
-        if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
-        else hipLaunchKernelGGL((k_narrow<false, true>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+    const int np_mode = h->opt_debug ? 1 : ((h->opt_clip_min > 0 && n_items >= h->opt_clip_min) ? 2 : 0);
+    if (np_mode == 1) {
+        if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, 1>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        else hipLaunchKernelGGL((k_narrow<false, 1>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+    } else if (np_mode == 0) {
+        if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, 0>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        else hipLaunchKernelGGL((k_narrow<false, 0>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
     } else {
-        if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
-        else hipLaunchKernelGGL((k_narrow<false, false>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, 2>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        else hipLaunchKernelGGL((k_narrow<false, 2>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        IntegArgs ig;
+        ig.items = h->items.p; ig.n_items = n_items; ig.ccount = ccount; ig.ccap = (int)h->ccap; ig.chunk_switch = kNpChunkSwitch;
+        ig.pcnt = h->pcnt.p; ig.poly_item = h->poly_item.p; ig.poly = h->poly.p; ig.pcap = np.pcap;
+        ig.poly_cand = np.poly_cand; ig.surv = np.surv; ig.scount = np.scount; ig.acc = h->acc.p; ig.rec = h->rec.p;
+        ig.rgn = h->rgn.p; ig.rr_cap = np.rr_cap; ig.icnt = h->icnt.p; ig.status = h->status.p;
+        hipLaunchKernelGGL(k_integ, dim3(grid_for(h->ccap, 64, kNpMaxBlocks)), dim3(64), 0, st, ig);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_NP], st));
 
@@ -516,8 +531,9 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         hipLaunchKernelGGL(k_shift, dim3(grid_for(h->rcap, 64, 2048)), dim3(64), 0, st, sh);
         hipLaunchKernelGGL(k_eig, dim3(n_items), dim3(64), 0, st, br);   // one wave per item
         FricArgs fr;
-        fr.items = h->items.p; fr.poly_item = h->poly_item.p; fr.poly = h->poly.p; fr.rgn = h->rgn.p;
-        fr.pcap = np.pcap; fr.rp_cap = np.rp_cap; fr.res = h->res.p; fr.acc = h->acc.p;
+        fr.items = h->items.p; fr.poly_item = h->poly_item.p; fr.poly = h->poly.p; fr.ccount = ccount; fr.ccap = (int)h->ccap;
+        fr.chunk_switch = kNpChunkSwitch; fr.pcnt = h->pcnt.p;
+        fr.pcap = np.pcap; fr.res = h->res.p; fr.acc = h->acc.p;
         fr.n_items = n_items; fr.status = h->status.p;
         hipLaunchKernelGGL(k_fric, dim3(grid_for(h->ccap, 64, 256 * 16)), dim3(64), 0, st, fr);
     }
@@ -840,7 +856,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->pin_din) (void)hipHostFree(h->pin_din);
     if (h->pin_dout) (void)hipHostFree(h->pin_dout);
     h->tail.release();
-    h->rgn.release(); h->poly_item.release(); h->poly.release(); h->surv.release(); h->scat_d.release(); h->scat_i.release();
+    h->rgn.release(); h->poly_item.release(); h->pcnt.release(); h->poly_cand.release(); h->poly.release(); h->surv.release(); h->scat_d.release(); h->scat_i.release();
     h->dual_poly.release(); h->dual_pkey.release();
     h->dual_in.release(); h->dual_acc.release(); h->dual_res.release(); h->dual_out.release(); h->dual_zero.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1130,6 +1146,7 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
     pfc_context *t = h->twin;
     t->opt_profile = h->opt_profile; t->opt_max_levels = h->opt_max_levels; t->opt_bfs_levels = h->opt_bfs_levels;
     t->opt_poison = h->opt_poison;
+    if (t->opt_clip_min != h->opt_clip_min) { t->opt_clip_min = h->opt_clip_min; t->ghave[0] = t->ghave[1] = false; }
     t->opt_graph = h->opt_graph;
     if (t->opt_no_filter != h->opt_no_filter) { t->opt_no_filter = h->opt_no_filter; t->ghave[0] = t->ghave[1] = false; }
     const int n0 = n_items / 2, n1 = n_items - n0;
@@ -1691,6 +1708,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "bfs_levels")) h->opt_bfs_levels = (int)value;
     else if (!std::strcmp(name, "graph")) h->opt_graph = value != 0;
     else if (!std::strcmp(name, "split_min")) h->opt_split_min = (int)value;
+    else if (!std::strcmp(name, "clip_min")) { h->opt_clip_min = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else if (!std::strcmp(name, "poison")) h->opt_poison = value != 0;
     else if (!std::strcmp(name, "fused")) { h->opt_fused = value != 0; h->fused_skip = 0; }
     else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }

@@ -133,8 +133,9 @@ constexpr int kAccSaa = 25;     // 6: sum w (x x n)(x x n)'
 constexpr int kAccSrr = 31;     // 6: sum w x x'
 constexpr int kAccFric = 37;    // 6: friction wrench about the cop [ang; lin]
 constexpr int kAccStride = 44;
-// moment record of one wave run: item, W, c_w(3), Snn 6, San 9, Saa 6, Srr 6 (about c_w)
-constexpr int kRecStride = 32;
+// moment record of one run of an item: item, W, c(3), Snn 6, San 9, Saa 6, Srr 6 (about the reference point c), and the
+// first moment m1 = sum w (r - c) (3; zero when c is the run's own pressure centroid: k_narrow's full modes), padding
+constexpr int kRecStride = 36;
 // per-item derived results (doubles)
 constexpr int kResCop = 0;      // 3
 constexpr int kResSinv = 3;     // 6

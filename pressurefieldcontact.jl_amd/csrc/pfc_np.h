@@ -16,16 +16,18 @@ struct NpArgs {
     int ccap;
     double *acc;
     double *rec;       // moment records (bristle)
-    int *rgn;        // region counters of the kept-polygon and record lists (kRgn x kRgnStride ints)
+    int *rgn;        // region counters of the record list (kRgn x kRgnStride ints, word 1)
     int rr_cap;      // record slots per region
+    int *pcnt;       // kept polygons per candidate chunk (written for every chunk of the evaluation)
+    int chunk_switch;  // number of chunks a batch must at least fall into (np_chunk picks the chunk size from it)
+    int *poly_cand;  // clip-only mode with the Dual list on: candidate index of every kept polygon, or null
     int *icnt;
     int n_items;
     int *clip_n;     // per candidate, or null
     // clipped polygons of bristle items, kept for the friction pass (k_fric): SoA [field][slot], slot < pcap
     int *poly_item;  // item | n_poly << 28
     double *poly;    // 34 fields: n̂ 3, centroid 3, ϵ_r² 4, vertices 8 x 3 (frame r²)
-    int rp_cap;      // polygon slots per region
-    int pcap;        // kRgn * rp_cap: the SoA stride of the polygon fields
+    int pcap;        // the SoA stride of the polygon fields (>= ccap rounded up to a chunk)
     int *surv;       // candidate indices of the pairs that contributed traction points (work list of the Dual passes)
     int *scount;
     TracSoA trac;
@@ -55,6 +57,18 @@ __device__ __forceinline__ V3 axpy_fma(double a, V3 x, V3 y) {
 #define PFC_EXP 0
 #endif
 constexpr int kNpBlock = 64;  // one wave per block: 16 KiB of LDS polygon staging per wave
+// Candidates are dealt out in CHUNKS of consecutive list entries: one workgroup walks a chunk round by round and keeps
+// the chunk's polygons in the chunk's own slot range [ch C, ch C + C) behind a counter it holds in a register -- no
+// reservation atomic, and since the candidate list is grouped by item a chunk's polygons belong to one item (two at a run
+// boundary), which is what lets the passes over the kept polygons (k_integ, k_fric) sum per item in registers.  Big
+// batches use 512-candidate chunks; a small scene's chunk is one wave round (np_chunk: latency before density).
+constexpr int kNpChunkBig = 512;
+// the largest of 512 / 256 / 128 / 64 candidates that still leaves chunk_switch chunks (workgroups with work)
+__device__ __forceinline__ int np_chunk(int n_c, int chunk_switch) {
+    int C = kNpChunkBig;
+    while (C > kNpBlock && (long long)C * chunk_switch > n_c) C >>= 1;
+    return C;
+}
 
 // weightPoly (src/math_kernel/utility.jl:21-26) on 4-vectors held in LDS slots
 // polygon ring in LDS: 8 physical slots x 4 coords per lane, [slot][coord][lane] layout (conflict-free per-lane
@@ -64,6 +78,21 @@ constexpr int kNpBlock = 64;  // one wave per block: 16 KiB of LDS polygon stagi
 __device__ __forceinline__ double readlane_f64(double v, int src) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
                             __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// wave total of a double on DPP (row_shr 1/2/4/8, row_bcast 15/31), returned as a uniform value
+__device__ __forceinline__ double wave_total(double v, int lane) {
+    double t;
+    t = dpp_move<0x111, 0xF>(v); v += t;
+    t = dpp_move<0x112, 0xF>(v); v += t;
+    t = dpp_move<0x114, 0xF>(v); v += t;
+    t = dpp_move<0x118, 0xF>(v); v += t;
+    t = dpp_move<0x142, 0xA>(v); v += (lane & 16) ? t : 0.0;
+    t = dpp_move<0x143, 0xC>(v); v += (lane >= 32) ? t : 0.0;
+    return readlane_f64(v, 63);
+}
+__device__ __forceinline__ int wave_total_i(int v, int lane) {
+    return __builtin_amdgcn_readlane(seg_incl_scan(v), 63);
 }
 
 // Per-item accumulation of N per-lane partial sums.  Segmented scan per value, then the N totals of each run are
@@ -149,25 +178,32 @@ __device__ __forceinline__ double lds_row_sums(double *buf, const double *v, boo
 //
 // TT: the scenario contains tet-tet instructions (non_friction.jl:166-194); compiled out otherwise so that the common
 // tri-tet-only scenario does not pay the registers of the plane / tet intersection.
-// DBG: option debug (per-candidate clip counts and the materialised TractionCache, pfc_debug_*): a build of its own, so
-// that the default one does not keep the nine TractionCache pointers, their counters and the slot bookkeeping live
-// (235 -> 223 VGPRs, 175 -> 145 scalar registers spilled into vector lanes; narrowphase 2.48 -> 2.41 ms).
-template <bool TT, bool DBG>
+// MODE 0: everything up to the per-item sums in this kernel.  MODE 1: the same with option debug (per-candidate clip
+// counts and the materialised TractionCache, pfc_debug_*): a build of its own, so that the default one does not keep the
+// nine TractionCache pointers, their counters and the slot bookkeeping live (235 -> 223 VGPRs, 175 -> 145 scalar
+// registers spilled into vector lanes; narrowphase 2.48 -> 2.41 ms).  MODE 2 (big batches): gather, clip, polygon set-up
+// and the kept polygon only; the quadrature and the per-item sums are k_integ's, which walks the compacted polygons with
+// every lane busy (here 46 % of the lanes are rejected candidates and a lane waits for the longest fan of its wave).
+template <bool TT, int MODE>
 __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
+    constexpr bool DBG = MODE == 1, CLIP = MODE == 2;
     __shared__ double poly[8 * 4 * kNpBlock];
     const int lane = threadIdx.x;
     int n_c = *g.ccount;
     if (n_c > g.ccap) n_c = g.ccap;
-    const int stride = gridDim.x * kNpBlock;
-    const int n_round = (n_c + stride - 1) / stride;
+    const int C = np_chunk(n_c, g.chunk_switch);
+    const int n_chunk = (n_c + C - 1) / C;
 #ifdef PFC_STAMPS
     unsigned long long st_c[6] = {0, 0, 0, 0, 0, 0}, st_r[3] = {0, 0, 0};
 #endif
+    for (int ch = blockIdx.x; ch < n_chunk; ch += gridDim.x) {
+    int pc = 0;   // polygons kept so far in this chunk's slot range
+    const int n_round = ((n_c - ch * C < C ? n_c - ch * C : C) + kNpBlock - 1) / kNpBlock;
     for (int rd = 0; rd < n_round; ++rd) {
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
         (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5;
         STAMP(t0);
-        const int idx = rd * stride + blockIdx.x * kNpBlock + lane;
+        const int idx = ch * C + rd * kNpBlock + lane;
         bool active = idx < n_c;
         WorkRec cw;
         cw.item = 0; cw.a = 0; cw.b = 0; cw.pad = 0;
@@ -407,6 +443,60 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         }
         if (DBG && g.clip_n && active) g.clip_n[idx] = n_poly;
         STAMP(t2);
+        if constexpr (CLIP) {
+            // ==== clip-only mode: polygon set-up, kept polygon, non-empty count; k_integ does the rest ==================
+            const bool has_poly = work && n_poly >= 3;
+            const unsigned long long km = __ballot(has_poly), am = __ballot(active);
+            const int slot = ch * C + pc + __popcll(km & ((1ull << lane) - 1ull));
+            pc += __popcll(km);
+            if (has_poly) {
+                const int n = n_poly;
+                // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98) fused with centroid(poly_r2, n̂2)
+                // (poly_eight.jl:35-52), as in the full kernel below; every vertex leaves for the kept polygon as it is converted
+                const size_t P = (size_t)g.pcap;
+                double *o = g.poly + slot;
+#define NT_(p, v) __builtin_nontemporal_store((v), (p))
+                double V[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
+                auto conv = [&](int k) {
+                    const double z0 = PR(k, 0), z1 = PR(k, 1), z2 = PR(k, 2), z3 = PR(k, 3);
+                    const V3 x = mk3(((V[0] * z0 + V[3] * z1) + V[6] * z2) + V[9] * z3,
+                                     ((V[1] * z0 + V[4] * z1) + V[7] * z2) + V[10] * z3,
+                                     ((V[2] * z0 + V[5] * z1) + V[8] * z2) + V[11] * z3);
+                    NT_(o + (10 + 3 * k) * P, x.x); NT_(o + (11 + 3 * k) * P, x.y); NT_(o + (12 + 3 * k) * P, x.z);
+                    return x;
+                };
+                const V3 a = conv(0);
+                V3 cc = conv(1);
+                double cum_sum = 0.0;
+                V3 cum_prod = mk3(0.0, 0.0, 0.0);
+                for (int k = 2; k < n; ++k) {
+                    const V3 b = cc;
+                    cc = conv(k);
+                    const double ar = triangle_area(a, b, cc, nh);
+                    cum_prod = cum_prod + ((a + b) + cc) * (1.0 / 3.0) * ar;
+                    cum_sum += ar;
+                }
+                const V3 cen = (cum_sum == 0.0) ? a : cum_prod / cum_sum;
+                NT_(&g.poly_item[slot], (int)((unsigned)cw.item | ((unsigned)n << 28)));
+                NT_(o, nh.x); NT_(o + P, nh.y); NT_(o + 2 * P, nh.z);
+                NT_(o + 3 * P, cen.x); NT_(o + 4 * P, cen.y); NT_(o + 5 * P, cen.z);
+                NT_(o + 6 * P, tp->epsr[0]); NT_(o + 7 * P, tp->epsr[1]); NT_(o + 8 * P, tp->epsr[2]);
+                NT_(o + 9 * P, tp->epsr[3]);
+                if (g.poly_cand) NT_(&g.poly_cand[slot], idx);
+#undef NT_
+            }
+            if (km) {
+                const int item_first = __builtin_amdgcn_readlane(cw.item, __builtin_ctzll(am));
+                if (__all(!active || cw.item == item_first)) {
+                    if (lane == 0) atomicAdd(&g.icnt[4 * (size_t)item_first + 2], __popcll(km));
+                } else {
+                    count_per_item(g.icnt, cw.item, 2, active, has_poly);
+                }
+            }
+            continue;
+        }
         // ==== phase 2 (wave-uniform): reserve a contiguous run of traction slots for the whole wave ================
         // A lane with an n-gon owns n * nq consecutive slots, so the traction points of a wave (and, because the
         // candidate list is grouped by item, of an item) are contiguous: the later per-point passes then reduce
@@ -439,16 +529,16 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         const int item_prev = __shfl_up(cw.item, 1, 64);
         const unsigned long long am = __ballot(active);
         const unsigned long long heads = __ballot(active && (lane == 0 || item_prev != cw.item || !((am >> (lane - 1)) & 1ull)));
-        unsigned long long base2_raw = 0;   // low word: polygon offset in the region, high word: record offset
+        int rbase_raw = 0;   // record offset in this workgroup's region
         int sbase_raw = 0;
         const int rgn_c = blockIdx.x & (kRgn - 1);
         if (lane == 0) {
-            // ONE 64-bit atomic on the region's own cache line reserves the polygon slots and the record slots
-            if (km)
-                base2_raw = atomicAdd(reinterpret_cast<unsigned long long *>(g.rgn + rgn_c * kRgnStride),
-                                      ((unsigned long long)__popcll(heads) << 32) | (unsigned long long)__popcll(km));
+            // one record per run of an item; the polygon slots need no reservation (the chunk's own range, counter pc)
+            if (km) rbase_raw = atomicAdd(g.rgn + rgn_c * kRgnStride + 1, __popcll(heads));
             if (sm) sbase_raw = atomicAdd(g.scount, __popcll(sm));   // Dual evaluations only
         }
+        const int pbase = pc;
+        pc += __popcll(km);
         STAMP(t3);
         // ==== phase 3 (divergent): integrate_over_polygon_patch! (non_friction.jl:217-234) ============================
         double sum[10], wr1[3], wrr[6];   // wr1, wrr: first / second moments of w about the polygon centroid
@@ -602,16 +692,13 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             // had a polygon but no pressure point leave an empty marker).
             const bool keep = contributed && !reg;
             if (km | sm) {
-                const int base = __builtin_amdgcn_readfirstlane((int)(base2_raw & 0xFFFFFFFFull));
                 const int sbase = __builtin_amdgcn_readfirstlane(sbase_raw);
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (polys) g.surv[sbase + __popcll(sm & below)] = contributed ? idx : -1;   // <= ccap entries
-                // a region holds every candidate its workgroups can see (rp_cap = (ccap + grid stride) / kRgn)
-                // (per slot, not per wave: a consumer reads every slot below min(count, capacity), none may be left unwritten)
-                const int off = base + __popcll(km & below);
-                if (lane == 0 && base + __popcll(km) > g.rp_cap) atomicOr(g.status, kStPolyOvf);
-                const int slot = rgn_c * g.rp_cap + off;
-                if (polyb && off < g.rp_cap) {
+                // the chunk's own slot range holds every candidate of the chunk; every slot below the chunk's count is written
+                const int off = pbase + __popcll(km & below);
+                const int slot = ch * C + off;
+                if (polyb && off < C) {
                     const size_t P = (size_t)g.pcap;
                     double *o = g.poly + slot;
                     // streaming stores: 0.5 GB per C3 batch must not evict the mesh records from the XCD's 4 MiB L2
@@ -649,7 +736,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             STAMP(r2);
             // ---- patch-stiffness moments of the bristle model, one record per run of an item in this wave, in the slots
             // reserved before the integration (run r of the wave -> slot rbase + r; a run without a record gets W = 0)
-            const int rbase = __builtin_amdgcn_readfirstlane((int)(base2_raw >> 32));   // offset in the region
+            const int rbase = __builtin_amdgcn_readfirstlane(rbase_raw);   // offset in the region
             const int rslot0 = rgn_c * g.rr_cap;
             unsigned long long rec_done = 0;   // bit r: run r has its record
             if (__any(contributed && !reg)) {
@@ -776,11 +863,13 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         }
 #ifdef PFC_STAMPS
         STAMP(t5);
-        if (rd * stride + blockIdx.x * kNpBlock < n_c) {   // rounds with work; summed in registers (an atomic per round
-            if (t1 == 0) t1 = t2;                           // on one address would itself dominate the timing)
+        {   // summed in registers (an atomic per round on one address would itself dominate the timing)
+            if (t1 == 0) t1 = t2;
             st_c[0] += t1 - t0; st_c[1] += t2 - t1; st_c[2] += t3 - t2; st_c[3] += t4 - t3; st_c[4] += t5 - t4; st_c[5] += 1;
         }
 #endif
+    }
+    if (lane == 0) g.pcnt[ch] = pc;
     }
 #ifdef PFC_STAMPS
     if (lane == 0 && g.stamps && st_c[5])
@@ -792,6 +881,290 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
 }
 #undef PR
 
+// =================================================================================================================
+// k_integ -- integrate_over_polygon_patch! (non_friction.jl:217-265) over the polygons k_narrow<.., 2> kept: one lane per
+// kept polygon, every lane busy (the clip kernel's waves are half rejected candidates), coalesced loads only.  The fan /
+// quadrature arithmetic is the full kernel's expression for expression, so the traction points are bit-identical.
+//
+// Per-item sums stay in REGISTERS across the 64-polygon pieces of a chunk (a chunk's polygons belong to one item, two at a
+// run boundary of the candidate list): the ten wrench / cop sums, and for bristle items the 27 patch-stiffness moments
+// (normal_wrench_cop, normal.jl:17-34, and calc_patch_spatial_stiffness!, friction.jl:147-169) taken about c0, the centroid
+// of the first polygon of the run -- a point inside the patch, so the shift to the cop (k_shift, parallel-axis terms with
+// the first moment m1 = sum w (r - c0) carried in the record) is a shift by less than the patch size.  One LDS transpose
+// reduction, one 10-lane and one record write per (chunk, item) instead of per wave round.
+// =================================================================================================================
+struct IntegArgs {
+    const ItemRec *items;
+    int n_items;
+    const int *ccount;
+    int ccap, chunk_switch;
+    const int *pcnt;
+    int *poly_item;          // key of a polygon that must not reach k_fric (no pressure point, regularized item) is cleared
+    const double *poly;
+    int pcap;
+    const int *poly_cand;    // candidate index per kept polygon (Dual list on) or null
+    int *surv, *scount;      // contributing candidates (work list of the Dual passes) or null
+    double *acc, *rec;
+    int *rgn;                // record counters (word 1 of a region)
+    int rr_cap;
+    int *icnt;
+    unsigned *status;
+};
+
+// the row-summing half of lds_row_sums on rows that already sit in LDS (row k at buf[k (64 + L) + lane])
+template <int N, int L>
+__device__ __forceinline__ double lds_rows_total(const double *buf, int lane, int lane0) {
+    constexpr int RS = 64 + L;
+    static_assert(N * L <= 64 && (L == 1 || L == 2 || L == 4), "rows x lanes per row must fit the wave");
+    double t = 0.0;
+    const int row = lane / L, part = lane % L;
+    if (row < N) {
+        const double *r = buf + row * RS + part;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 64 / L; j += 8) {
+            const double a0 = r[L * j], a1 = r[L * (j + 1)], a2 = r[L * (j + 2)], a3 = r[L * (j + 3)];
+            const double a4 = r[L * (j + 4)], a5 = r[L * (j + 5)], a6 = r[L * (j + 6)], a7 = r[L * (j + 7)];
+            t0 += a0; t1 += a1; t2 += a2; t3 += a3;
+            t0 += a4; t1 += a5; t2 += a6; t3 += a7;
+        }
+        t = (t0 + t1) + (t2 + t3);
+    }
+#pragma unroll
+    for (int m = 1; m < L; m <<= 1) t += __shfl_xor(t, m, 64);
+    const int dst_row = lane - lane0;
+    const double out = __shfl(t, (dst_row >= 0 && dst_row < N) ? dst_row * L : 0, 64);
+    return (dst_row >= 0 && dst_row < N) ? out : 0.0;
+}
+
+__global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
+    constexpr int RS = 66;                  // row stride of lds_row_sums / lds_rows_total with two lanes per row
+    __shared__ double m27[27 * RS];         // the 27 running moments of the current run, one column per lane
+    const int lane = threadIdx.x;
+    int n_c = *g.ccount;
+    if (n_c > g.ccap) n_c = g.ccap;
+    const int C = np_chunk(n_c, g.chunk_switch);
+    const int n_chunk = (n_c + C - 1) / C;
+    const size_t P = (size_t)g.pcap;
+    for (int ch = blockIdx.x; ch < n_chunk; ch += gridDim.x) {
+        int cnt = __builtin_amdgcn_readfirstlane(g.pcnt[ch]);
+        if (cnt > C) cnt = C;
+        // the running sums of the current (chunk, item) run: ten in registers, the 27 moments in this lane's LDS column
+        int cur = -1, n_tr = 0;
+        bool cur_reg = false;
+        V3 c0 = mk3(0.0, 0.0, 0.0);
+        double s10[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s10[k] = 0.0;
+        auto flush = [&]() {
+            if (cur < 0 || !__any(n_tr > 0)) return;
+            // the ten sums: wave totals on DPP (once per run of a chunk), total k on lane k
+            double t10 = 0.0, Wt = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const double t = wave_total(s10[k], lane);
+                if (lane == k) t10 = t;
+                if (k == 6) Wt = t;
+                if (k == 7) sx = t;
+                if (k == 8) sy = t;
+                if (k == 9) sz = t;
+            }
+            if (lane < 10 && t10 != 0.0) unsafeAtomicAdd(&g.acc[(size_t)cur * kAccStride + lane], t10);
+            if (!cur_reg && Wt > 0.0) {
+                wave_lds_sync();
+                double mine = lds_rows_total<27, 2>(m27, lane, 5);             // lanes 5..31: moments about c0
+                if (lane == 0) mine = (double)cur;
+                if (lane == 1) mine = Wt;
+                if (lane == 2) mine = c0.x;
+                if (lane == 3) mine = c0.y;
+                if (lane == 4) mine = c0.z;
+                if (lane == 32) mine = sx - Wt * c0.x;      // m1 = sum w (r - c0)
+                if (lane == 33) mine = sy - Wt * c0.y;
+                if (lane == 34) mine = sz - Wt * c0.z;
+                const int rgn_c = ch & (kRgn - 1);
+                int rs = 0;
+                if (lane == 0) rs = atomicAdd(g.rgn + rgn_c * kRgnStride + 1, 1);
+                rs = __builtin_amdgcn_readfirstlane(rs);
+                if (rs < g.rr_cap) {
+                    if (lane < kRecStride) g.rec[((size_t)rgn_c * g.rr_cap + rs) * kRecStride + lane] = mine;
+                } else if (lane == 0) {
+                    atomicOr(g.status, kStRecOvf);
+                }
+                wave_lds_sync();
+            }
+            const int nt = wave_total_i(n_tr, lane);
+            if (lane == 0 && nt) atomicAdd(&g.icnt[4 * (size_t)cur + 3], nt);
+        };
+        for (int p0 = 0; p0 < cnt; p0 += 64) {
+            const int idx = ch * C + p0 + lane;
+            const bool active = p0 + lane < cnt;
+            unsigned pk = active ? (unsigned)g.poly_item[idx] : 0u;
+            if ((pk >> 28) > 8u || ((pk >> 28) >= 3u && (pk & 0x0FFFFFFFu) >= (unsigned)g.n_items)) {
+                atomicOr(g.status, kStHole);     // not a key k_narrow writes: an unwritten slot is reported, never followed
+                pk = 0u;
+            }
+            const int n = (int)(pk >> 28);
+            const bool has = n >= 3;
+            const int item = has ? (int)(pk & 0x0FFFFFFFu) : -1;
+            const double *o = g.poly + idx;
+            V3 nh = mk3(0.0, 0.0, 0.0), cen = nh;
+            double er0 = 0.0, er1 = 0.0, er2 = 0.0, er3 = 0.0;
+            if (has) {
+                nh = mk3(o[0], o[P], o[2 * P]);
+                cen = mk3(o[3 * P], o[4 * P], o[5 * P]);
+                er0 = o[6 * P]; er1 = o[7 * P]; er2 = o[8 * P]; er3 = o[9 * P];
+            }
+            bool contributed = false, lane_reg = false;
+            unsigned long long todo = __ballot(has);
+            while (todo) {     // the runs of equal items of this piece (one, two at a run boundary of the candidate list)
+                const int f = __builtin_ctzll(todo);
+                const int run_item = __builtin_amdgcn_readlane(item, f);
+                const bool in_run = has && item == run_item;
+                todo &= ~__ballot(in_run);
+                // the item's constants through the scalar path: run_item is uniform
+                const ItemRec *it = g.items + run_item;
+                const bool reg = it->model == PFC_REGULARIZED;
+                const int nq = it->nq;
+                const V3 w = ld3(it->w), vl = ld3(it->v);
+                const double chi = it->chi, Ebar = it->Ebar;
+                if (run_item != cur) {
+                    flush();
+                    cur = run_item;
+                    cur_reg = reg;
+                    c0 = mk3(readlane_f64(cen.x, f), readlane_f64(cen.y, f), readlane_f64(cen.z, f));
+                    n_tr = 0;
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) s10[k] = 0.0;
+                    if (!reg) {
+#pragma unroll
+                        for (int k = 0; k < 27; ++k) m27[k * RS + lane] = 0.0;
+                    }
+                }
+                if (!in_run) continue;
+                lane_reg = reg;
+                int ntl = 0;
+                V3 v2 = mk3(o[(10 + 3 * (n - 1)) * P], o[(11 + 3 * (n - 1)) * P], o[(12 + 3 * (n - 1)) * P]);
+                V3 vn = mk3(o[10 * P], o[11 * P], o[12 * P]);
+                // TriTetQuadRule rules 1 and 2, literal decimals of src/clip/quadrature.jl:24-39; fillTractionCacheInnerLoop!
+                // (non_friction.jl:251-265): r, p and dA are the full kernel's expressions, operation for operation
+                auto points = [&](auto &&body) {
+                    for (int k = 0; k < n; ++k) {
+                        const V3 v1 = v2;
+                        v2 = vn;
+                        // the next vertex is fetched while this triangle's points are evaluated (slot k + 1 <= 7 always exists)
+                        if (k + 1 < n) vn = mk3(o[(13 + 3 * k) * P], o[(14 + 3 * k) * P], o[(15 + 3 * k) * P]);
+                        const double area = triangle_area(v1, v2, cen, nh);
+                        if (!(0.0 < area)) continue;   // non_friction.jl:232
+                        for (int q = 0; q < nq; ++q) {
+                            double q0, q1, q2, qw;
+                            if (nq == 1) {
+                                q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
+                            } else {
+                                const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
+                                q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
+                                qw = 0.33333333333333331483;
+                            }
+                            const V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
+                                             (v1.z * q0 + v2.z * q1) + cen.z * q2);
+                            double eq = __builtin_fma(er0, r.x, er3);
+                            eq = __builtin_fma(er1, r.y, eq);
+                            eq = __builtin_fma(er2, r.z, eq);
+                            const V3 rdot = vl + cross(w, r);
+                            const double ee = -dot(mk3(er0, er1, er2), rdot);
+                            const double damp = fmax(0.0, 1.0 + chi * ee);
+                            const double p = eq * Ebar * damp;
+                            const double dA = qw * area;
+                            if (!(0.0 < p)) continue;  // :245
+                            ++ntl;
+                            body(r, rdot, p * dA);
+                        }
+                    }
+                };
+                if (reg) {
+                    // yes_contact!(::Regularized) (friction.jl:50-72) fused, as in the full kernel
+                    const double v_c = it->v_c, mu_s = it->mu_s, mu_d = it->mu_d;
+                    double fs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                    points([&](const V3 &r, const V3 &rdot, double p_dA) {
+                        const V3 vt = vec_sub_vec_proj(rdot, nh);
+                        const double m2 = dot_fma(vt, vt);
+                        V3 T;
+                        if (m2 < v_c * v_c) {
+                            T = vt * (-(mu_s / v_c));
+                        } else {
+                            double ri = __builtin_amdgcn_rsq(m2);
+                            const double hm = 0.5 * m2;
+                            ri = ri * __builtin_fma(-hm * ri, ri, 1.5);
+                            ri = ri * __builtin_fma(-hm * ri, ri, 1.5);
+                            const double mg = m2 * ri;
+                            const double mu = clamped_piecewise(mg, 2 * v_c, 3 * v_c, mu_s, mu_d);
+                            T = vt * (-(mu * ri));
+                        }
+                        const V3 tk = (nh + T) * p_dA;
+                        const V3 ta = cross_fma(r, tk);
+                        fs[0] += ta.x; fs[1] += ta.y; fs[2] += ta.z;
+                        fs[3] += tk.x; fs[4] += tk.y; fs[5] += tk.z;
+                    });
+                    if (ntl > 0) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) s10[k] += fs[k];
+                    }
+                } else {
+                    // normal_wrench_cop (normal.jl:17-34), pass 1 of the bristle model: W and the moments of w about c0
+                    double W = 0.0, wr1[3] = {0.0, 0.0, 0.0}, wrr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                    points([&](const V3 &r, const V3 &, double p_dA) {
+                        W += p_dA;
+                        const V3 rc = r - c0;
+                        const double wx = p_dA * rc.x, wy = p_dA * rc.y, wz = p_dA * rc.z;
+                        wr1[0] += wx; wr1[1] += wy; wr1[2] += wz;
+                        wrr[0] = __builtin_fma(wx, rc.x, wrr[0]); wrr[1] = __builtin_fma(wx, rc.y, wrr[1]);
+                        wrr[2] = __builtin_fma(wx, rc.z, wrr[2]); wrr[3] = __builtin_fma(wy, rc.y, wrr[3]);
+                        wrr[4] = __builtin_fma(wy, rc.z, wrr[4]); wrr[5] = __builtin_fma(wz, rc.z, wrr[5]);
+                    });
+                    if (ntl > 0) {
+                        // the polygon's share of the ten sums: torque (sum w r) x n̂, force n̂ W, W, sum w r
+                        const V3 Sr = mk3(wr1[0] + W * c0.x, wr1[1] + W * c0.y, wr1[2] + W * c0.z);
+                        const V3 ta = cross(Sr, nh);
+                        s10[0] += ta.x; s10[1] += ta.y; s10[2] += ta.z;
+                        s10[3] += nh.x * W; s10[4] += nh.y * W; s10[5] += nh.z * W;
+                        s10[6] += W; s10[7] += Sr.x; s10[8] += Sr.y; s10[9] += Sr.z;
+                        // and of the 27 moments about c0 (this lane's LDS column); n̂ is constant over the polygon:
+                        // sum w n n' = W n n', sum w (x x n) n' = (m1 x n) n', sum w (x x n)(x x n)' = [n]x Q [n]x'
+                        double *mc = m27 + lane;
+#define M27_(k, v) mc[(k) * RS] += (v)
+                        M27_(0, W * nh.x * nh.x); M27_(1, W * nh.x * nh.y); M27_(2, W * nh.x * nh.z);
+                        M27_(3, W * nh.y * nh.y); M27_(4, W * nh.y * nh.z); M27_(5, W * nh.z * nh.z);
+                        const V3 an = cross(mk3(wr1[0], wr1[1], wr1[2]), nh);
+                        M27_(6, an.x * nh.x); M27_(7, an.y * nh.x); M27_(8, an.z * nh.x);
+                        M27_(9, an.x * nh.y); M27_(10, an.y * nh.y); M27_(11, an.z * nh.y);
+                        M27_(12, an.x * nh.z); M27_(13, an.y * nh.z); M27_(14, an.z * nh.z);
+                        const V3 q0c = mk3(wrr[0], wrr[1], wrr[2]), q1c = mk3(wrr[1], wrr[3], wrr[4]), q2c = mk3(wrr[2], wrr[4], wrr[5]);
+                        const V3 m0 = cross(nh, q0c), m1c = cross(nh, q1c), m2c = cross(nh, q2c);       // M = [n]x Q
+                        const V3 r0 = cross(nh, mk3(m0.x, m1c.x, m2c.x)), r1 = cross(nh, mk3(m0.y, m1c.y, m2c.y));
+                        const V3 r2 = cross(nh, mk3(m0.z, m1c.z, m2c.z));
+                        M27_(15, r0.x); M27_(16, r0.y); M27_(17, r0.z); M27_(18, r1.y); M27_(19, r1.z); M27_(20, r2.z);
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) M27_(21 + k, wrr[k]);
+#undef M27_
+                    }
+                }
+                if (ntl > 0) { contributed = true; n_tr += ntl; }
+            }
+            // a polygon without a pressure point, or of a regularized item, is not for the friction pass
+            if (has && (!contributed || lane_reg)) g.poly_item[idx] = 0;
+            if (g.surv != nullptr) {
+                const unsigned long long sm = __ballot(has);
+                if (sm) {
+                    int sbase = 0;
+                    if (lane == 0) sbase = atomicAdd(g.scount, __popcll(sm));
+                    sbase = __builtin_amdgcn_readfirstlane(sbase);
+                    if (has) g.surv[sbase + __popcll(sm & ((1ull << lane) - 1ull))] = contributed ? g.poly_cand[idx] : -1;
+                }
+            }
+        }
+        flush();
+    }
+}
+
 // Bristle friction pass (after k_eig): calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48)
 // over the polygons k_narrow kept.  One lane per kept polygon, every load is a coalesced read of consecutive slots;
 // the fan / quadrature arithmetic is the one of k_narrow, so the traction points are bit-identical.
@@ -799,8 +1172,10 @@ struct FricArgs {
     const ItemRec *items;
     const int *poly_item;
     const double *poly;
-    const int *rgn;      // region counters (word 0: kept polygons)
-    int rp_cap, pcap;    // slots per region, kRgn * rp_cap
+    const int *ccount;   // candidate count and the chunk rule (np_chunk): the kept polygons sit in per-chunk slot ranges
+    int ccap, chunk_switch;
+    const int *pcnt;     // kept polygons per chunk
+    int pcap;
     int n_items;
     unsigned *status;
     const double *res;
@@ -809,12 +1184,16 @@ struct FricArgs {
 __global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
     const int lane = threadIdx.x;
     const size_t P = (size_t)g.pcap;
-    const RgnScan rs = rgn_scan(g.rgn, 0, g.rp_cap, lane);
-    for (int w = blockIdx.x; w < rs.total; w += gridDim.x) {
-        int slot0, n_live;
-        rgn_locate(rs, w, g.rp_cap, slot0, n_live);
-        const int idx = slot0 + lane;
-        const bool active = lane < n_live;
+    int n_c = *g.ccount;
+    if (n_c > g.ccap) n_c = g.ccap;
+    const int C = np_chunk(n_c, g.chunk_switch);
+    const int n_chunk = (n_c + C - 1) / C;
+    for (int ch = blockIdx.x; ch < n_chunk; ch += gridDim.x) {
+      int cnt = __builtin_amdgcn_readfirstlane(g.pcnt[ch]);
+      if (cnt > C) cnt = C;
+      for (int p0 = 0; p0 < cnt; p0 += 64) {
+        const int idx = ch * C + p0 + lane;
+        const bool active = p0 + lane < cnt;
         double sum[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) sum[k] = 0.0;
@@ -905,6 +1284,7 @@ __global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
             }
         }
         accumulate_items<6>(g.acc, item, active, contributed, sum, kAccFric);
+      }
     }
 }
 

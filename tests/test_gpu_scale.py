@@ -353,3 +353,56 @@ def test_evaluate_sharded_with_the_hip_evaluator(pfc):
         for j, k in enumerate(p):
             assert np.array_equal(ct[j], ref[k].counts) and H.rel_err(wr[j], ref[k].wrench) < TOL
     m.close()
+
+
+def test_clip_and_integrate_split_equals_the_one_kernel_narrowphase(pfc):
+    """Option clip_min: from that many items on, the narrowphase runs as a clip-only kernel (gather, clip, polygon set-up,
+    kept polygon) followed by k_integ over the compacted polygons.  Forced on (clip_min = 1) and off (0) on scenes of
+    every kind -- regularized boxes, a bristle blob / tool batch, random and degenerate fuzz poses with mixed models and
+    tet-tet instructions -- the per-item counters must be equal and the sums agree to reduction-order accuracy; both
+    agree with the oracle."""
+    import helpers as H
+    from test_gpu_parity import _fuzz_workload
+    rng = np.random.default_rng(77)
+    worlds = [pfc.configs.c1_boxes(), pfc.configs.c2_box_on_plane(5, montecarlo=True),
+              pfc.configs.c3_blob_tool(40, seed=9, n_div_blob=7, n_div_tool=5),
+              _fuzz_workload(pfc, rng, 300, False, tet_tet=True), _fuzz_workload(pfc, rng, 300, True, tet_tet=True)]
+    for w in worlds:
+        ref = H.oracle_run(pfc, w, debug=False)
+        out = []
+        for cm in (0, 1):
+            m = pfc.configs.build_scenario(w)
+            m.set_option("fused", 0)
+            m.set_option("clip_min", cm)
+            out.append(m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids))
+            m.close()
+        assert np.array_equal(out[0][2], out[1][2]), w.name
+        for k in range(w.n_items):
+            assert np.array_equal(out[1][2][k], ref[k].counts), (w.name, k)
+        scale = max(np.abs(out[0][0]).max(), 1e-300)
+        assert np.abs(out[0][0] - out[1][0]).max() <= 1e-11 * scale, w.name
+        wref = np.array([r.wrench for r in ref])
+        assert np.abs(out[1][0] - wref).max() <= 1e-9 * max(np.abs(wref).max(), 1e-300), w.name
+        sref = np.array([r.sdot for r in ref])
+        assert np.abs(out[1][1] - sref).max() <= 1e-6 * max(np.abs(sref).max(), 1e-300), w.name
+
+
+def test_dual_evaluation_over_the_split_narrowphase(pfc):
+    """pfc_eval_dual with the value pass in clip-only + k_integ form (the list of contributing candidates is then written
+    by k_integ from the candidate index kept with every polygon): partials equal to those of the one-kernel value pass."""
+    w = pfc.configs.c3_blob_tool(24, seed=12, n_div_blob=7, n_div_tool=5)
+    rng = np.random.default_rng(5)
+    n_dir = 3
+    dp = rng.standard_normal((w.n_items, n_dir, 24)) * 1e-2
+    dt = rng.standard_normal((w.n_items, n_dir, 6))
+    ds = rng.standard_normal((w.n_items, n_dir, 6)) * 1e-3
+    out = []
+    for cm in (0, 1):
+        m = pfc.configs.build_scenario(w)
+        m.set_option("fused", 0)
+        m.set_option("clip_min", cm)
+        out.append(m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, dp, dt, ds, w.ins_ids))
+        m.close()
+    for a, b in zip(out[0], out[1]):
+        a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+        assert np.abs(a - b).max() <= 1e-9 * max(np.abs(a).max(), 1e-300)
