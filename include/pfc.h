@@ -185,7 +185,9 @@ int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, con
  * resolver; same candidate set, for A/B checks), "split_min" (default 1024; 0 = never: an evaluation of at least
  * this many items with ins_ids given is run as two concurrent halves on two streams with their own work lists, the
  * vector-ALU-bound broadphase of one half sharing the CUs with the latency-bound narrowphase of the other; results,
- * counters and stream ordering are those of the unsplit call), "poison" (diagnostic, default 0: before every
+ * counters and stream ordering are those of the unsplit call), "clip_min" (default 1024; 0 = never: a launch of at
+ * least this many items runs the narrowphase as a clip-only kernel that keeps every clipped polygon, followed by the
+ * integration over the compacted polygons; same results up to the order of the sums), "poison" (diagnostic, default 0: before every
  * evaluation the work lists are filled with entries whose item index is -1; the kernels never follow an item index
  * out of range but report it, PFC_ERR_STATE "a work-list slot was read before it was written"), "fused" (default 1:
  * an evaluation of <= 256 items over small trees runs as ONE kernel, one workgroup per item, instead of the batched

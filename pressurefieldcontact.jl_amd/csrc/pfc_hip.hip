@@ -271,7 +271,7 @@ struct pfc_context {
     int fu_ndir = 0;
     bool pending_fused = false, last_fused = false;
     int opt_split_min = 1024;          // 0: never split
-    int opt_clip_min = 256;            // items from which the narrowphase runs as clip-only kernel + k_integ; 0: never
+    int opt_clip_min = 1024;           // items per launch from which the narrowphase runs as clip-only kernel + k_integ (break-even between 512 and 1024 C3 poses, scripts/sweep_clip.sh); 0: never
     int opt_poison = 0;                // diagnostic: fill (re)allocated work lists with 0xFF bytes (item index -1)
     int split_n0 = 0;                  // items in the first half of the pending evaluation (0: not split)
     int last_parts = 1;                // 2 if the last checked evaluation ran as two halves

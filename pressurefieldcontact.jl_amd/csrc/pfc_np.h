@@ -1014,19 +1014,20 @@ __global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
                 cen = mk3(o[3 * P], o[4 * P], o[5 * P]);
                 er0 = o[6 * P]; er1 = o[7 * P]; er2 = o[8 * P]; er3 = o[9 * P];
             }
-            bool contributed = false, lane_reg = false;
+            // the item's constants per lane (vector loads issued together with the polygon's: no dependent scalar round trip)
+            const ItemRec *it = g.items + (has ? item : 0);
+            const bool lane_reg = it->model == PFC_REGULARIZED;
+            const int nq = it->nq;
+            const V3 w = ld3(it->w), vl = ld3(it->v);
+            const double chi = it->chi, Ebar = it->Ebar;
+            bool contributed = false;
             unsigned long long todo = __ballot(has);
             while (todo) {     // the runs of equal items of this piece (one, two at a run boundary of the candidate list)
                 const int f = __builtin_ctzll(todo);
                 const int run_item = __builtin_amdgcn_readlane(item, f);
                 const bool in_run = has && item == run_item;
                 todo &= ~__ballot(in_run);
-                // the item's constants through the scalar path: run_item is uniform
-                const ItemRec *it = g.items + run_item;
-                const bool reg = it->model == PFC_REGULARIZED;
-                const int nq = it->nq;
-                const V3 w = ld3(it->w), vl = ld3(it->v);
-                const double chi = it->chi, Ebar = it->Ebar;
+                const bool reg = __builtin_amdgcn_readlane((int)lane_reg, f) != 0;
                 if (run_item != cur) {
                     flush();
                     cur = run_item;
@@ -1041,7 +1042,6 @@ __global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
                     }
                 }
                 if (!in_run) continue;
-                lane_reg = reg;
                 int ntl = 0;
                 V3 v2 = mk3(o[(10 + 3 * (n - 1)) * P], o[(11 + 3 * (n - 1)) * P], o[(12 + 3 * (n - 1)) * P]);
                 V3 vn = mk3(o[10 * P], o[11 * P], o[12 * P]);
