@@ -329,7 +329,8 @@ def main():
         parts_n = parts_prof
         # SURVEY §8(d) accounting: algorithmic bytes / kernel time against the HBM peak (well below 1: these kernels re-read
         # their 64..256-byte records from L2 / Infinity Cache and are bound by vector issue, see "valu").
-        roof_np = {"kernel": "k_narrow<false, false>", "bound": "hbm",
+        roof_np = {"kernel": "k_narrow<false, 2> + k_integ (the narrowphase of a big batch: clip-only kernel, then the integration "
+                             "over the kept polygons; ms_per_launch covers both, HIP events around the pair)", "bound": "hbm",
                    "achieved": BYTES_PER_OP * st_prof["candidates"] / parts_n / (np_ms * 1e-3) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms_per_launch": np_ms,
                    "units_per_launch": st_prof["candidates"] / parts_n, "bytes_per_unit": BYTES_PER_OP}
@@ -350,11 +351,13 @@ def main():
                 # v_pk_fma_f32 4.2, the integer add/logic/shift mix 3.4 (taken for every instruction the mix counters do not
                 # classify: moves, selects, compares, conversions).  Mix from SQ_INSTS_VALU_{ADD,MUL,FMA}_F32/F64 (pmc_valu.json).
                 CYC_F32, CYC_F64, CYC_OTHER = 2.4, 4.2, 3.4
+                def vsum(kname, suffix):       # the narrowphase is two kernels: k_narrow (clip) + k_integ
+                    ks = ("k_narrow", "k_integ") if kname == "k_narrow" else (kname,)
+                    return sum(vj.get(f"{k}_{suffix}", 0) for k in ks)
                 for r, kname, unit_key in ((roof_bp, "k_bp_dfs32", "node_tests"), (roof_np, "k_narrow", "candidates")):
-                    key = kname + "_valu_insts"
-                    n_valu = vj[key]
-                    f32 = sum(vj.get(f"{kname}_valu_{t}_f32", 0) for t in ("add", "mul", "fma"))
-                    f64 = sum(vj.get(f"{kname}_valu_{t}_f64", 0) for t in ("add", "mul", "fma", "trans"))
+                    n_valu = vsum(kname, "valu_insts")
+                    f32 = sum(vsum(kname, f"valu_{t}_f32") for t in ("add", "mul", "fma"))
+                    f64 = sum(vsum(kname, f"valu_{t}_f64") for t in ("add", "mul", "fma", "trans"))
                     have_mix = (kname + "_valu_fma_f64") in vj
                     if have_mix:
                         cyc = (f32 * CYC_F32 + f64 * CYC_F64 + (n_valu - f32 - f64) * CYC_OTHER) / n_valu
@@ -363,15 +366,16 @@ def main():
                     per_unit = n_valu / vj[unit_key]
                     issue_ms = per_unit * r["units_per_launch"] * cyc / (N_SIMD * CLOCK_HZ) * 1e3
                     aia = kname + "_active_inst_any_cycles"
+                    aia_v = vsum(kname, "active_inst_any_cycles")
                     r["valu"] = {"wave_instructions_per_unit": per_unit, "cycles_per_instruction": cyc,
                                  "mix": {"f32": f32 / n_valu, "f64": f64 / n_valu, "other": 1.0 - (f32 + f64) / n_valu} if have_mix else None,
-                                 "active_lanes_per_instruction": (vj[kname + "_valu_thread_cycles"] / n_valu
+                                 "active_lanes_per_instruction": (vsum(kname, "valu_thread_cycles") / n_valu
                                                                   if (kname + "_valu_thread_cycles") in vj else None),
                                  "issue_bound_ms": issue_ms, "frac_of_issue_peak": issue_ms / r["ms_per_launch"],
                                  # SQ_ACTIVE_INST_ANY (quad-cycles, summed over WAVES) over the SIMD-cycles of a launch: the mean
                                  # number of this kernel's waves per SIMD that have an instruction of any type (VALU, SALU, LDS,
                                  # VMEM) in flight; it is a sum over resident waves, so it is not capped at 1
-                                 "waves_with_inst_in_flight_per_simd": (vj[aia] / parts_n * 4.0 /
+                                 "waves_with_inst_in_flight_per_simd": (aia_v / parts_n * 4.0 /
                                                                         (N_SIMD * CLOCK_HZ * r["ms_per_launch"] * 1e-3)) if aia in vj else None,
                                  "note": "issue cost per wave64 VALU instruction weighted by the measured instruction mix (Float32 2.4, "
                                          "Float64 4.2, other 3.4 cycles: profiles/r02_valu_rate.txt); 1024 SIMDs, 2.4 GHz; counts from "

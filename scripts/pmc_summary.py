@@ -3,13 +3,26 @@ WRITE_SIZE totals (KB as reported) and the per-launch traffic bench.py reports a
 usage: python scripts/pmc_summary.py <tag> [round]      reads gpurun_out/<tag>_{fetch,write,stats}"""
 import csv, glob, json, os, re, shutil, sys
 
+
+def newest_per_dir(pattern):
+    """gpurun merges every call's output into the same directories: keep only the newest file of each directory, so
+    that counters of an earlier build never mix with the current one's"""
+    best = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
+
 tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 raw = {}
 for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     acc = {}
-    for f in glob.glob(os.path.join(root, "gpurun_out", f"{tag}_{sub}", "**", "*counter_collection.csv"), recursive=True):
+    for f in newest_per_dir(os.path.join(root, "gpurun_out", f"{tag}_{sub}", "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != ctr:
                 continue
@@ -32,19 +45,21 @@ def per_launch(name):
                      raw["WRITE_SIZE"].get(name, {}).get("per_call_KB", 0.0))
 
 out = {"k_bp_dfs32_bytes_per_launch": per_launch("pfc::k_bp_dfs32") + per_launch("pfc::k_bp_dfs") + per_launch("pfc::k_bp_expand"),
-       "k_narrow0_bytes_per_launch": per_launch("void pfc::k_narrow<false, false>"),
+       "k_narrow0_bytes_per_launch": per_launch("void pfc::k_narrow<false, 2>") + per_launch("pfc::k_integ"),
+       "k_narrow_clip_bytes_per_launch": per_launch("void pfc::k_narrow<false, 2>"),
+       "k_integ_bytes_per_launch": per_launch("pfc::k_integ"),
        "k_fric_bytes_per_launch": per_launch("pfc::k_fric"),
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch of bench.py's default workload "
                "(8192 poses as two concurrent 4096-pose halves: a launch covers one half); bytes = 1024 x (2 x FETCH_SIZE "
                "+ WRITE_SIZE): the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies 128-byte line fills at "
                "64 B); Infinity-Cache hits are counted, so this is memory-side traffic of the L2, an upper bound of HBM bytes"}
 json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
-for f in glob.glob(os.path.join(root, "gpurun_out", f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True):
+for f in newest_per_dir(os.path.join(root, "gpurun_out", f"{tag}_stats", "**", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(root, "profiles", f"{rnd}_kernel_stats.csv"))
 # rocprofv3's own summary averages over ALL launches, including the few of the first step that ran on truncated work
 # lists (buffers still growing); the steady-state averages below are the ones bench.py's HIP-event times agree with
 steady = {}
-for f in glob.glob(os.path.join(root, "gpurun_out", f"{tag}_stats", "**", "*kernel_trace.csv"), recursive=True):
+for f in newest_per_dir(os.path.join(root, "gpurun_out", f"{tag}_stats", "**", "*kernel_trace.csv")):
     dur = {}
     for row in csv.DictReader(open(f)):
         dur.setdefault(re.sub(r"\(.*", "", row["Kernel_Name"]), []).append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))

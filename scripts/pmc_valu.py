@@ -2,12 +2,25 @@
 unit counts of a bench line.  usage: python scripts/pmc_valu.py <tag>[,<tag2>...] <bench.json>
 Values are PER STEP: parts x the per-launch averages (a split step launches every kernel once per half)."""
 import csv, glob, json, os, re, sys, collections
+
+
+def newest_per_dir(pattern):
+    """gpurun merges every call's output into the same directories: keep only the newest file of each directory, so
+    that counters of an earlier build never mix with the current one's"""
+    best = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, bench = sys.argv[1], json.load(open(sys.argv[2]))
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for tg in tag.split(","):
     seen = set()       # a counter that several groups of one tag collected is taken from the first group only
-    for f in sorted(glob.glob(os.path.join(root, "gpurun_out", tg + "_g*", "**", "*counter_collection.csv"), recursive=True)):
+    for f in newest_per_dir(os.path.join(root, "gpurun_out", tg + "_g*", "**", "*counter_collection.csv")):
         mine = set()
         for row in csv.DictReader(open(f)):
             if (tg, row["Counter_Name"]) in seen:
@@ -32,7 +45,8 @@ out = {"source": "rocprofv3 --pmc (scripts/pmc_probe.sh, one counter group per p
                  f"({int(bench['config'].get('items_per_step', bench['config'].get('poses_per_gpu', 0)))} poses as {parts} concurrent part(s)); PER STEP = {parts} x the per-launch averages",
        "measured": "round 2",
        "node_tests": int(bench["config"]["node_tests_per_step"]), "candidates": int(bench["config"]["ops_per_step"])}
-for kern, name in (("pfc::k_bp_dfs32", "k_bp_dfs32"), ("void pfc::k_narrow<false, false>", "k_narrow"), ("pfc::k_fric", "k_fric")):
+for kern, name in (("pfc::k_bp_dfs32", "k_bp_dfs32"), ("void pfc::k_narrow<false, 2>", "k_narrow"), ("pfc::k_integ", "k_integ"),
+                   ("pfc::k_fric", "k_fric")):
     for ctr, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAIT_ANY", "wait_any_cycles"),
                      ("SQ_WAIT_INST_ANY", "wait_inst_any_cycles"), ("SQ_ACTIVE_INST_ANY", "active_inst_any_cycles"),
                      ("SQ_INSTS_SALU", "salu_insts"), ("SQ_INSTS_LDS", "lds_insts"), ("TCC_HIT_sum", "tcc_hit"), ("TCC_MISS_sum", "tcc_miss"),
