@@ -143,6 +143,19 @@ int pfc_eval_dual_device(pfc_handle h, int n_items, int n_dir, const int *d_ins_
                          int *d_counts, void *stream);
 
 /*
+ * Further seed directions AT THE POINT OF THE PREVIOUS pfc_eval_dual_device evaluation of this handle: the chunks of one
+ * Jacobian (update of the Radau iteration matrix: ceil(NX / N_chunk) Dual evaluations with the same values and different
+ * partials, src/radau/radau_functions.jl:2-14).  Only the Dual passes run; candidates, contributing pairs and per-item
+ * results of that evaluation's value pass are reused, its value outputs are not written again.  n_dir may differ from the
+ * first call.  Requires that pfc_check() returned PFC_OK for that evaluation and that nothing else was evaluated on the
+ * handle since (PFC_ERR_STATE otherwise); follow with pfc_check() (synchronises; no speculation: it cannot ask for a
+ * re-issue).  pfc_eval_dual applies the same reuse by itself when the value inputs of a call equal, bit for bit, those
+ * of the previous call (option "dual_reuse", default 1).
+ */
+int pfc_eval_dual_device_more(pfc_handle h, int n_dir, const double *d_dpose, const double *d_dtwist, const double *d_ds,
+                              double *d_dwrench, double *d_dsdot, void *stream);
+
+/*
  * eMesh_to_tree (src/geometry/blob_types.jl:136-173) on the host: builds the flattened binary OBB tree that
  * pfc_add_mesh takes.  method PFC_TREE_BLOB follows the reference (bottom-up merging of face/edge-adjacent blobs by
  * marginal cost :74-134, median-split top-down over the remaining blobs src/geometry/top_down.jl:10-32, tight leaf
@@ -185,7 +198,9 @@ int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, con
  * resolver; same candidate set, for A/B checks), "split_min" (default 1024; 0 = never: an evaluation of at least
  * this many items with ins_ids given is run as two concurrent halves on two streams with their own work lists, the
  * vector-ALU-bound broadphase of one half sharing the CUs with the latency-bound narrowphase of the other; results,
- * counters and stream ordering are those of the unsplit call), "clip_min" (default 1024; 0 = never: a launch of at
+ * counters and stream ordering are those of the unsplit call), "dual_reuse" (default 1: pfc_eval_dual compares the
+ * value inputs of a call above the small-scene limits with those of the previous call and, if they are bitwise equal,
+ * runs only the Dual passes on the previous call's value pass -- the chunks of one Jacobian), "clip_min" (default 1024; 0 = never: a launch of at
  * least this many items runs the narrowphase as a clip-only kernel that keeps every clipped polygon, followed by the
  * integration over the compacted polygons; same results up to the order of the sums), "poison" (diagnostic, default 0: before every
  * evaluation the work lists are filled with entries whose item index is -1; the kernels never follow an item index
@@ -206,6 +221,8 @@ int pfc_get_stats(pfc_handle h, long long *out8);
 int pfc_get_stage_ms(pfc_handle h, float *out6);
 int pfc_last_parts(pfc_handle h);   /* 1, or 2 if the last checked evaluation ran as two concurrent halves; 0: it ran as the
                                      * single fused small-scene kernel (option "fused") */
+int pfc_last_dual_reused(pfc_handle h);   /* 1 if the last Dual evaluation ran only its Dual passes on the value pass of the
+                                             previous one (pfc_eval_dual_device_more, or pfc_eval_dual with equal value inputs) */
 
 /*
  * Debug views of the last evaluation (debug option), needed to restate test/test_normal.jl:31-41 and

@@ -280,7 +280,13 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
         cw.item = 0; cw.a = 0; cw.b = 0; cw.pad = 0;
         int ci = -1;
         if (active) ci = g.surv[idx];   // -1: the pair had a polygon but did not contribute in the value pass
+        if (ci >= g.ccap) { atomicOr(g.status, kStHole); ci = -1; }      // not an index the value pass writes: reported, never followed
         if (ci >= 0) cw = g.cand[ci];
+        if ((unsigned)cw.item >= (unsigned)g.n_items) {                  // an unwritten (or overwritten) candidate slot
+            atomicOr(g.status, kStHole);
+            cw.item = 0; cw.a = 0; cw.b = 0;
+            ci = -1;
+        }
         const ItemRec *it = g.items + cw.item;
         const GTetRec *tp = (const GTetRec *)(it->tet + cw.b);
         const bool reg = it->model == PFC_REGULARIZED;

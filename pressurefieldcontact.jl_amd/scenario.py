@@ -357,6 +357,13 @@ class MechanismScenario:
                                                     d_s or None, d_dpose, d_dtwist, d_ds or None, d_wrench, d_sdot,
                                                     d_dwrench, d_dsdot, d_counts or None, stream or None))
 
+    def eval_dual_device_more(self, n_dir: int, d_dpose: int, d_dtwist: int, d_ds: int, d_dwrench: int, d_dsdot: int,
+                              stream: int = 0):
+        """pfc_eval_dual_device_more: further seed directions at the point of the previous eval_dual_device evaluation
+        (the chunks of one Jacobian); only the Dual passes run.  Follow with check()."""
+        self._check(_lib.lib().pfc_eval_dual_device_more(self._h, int(n_dir), d_dpose, d_dtwist, d_ds or None, d_dwrench,
+                                                         d_dsdot, stream or None))
+
     def check(self) -> int:
         """pfc_check: synchronise; returns the status (PFC_ERR_OVERFLOW means: re-issue, buffers were grown)."""
         rc = _lib.lib().pfc_check(self._h)
@@ -374,6 +381,10 @@ class MechanismScenario:
         """1, or 2 if the last checked evaluation ran as two concurrent halves (option split_min); 0 if it ran as the
         single fused small-scene kernel (option fused)."""
         return int(_lib.lib().pfc_last_parts(self._h))
+
+    def last_dual_reused(self) -> bool:
+        """True if the last Dual evaluation ran only its Dual passes on the previous one's value pass."""
+        return bool(_lib.lib().pfc_last_dual_reused(self._h))
 
     def stage_ms(self) -> dict:
         out = (C.c_float * 6)()

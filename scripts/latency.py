@@ -42,6 +42,12 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
         return m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
     dd = med(pair, blocks=6, per=10)[0] - dt
     print(f"{'':45s} {dd*1e6:9.1f} us/Dual eval (6 partials)")
+    # the further chunks of a Jacobian: same values, other partials (src/radau/radau_functions.jl:2-14)
+    def again():
+        return m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *dz, w.ins_ids)
+    again()
+    da = med(again, blocks=6, per=10)[0]
+    print(f"{'':45s} {da*1e6:9.1f} us/further Dual eval at the same point (value pass reused: {m.last_dual_reused()})")
     # device-resident Dual evaluation (pfc_eval_dual_device + pfc_check): what the host-buffer figure above pays on top is
     # 288 B per (item, direction) of seeds over PCIe and the staging copies
     try:
@@ -62,6 +68,11 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
         for _ in range(5):
             dual_dev()
         print(f"{'':45s} {med(dual_dev, blocks=6, per=10)[0] * 1e6:9.1f} us/Dual eval (6 partials), device-resident buffers")
+        def more_dev():
+            m.eval_dual_device_more(nd, t[4].data_ptr(), t[5].data_ptr(), t[6].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), st)
+            m.check()
+        dual_dev()
+        print(f"{'':45s} {med(more_dev, blocks=6, per=10)[0] * 1e6:9.1f} us/further Dual eval, device-resident (pfc_eval_dual_device_more)")
     except ImportError:
         pass
     m.close()

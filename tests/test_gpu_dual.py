@@ -271,3 +271,155 @@ def test_dual_large_batch_one_sync_equals_two_stage(pfc):
     assert np.array_equal(a[4], b[4])
     for x, y, tol in ((a[0], b[0], 1e-11), (a[1], b[1], 1e-7), (a[2], b[2], 1e-9), (a[3], b[3], 1e-6)):
         np.testing.assert_allclose(y, x, rtol=tol, atol=tol * max(np.abs(x).max(), 1e-300))
+
+
+def test_jacobian_chunks_reuse_the_value_pass(pfc):
+    """The chunks of one Jacobian (src/radau/radau_functions.jl:2-14): Dual evaluations with the same values and different
+    partials.  pfc_eval_dual recognises bitwise-equal value inputs and runs only the Dual passes on the previous call's
+    value pass (option dual_reuse); every call must equal a fresh handle's full evaluation, a changed value input must
+    not be mistaken for a repeat, and a different number of directions may follow."""
+    rng = np.random.default_rng(31)
+    w = pfc.configs.c3_blob_tool(700, n_div_blob=6, n_div_tool=5)
+    n = w.n_items
+
+    def seeds(nd):
+        return (rng.standard_normal((n, nd, 24)) * 1e-2, rng.standard_normal((n, nd, 6)) * 0.1,
+                rng.standard_normal((n, nd, 6)) * 1e-3)
+
+    def fresh(pose, twist, s, sd):
+        f = pfc.configs.build_scenario(w)
+        f.set_option("dual_reuse", 0)
+        out = f.force_all_elastic_intersections_dual(pose, twist, s, *sd, w.ins_ids)
+        f.close()
+        return out
+
+    def same(a, b):
+        assert np.array_equal(a[4], b[4])
+        for x, y, tol in ((a[0], b[0], 1e-11), (a[1], b[1], 1e-7), (a[2], b[2], 1e-9), (a[3], b[3], 1e-6)):
+            np.testing.assert_allclose(y, x, rtol=tol, atol=tol * max(np.abs(x).max(), 1e-300))
+
+    m = pfc.configs.build_scenario(w)
+    stats = []
+    pose2 = w.pose.copy()
+    pose2[5, 21] += 1e-9            # one translation component of one item, far below any tolerance of the comparison
+    for pose, nd in ((w.pose, 6), (w.pose, 6), (w.pose, 3), (pose2, 6), (pose2, 2), (w.pose, 6)):
+        sd = seeds(nd)
+        got = m.force_all_elastic_intersections_dual(pose, w.twist, w.s, *sd, w.ins_ids)
+        stats.append(m.last_dual_reused())
+        same(fresh(pose, w.twist, w.s, sd), got)
+    assert stats == [False, True, True, False, True, False], stats
+    # the repeat of a point is cheaper than its first evaluation (only the Dual passes run): timing is not asserted, the
+    # path is: a value evaluation in between must end the reuse (the handle's device state is overwritten)
+    sd = seeds(6)
+    a = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd, w.ins_ids)
+    m.force_all_elastic_intersections(pose2, w.twist, w.s, w.ins_ids)
+    b = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd, w.ins_ids)
+    assert not m.last_dual_reused()
+    same(a, b)
+    m.close()
+
+
+def test_dual_device_more_directions(pfc):
+    """pfc_eval_dual_device_more: further seed directions on the value pass of the previous pfc_eval_dual_device
+    evaluation; refused (PFC_ERR_STATE) without one or after another evaluation."""
+    import torch
+    rng = np.random.default_rng(37)
+    w = pfc.configs.c3_blob_tool(40, n_div_blob=8, n_div_tool=6)
+    n = w.n_items
+    dev = torch.device("cuda", 0)
+    T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    t_ins, t_pose, t_tw, t_s = T(w.ins_ids, torch.int32), T(w.pose), T(w.twist), T(w.s)
+    o_w, o_sd = torch.zeros((n, 6), dtype=torch.float64, device=dev), torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    o_ct = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    m = pfc.configs.build_scenario(w)
+
+    def seeds(nd):
+        return (rng.standard_normal((n, nd, 24)) * 1e-2, rng.standard_normal((n, nd, 6)) * 0.1,
+                rng.standard_normal((n, nd, 6)) * 1e-3)
+
+    def ref(sd):
+        f = pfc.configs.build_scenario(w)
+        f.set_option("dual_reuse", 0)
+        out = f.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd, w.ins_ids)
+        f.close()
+        return out
+
+    sd0 = seeds(6)
+    t0 = [T(x) for x in sd0]
+    o_dw = torch.zeros((n, 6, 6), dtype=torch.float64, device=dev); o_dsd = torch.zeros_like(o_dw)
+    with pytest.raises(Exception):           # nothing to extend yet
+        m.eval_dual_device_more(6, t0[0].data_ptr(), t0[1].data_ptr(), t0[2].data_ptr(), o_dw.data_ptr(), o_dsd.data_ptr(), stream)
+    for k in range(40):
+        m.eval_dual_device(n, 6, t_ins.data_ptr(), t_pose.data_ptr(), t_tw.data_ptr(), t_s.data_ptr(), t0[0].data_ptr(),
+                           t0[1].data_ptr(), t0[2].data_ptr(), o_w.data_ptr(), o_sd.data_ptr(), o_dw.data_ptr(), o_dsd.data_ptr(),
+                           o_ct.data_ptr(), stream)
+        if m.check() == 0:
+            break
+    for nd in (6, 4, 9):
+        sd = seeds(nd)
+        t = [T(x) for x in sd]
+        dw = torch.zeros((n, nd, 6), dtype=torch.float64, device=dev); dsd = torch.zeros_like(dw)
+        m.eval_dual_device_more(nd, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), dw.data_ptr(), dsd.data_ptr(), stream)
+        assert m.check() == 0
+        want = ref(sd)
+        np.testing.assert_allclose(dw.cpu().numpy(), want[2], rtol=1e-9, atol=1e-9 * np.abs(want[2]).max())
+        np.testing.assert_allclose(dsd.cpu().numpy(), want[3], rtol=1e-6, atol=1e-6 * np.abs(want[3]).max())
+    # a value evaluation ends it
+    m.eval_device(n, t_ins.data_ptr(), t_pose.data_ptr(), t_tw.data_ptr(), t_s.data_ptr(), o_w.data_ptr(), o_sd.data_ptr(),
+                  o_ct.data_ptr(), stream)
+    assert m.check() == 0
+    with pytest.raises(Exception):
+        m.eval_dual_device_more(6, t0[0].data_ptr(), t0[1].data_ptr(), t0[2].data_ptr(), o_dw.data_ptr(), o_dsd.data_ptr(), stream)
+    m.close()
+
+
+@pytest.mark.parametrize("poison", [0, 1])
+@pytest.mark.parametrize("cfg", ["c1", "c2", "pencil", "c3pose"])
+def test_jacobian_chunks_on_small_scenes(pfc, cfg, poison):
+    """The same reuse on the small-scene paths: the first Dual evaluation of a point runs in the all-in-one kernel
+    (regularized scenes) or as fused value kernel + batched Dual passes (bristle); a repeat of the point takes the
+    hybrid path, which hands its lists over, and the chunks after it run only the Dual passes.  Every call equals a fresh
+    handle's evaluation; value evaluations in between end the reuse.  poison = 1: the work lists are refilled with
+    entries that must never be followed before every evaluation -- but not before a reuse, whose lists they are (a first
+    version did, and the Dual narrowphase followed the poisoned candidates: GPU memory fault, found by scripts/soak.py)."""
+    rng = np.random.default_rng(41)
+    if cfg == "c1":
+        w = pfc.configs.c1_boxes()
+    elif cfg == "c2":
+        w = pfc.configs.c2_box_on_plane(3, montecarlo=True)
+    elif cfg == "pencil":
+        w = pfc.configs.c3_blob_tool(2, seed=3, n_div_blob=5, n_div_tool=4)       # bristle, small trees
+    else:
+        w = pfc.configs.c3_blob_tool(3, seed=4)       # the full-size meshes: beyond the fused kernel, the one-graph path
+    n = w.n_items
+
+    def seeds(nd):
+        return (rng.standard_normal((n, nd, 24)) * 1e-2, rng.standard_normal((n, nd, 6)) * 0.1,
+                rng.standard_normal((n, nd, 6)) * 1e-3)
+
+    def fresh(sd):
+        f = pfc.configs.build_scenario(w)
+        f.set_option("dual_reuse", 0)
+        f.set_option("fused", 0)
+        out = f.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd, w.ins_ids)
+        f.close()
+        return out
+
+    m = pfc.configs.build_scenario(w)
+    m.set_option("poison", poison)
+    flags = []
+    for k, nd in enumerate((6, 6, 6, 3, 6)):
+        sd = seeds(nd)
+        got = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd, w.ins_ids)
+        flags.append(m.last_dual_reused())
+        want = fresh(sd)
+        assert np.array_equal(got[4], want[4])
+        for x, y, tol in ((want[0], got[0], 1e-10), (want[1], got[1], 1e-6), (want[2], got[2], 1e-8), (want[3], got[3], 1e-5)):
+            np.testing.assert_allclose(y, x, rtol=tol, atol=tol * max(np.abs(x).max(), 1e-300))
+    assert flags[0] is False and flags[-1] is True and flags[-2] is True, flags
+    m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    sd = seeds(6)
+    m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd, w.ins_ids)
+    assert not m.last_dual_reused()
+    m.close()
