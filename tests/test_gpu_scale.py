@@ -406,3 +406,44 @@ def test_dual_evaluation_over_the_split_narrowphase(pfc):
     for a, b in zip(out[0], out[1]):
         a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
         assert np.abs(a - b).max() <= 1e-9 * max(np.abs(a).max(), 1e-300)
+
+
+def test_split_narrowphase_on_many_small_mixed_items(pfc):
+    """20 000 fuzz items (four small meshes, regularized / bristle / tet-tet instructions mixed at random, ~100 candidates
+    each): more than a million candidates, so the candidate chunks are 512 wide and a 64-polygon piece of k_integ holds
+    the runs of several items of different friction models -- the path a big single-instruction batch never takes.  The
+    split narrowphase must reproduce the one-kernel narrowphase (itself checked against the oracle on subsets of these
+    workloads by the fuzz tests): per-item counters equal, sums to reduction-order accuracy; a sample of items is checked
+    against the oracle directly."""
+    import helpers as H
+    from test_gpu_parity import _fuzz_workload
+    rng = np.random.default_rng(4242)
+    w = _fuzz_workload(pfc, rng, 20000, False, tet_tet=True)
+    out = []
+    for cm in (0, 1024):
+        m = pfc.configs.build_scenario(w)
+        m.set_option("clip_min", cm)
+        out.append(m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids))
+        if cm:
+            assert m.stats()["candidates"] >= 512 * 2048, m.stats()       # wide chunks were in use
+        m.close()
+    assert np.array_equal(out[0][2], out[1][2])
+    scale = np.abs(out[0][0]).max()
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-11 * scale
+    # sdot of a bristle item is conditioned like its patch stiffness (DESIGN.md section 5.7): 1e-6 per item, except for sliver
+    # contacts whose K-bar has two or more eigenvalues at the rounding level of K (there the reference's own sdot moves by
+    # as much under a perturbation of K by its backward error, tests/test_sdot_sensitivity.py)
+    ds = np.abs(out[0][1] - out[1][1]).max(axis=1)
+    rel = ds / np.maximum(np.abs(out[0][1]).max(axis=1), 1e-300)
+    loose = np.flatnonzero(rel > 1e-6)
+    assert len(loose) <= w.n_items // 500, len(loose)
+    for r, k in zip(H.oracle_run(pfc, w, items=loose, debug=True), loose):
+        assert r.has_K and rel[k] < 5e-3, (k, rel[k])
+        Kb = np.diag(r.Sinv) @ r.K @ np.diag(r.Sinv)
+        ev = np.linalg.eigvalsh((Kb + Kb.T) / 2)
+        assert np.sum(ev < 1e-12 * ev[-1]) >= 2, (k, rel[k], ev)
+    items = rng.choice(w.n_items, 40, replace=False)
+    ref = H.oracle_run(pfc, w, items=items, debug=False)
+    for r, k in zip(ref, items):
+        assert np.array_equal(out[1][2][k], r.counts), k
+        assert np.abs(out[1][0][k] - r.wrench).max() <= 1e-9 * max(np.abs(r.wrench).max(), 1e-300), k
