@@ -741,31 +741,11 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                 const V3 v1 = mk3(FR(pt, rb, km, 0), FR(pt, rb, km, 1), FR(pt, rb, km, 2));
                 const V3 v2 = mk3(FR(pt, rb, k, 0), FR(pt, rb, k, 1), FR(pt, rb, k, 2));
                 const double er0 = s_epsr[0][pt], er1 = s_epsr[1][pt], er2 = s_epsr[2][pt], er3 = s_epsr[3][pt];
-                const double area = triangle_area(v1, v2, cen, nh);
-                if (!(0.0 < area)) continue;  // :232
                 double tW = 0.0, tm[3] = {0.0, 0.0, 0.0}, tq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                for (int q = 0; q < nq; ++q) {
-                    // TriTetQuadRule rules 1 and 2, literal decimals of src/clip/quadrature.jl:24-39
-                    double q0, q1, q2, qw;
-                    if (nq == 1) {
-                        q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
-                    } else {
-                        const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
-                        q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
-                        qw = 0.33333333333333331483;
-                    }
-                    // fillTractionCacheInnerLoop! (:251-265)
-                    const V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
-                                     (v1.z * q0 + v2.z * q1) + cen.z * q2);
-                    double eq = __builtin_fma(er0, r.x, er3);
-                    eq = __builtin_fma(er1, r.y, eq);
-                    eq = __builtin_fma(er2, r.z, eq);
-                    const V3 rdot = vl + cross(w, r);
-                    const double ee = -dot(mk3(er0, er1, er2), rdot);
-                    const double damp = fmax(0.0, 1.0 + chi * ee);
-                    const double p = eq * Ebar * damp;
-                    const double dA = qw * area;
-                    if (!(0.0 < p)) continue;  // :245
+                PointParams pp;
+                pp.w = w; pp.vl = vl; pp.chi = chi; pp.Ebar = Ebar; pp.er0 = er0; pp.er1 = er1; pp.er2 = er2; pp.er3 = er3; pp.nq = nq;
+                // the traction points of this fan triangle: the shared statement of r, p, dA (fan_triangle_points, pfc_kernels.h)
+                const int n_pt = fan_triangle_points(pp, v1, v2, cen, nh, [&](const V3 &r, const V3 &rdot, double p, double dA) {
                     const double p_dA = p * dA;
                     if (pass == 0) {
                         ++my_nt;
@@ -829,7 +809,8 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                         acc[0] += ta.x; acc[1] += ta.y; acc[2] += ta.z;
                         acc[3] += Tc.x; acc[4] += Tc.y; acc[5] += Tc.z;
                     }
-                }
+                });
+                if (n_pt == 0) continue;
                 if (pass == 0 && !reg) {
                     const V3 Sr = mk3(tm[0] + tW * cen.x, tm[1] + tW * cen.y, tm[2] + tW * cen.z);   // sum w r
                     const V3 ta = cross(Sr, nh);

@@ -338,6 +338,49 @@ __device__ __forceinline__ int sat15_f32(const double *ea64, const double *eb64,
     return sep ? 0 : (hit ? 1 : 2);
 }
 
+// The traction points of ONE fan triangle (v1, v2, polygon centroid): fillTractionCacheForTriangle! +
+// fillTractionCacheInnerLoop! (src/contact_algorithms_non_friction.jl:236-265) with TriTetQuadRule rules 1 and 2 (literal
+// decimals of src/clip/quadrature.jl:24-39).  The ONE statement of r, p and dA shared by every value kernel (k_narrow,
+// k_integ, k_fric, k_fused): the per-item traction counts and the bit-identity of the traction points between the
+// passes rest on these expressions being the same everywhere.  body(r, rdot, p, dA) is called for every point with
+// 0 < p (:245); returns the number of such points.
+struct PointParams {
+    V3 w, vl;                          // twist of the item: angular, linear
+    double chi, Ebar, er0, er1, er2, er3;   // damping, modulus, the tet's strain row eps_r2
+    int nq;                            // quadrature points per triangle: 1 or 3
+};
+template <class F>
+__device__ __forceinline__ int fan_triangle_points(const PointParams &c, const V3 &v1, const V3 &v2, const V3 &cen, const V3 &nh,
+                                                   F &&body) {
+    const double area = triangle_area(v1, v2, cen, nh);
+    if (!(0.0 < area)) return 0;       // :232
+    int n_pt = 0;
+    for (int q = 0; q < c.nq; ++q) {
+        double q0, q1, q2, qw;
+        if (c.nq == 1) {
+            q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
+        } else {
+            const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
+            q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
+            qw = 0.33333333333333331483;
+        }
+        const V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
+                         (v1.z * q0 + v2.z * q1) + cen.z * q2);
+        double eq = __builtin_fma(c.er0, r.x, c.er3);
+        eq = __builtin_fma(c.er1, r.y, eq);
+        eq = __builtin_fma(c.er2, r.z, eq);
+        const V3 rdot = c.vl + cross(c.w, r);
+        const double ee = -dot(mk3(c.er0, c.er1, c.er2), rdot);
+        const double damp = fmax(0.0, 1.0 + c.chi * ee);
+        const double p = eq * c.Ebar * damp;
+        const double dA = qw * area;
+        if (!(0.0 < p)) continue;      // :245
+        ++n_pt;
+        body(r, rdot, p, dA);
+    }
+    return n_pt;
+}
+
 // The 15 axes on Float32 inputs with a caller-supplied error radius E (see k_bp_dfs32).
 // returns 0 = separated, 1 = overlapping, 2 = undecided.  "Some axis has d > E" and "every axis has d < -E" are both
 // statements about max d, so only the maximum is carried (v_max3_f32: 8 instructions instead of 30 compares and as many

@@ -589,40 +589,18 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             const bool store = DBG && materialise && (tbase + slots <= g.tcap);
             if (DBG && materialise && !store) atomicOr(g.status, kStTracOvf);
             int tpos = tbase;
+            PointParams pp;
+            pp.w = w; pp.vl = vl; pp.chi = chi; pp.Ebar = Ebar; pp.er0 = er0; pp.er1 = er1; pp.er2 = er2; pp.er3 = er3; pp.nq = nq;
             V3 v2 = mk3(PR(n - 1, 0), PR(n - 1, 1), PR(n - 1, 2));
             for (int k = 0; k < n; ++k) {
                 V3 v1 = v2;
                 v2 = mk3(PR(k, 0), PR(k, 1), PR(k, 2));
-                double area = triangle_area(v1, v2, cen, nh);
 #if PFC_EXP == 7
-                if (!(0.0 < area) || area < 1e300) continue;
-#else
-                if (!(0.0 < area)) continue;  // :232
+                if (nh.x > -1e300) continue;
 #endif
-                for (int q = 0; q < nq; ++q) {
-                    // TriTetQuadRule rules 1 and 2, literal decimals of src/clip/quadrature.jl:24-39
-                    double q0, q1, q2, qw;
-                    if (nq == 1) {
-                        q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
-                    } else {
-                        const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
-                        q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
-                        qw = 0.33333333333333331483;
-                    }
-                    // fillTractionCacheInnerLoop! (:251-265)
-                    V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
-                               (v1.z * q0 + v2.z * q1) + cen.z * q2);
-                    double eq = __builtin_fma(er0, r.x, er3);
-                    eq = __builtin_fma(er1, r.y, eq);
-                    eq = __builtin_fma(er2, r.z, eq);
-                    V3 rdot = vl + cross(w, r);
-                    double ee = -dot(mk3(er0, er1, er2), rdot);
-                    double damp = fmax(0.0, 1.0 + chi * ee);
-                    double p = eq * Ebar * damp;
-                    double dA = qw * area;
-                    if (!(0.0 < p)) continue;  // :245
-                    ++n_trac_lane;
-                    double p_dA = p * dA;
+                // fillTractionCacheForTriangle! / InnerLoop! (:236-265): the shared statement of r, p, dA (pfc_kernels.h)
+                n_trac_lane += fan_triangle_points(pp, v1, v2, cen, nh, [&](const V3 &r, const V3 &rdot, double p, double dA) {
+                    const double p_dA = p * dA;
                     if (DBG && store) {
                         g.trac.item[tpos] = cw.item;
                         g.trac.nx[tpos] = nh.x; g.trac.ny[tpos] = nh.y; g.trac.nz[tpos] = nh.z;
@@ -666,7 +644,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                         wrr[2] = __builtin_fma(wx, rc.z, wrr[2]); wrr[3] = __builtin_fma(wy, rc.y, wrr[3]);
                         wrr[4] = __builtin_fma(wy, rc.z, wrr[4]); wrr[5] = __builtin_fma(wz, rc.z, wrr[5]);
                     }
-                }
+                });
             }
             if (!reg) {
                 const double W = sum[6];
@@ -1047,44 +1025,23 @@ __global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
                 V3 vn = mk3(o[10 * P], o[11 * P], o[12 * P]);
                 // TriTetQuadRule rules 1 and 2, literal decimals of src/clip/quadrature.jl:24-39; fillTractionCacheInnerLoop!
                 // (non_friction.jl:251-265): r, p and dA are the full kernel's expressions, operation for operation
+                PointParams pp;
+                pp.w = w; pp.vl = vl; pp.chi = chi; pp.Ebar = Ebar; pp.er0 = er0; pp.er1 = er1; pp.er2 = er2; pp.er3 = er3; pp.nq = nq;
                 auto points = [&](auto &&body) {
                     for (int k = 0; k < n; ++k) {
                         const V3 v1 = v2;
                         v2 = vn;
                         // the next vertex is fetched while this triangle's points are evaluated (slot k + 1 <= 7 always exists)
                         if (k + 1 < n) vn = mk3(o[(13 + 3 * k) * P], o[(14 + 3 * k) * P], o[(15 + 3 * k) * P]);
-                        const double area = triangle_area(v1, v2, cen, nh);
-                        if (!(0.0 < area)) continue;   // non_friction.jl:232
-                        for (int q = 0; q < nq; ++q) {
-                            double q0, q1, q2, qw;
-                            if (nq == 1) {
-                                q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
-                            } else {
-                                const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
-                                q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
-                                qw = 0.33333333333333331483;
-                            }
-                            const V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
-                                             (v1.z * q0 + v2.z * q1) + cen.z * q2);
-                            double eq = __builtin_fma(er0, r.x, er3);
-                            eq = __builtin_fma(er1, r.y, eq);
-                            eq = __builtin_fma(er2, r.z, eq);
-                            const V3 rdot = vl + cross(w, r);
-                            const double ee = -dot(mk3(er0, er1, er2), rdot);
-                            const double damp = fmax(0.0, 1.0 + chi * ee);
-                            const double p = eq * Ebar * damp;
-                            const double dA = qw * area;
-                            if (!(0.0 < p)) continue;  // :245
-                            ++ntl;
-                            body(r, rdot, p * dA);
-                        }
+                        ntl += fan_triangle_points(pp, v1, v2, cen, nh, body);
                     }
                 };
                 if (reg) {
                     // yes_contact!(::Regularized) (friction.jl:50-72) fused, as in the full kernel
                     const double v_c = it->v_c, mu_s = it->mu_s, mu_d = it->mu_d;
                     double fs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                    points([&](const V3 &r, const V3 &rdot, double p_dA) {
+                    points([&](const V3 &r, const V3 &rdot, double p, double dA) {
+                        const double p_dA = p * dA;
                         const V3 vt = vec_sub_vec_proj(rdot, nh);
                         const double m2 = dot_fma(vt, vt);
                         V3 T;
@@ -1111,7 +1068,8 @@ __global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
                 } else {
                     // normal_wrench_cop (normal.jl:17-34), pass 1 of the bristle model: W and the moments of w about c0
                     double W = 0.0, wr1[3] = {0.0, 0.0, 0.0}, wrr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                    points([&](const V3 &r, const V3 &, double p_dA) {
+                    points([&](const V3 &r, const V3 &, double p, double dA) {
+                        const double p_dA = p * dA;
                         W += p_dA;
                         const V3 rc = r - c0;
                         const double wx = p_dA * rc.x, wy = p_dA * rc.y, wz = p_dA * rc.z;
@@ -1222,34 +1180,15 @@ __global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
             const V3 ts_c0 = ((Dl - cross(Da, cop)) + vl * tau) * (-k_bar), ts_e = (Da + w * tau) * (-k_bar);
             V3 v2 = mk3(o[(10 + 3 * (n - 1)) * P], o[(11 + 3 * (n - 1)) * P], o[(12 + 3 * (n - 1)) * P]);
             V3 vn = mk3(o[10 * P], o[11 * P], o[12 * P]);
+            PointParams pp;
+            pp.w = w; pp.vl = vl; pp.chi = chi; pp.Ebar = Ebar; pp.er0 = er0; pp.er1 = er1; pp.er2 = er2; pp.er3 = er3; pp.nq = nq;
             for (int k = 0; k < n; ++k) {
                 const V3 v1 = v2;
                 v2 = vn;
                 // the next vertex is fetched while this triangle's points are evaluated (slot k + 1 <= 7 always exists)
                 if (k + 1 < n) vn = mk3(o[(13 + 3 * k) * P], o[(14 + 3 * k) * P], o[(15 + 3 * k) * P]);
-                const double area = triangle_area(v1, v2, cen, nh);
-                if (!(0.0 < area)) continue;
-                for (int q = 0; q < nq; ++q) {
-                    double q0, q1, q2, qw;
-                    if (nq == 1) {
-                        q0 = q1 = q2 = 0.33333333333333331483; qw = 1.0;
-                    } else {
-                        const double qa = 0.16666666666666674068, qb = 0.66666666666666651864;
-                        q0 = (q == 1) ? qb : qa; q1 = (q == 0) ? qb : qa; q2 = (q == 2) ? qb : qa;
-                        qw = 0.33333333333333331483;
-                    }
-                    const V3 r = mk3((v1.x * q0 + v2.x * q1) + cen.x * q2, (v1.y * q0 + v2.y * q1) + cen.y * q2,
-                                     (v1.z * q0 + v2.z * q1) + cen.z * q2);
-                    double eq = __builtin_fma(er0, r.x, er3);
-                    eq = __builtin_fma(er1, r.y, eq);
-                    eq = __builtin_fma(er2, r.z, eq);
-                    const V3 rdot = vl + cross(w, r);
-                    const double ee = -dot(mk3(er0, er1, er2), rdot);
-                    const double damp = fmax(0.0, 1.0 + chi * ee);
-                    const double p = eq * Ebar * damp;
-                    const double dA = qw * area;
-                    if (!(0.0 < p)) continue;
-                    contributed = true;
+                // the traction points of k_narrow / k_integ, bit for bit (fan_triangle_points, pfc_kernels.h)
+                if (fan_triangle_points(pp, v1, v2, cen, nh, [&](const V3 &r, const V3 &, double p, double dA) {
                     const double p_dA = p * dA;
                     const V3 x = r - cop;
                     // T̄s = -k̄ (Δ_lin + Δ_ang x (r - cop) + τ (v + ω x r)) (friction.jl:186-190) = c0 + e x r with the
@@ -1280,7 +1219,8 @@ __global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
                     const V3 ta = cross_fma(x, Tc);
                     sum[0] += ta.x; sum[1] += ta.y; sum[2] += ta.z;
                     sum[3] += Tc.x; sum[4] += Tc.y; sum[5] += Tc.z;
-                }
+                }))
+                    contributed = true;
             }
         }
         accumulate_items<6>(g.acc, item, active, contributed, sum, kAccFric);
