@@ -124,6 +124,19 @@ def _i(a):
     return a, a.ctypes.data_as(_ip)
 
 
+def _da(a):
+    """float64 C-contiguous view (no copy when it already is one) and its address"""
+    if not (type(a) is np.ndarray and a.dtype == np.float64 and a.flags.c_contiguous):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data
+
+
+def _ia(a):
+    if not (type(a) is np.ndarray and a.dtype == np.int32 and a.flags.c_contiguous):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data
+
+
 class MechanismScenario:
     """Contact part of MechanismScenario{T} (src/mechanism_scenario.jl:166-199), backed by a pfc_handle."""
 
@@ -268,24 +281,25 @@ class MechanismScenario:
         Returns (wrench (n,6), sdot (n,6), counts (n,4))."""
         if not self._finalized:
             raise RuntimeError("finalize the scenario first")
-        pose_a, pose_p = _d(pose)
+        pose_a, pose_p = _da(pose)
         n = pose_a.size // 24
-        tw_a, tw_p = _d(twist)
+        tw_a, tw_p = _da(twist)
         if tw_a.size != 6 * n:
             raise ValueError("twist must have 6 entries per item")
         s_p = None
         if s is not None:
-            s_a, s_p = _d(s)
+            s_a, s_p = _da(s)
             if s_a.size != 6 * n:
                 raise ValueError("s must have 6 entries per item")
         id_p = None
         if ins_ids is not None:
-            id_a, id_p = _i(ins_ids)
+            id_a, id_p = _ia(ins_ids)
             if id_a.size != n:
                 raise ValueError("ins_ids must have one entry per item")
         wrench = np.zeros((n, 6)); sdot = np.zeros((n, 6)); counts = np.zeros((n, 4), dtype=np.int32)
-        self._check(_lib.lib().pfc_eval(self._h, n, id_p, pose_p, tw_p, s_p, wrench.ctypes.data_as(_dp),
-                                        sdot.ctypes.data_as(_dp), counts.ctypes.data_as(_ip)))
+        rc = _lib.lib().pfc_eval_addr(self._h, n, id_p, pose_p, tw_p, s_p, wrench.ctypes.data, sdot.ctypes.data, counts.ctypes.data)
+        if rc != 0:
+            self._check(rc)
         return wrench, sdot, counts
 
     def force_all_elastic_intersections_dual(self, pose, twist, s, d_pose, d_twist, d_s=None,
@@ -295,35 +309,35 @@ class MechanismScenario:
         or None.  Returns (wrench, sdot, d_wrench (n, n_dir, 6), d_sdot (n, n_dir, 6), counts)."""
         if not self._finalized:
             raise RuntimeError("finalize the scenario first")
-        pose_a, pose_p = _d(pose)
+        pose_a, pose_p = _da(pose)
         n = pose_a.size // 24
-        tw_a, tw_p = _d(twist)
-        dp_a, dp_p = _d(d_pose)
+        tw_a, tw_p = _da(twist)
+        dp_a, dp_p = _da(d_pose)
         if n == 0 or dp_a.size % (24 * n) != 0:
             raise ValueError("d_pose must be (n, n_dir, 24)")
         n_dir = dp_a.size // (24 * n)
-        dt_a, dt_p = _d(d_twist)
+        dt_a, dt_p = _da(d_twist)
         if tw_a.size != 6 * n or dt_a.size != 6 * n * n_dir:
             raise ValueError("twist must be (n, 6) and d_twist (n, n_dir, 6)")
         s_p = ds_p = id_p = None
         if s is not None:
-            s_a, s_p = _d(s)
+            s_a, s_p = _da(s)
             if s_a.size != 6 * n:
                 raise ValueError("s must have 6 entries per item")
         if d_s is not None:
-            ds_a, ds_p = _d(d_s)
+            ds_a, ds_p = _da(d_s)
             if ds_a.size != 6 * n * n_dir:
                 raise ValueError("d_s must be (n, n_dir, 6)")
         if ins_ids is not None:
-            id_a, id_p = _i(ins_ids)
+            id_a, id_p = _ia(ins_ids)
             if id_a.size != n:
                 raise ValueError("ins_ids must have one entry per item")
         wrench = np.zeros((n, 6)); sdot = np.zeros((n, 6)); counts = np.zeros((n, 4), dtype=np.int32)
         dw = np.zeros((n, n_dir, 6)); dsd = np.zeros((n, n_dir, 6))
-        self._check(_lib.lib().pfc_eval_dual(self._h, n, n_dir, id_p, pose_p, tw_p, s_p, dp_p, dt_p, ds_p,
-                                             wrench.ctypes.data_as(_dp), sdot.ctypes.data_as(_dp),
-                                             dw.ctypes.data_as(_dp), dsd.ctypes.data_as(_dp),
-                                             counts.ctypes.data_as(_ip)))
+        rc = _lib.lib().pfc_eval_dual_addr(self._h, n, n_dir, id_p, pose_p, tw_p, s_p, dp_p, dt_p, ds_p, wrench.ctypes.data,
+                                           sdot.ctypes.data, dw.ctypes.data, dsd.ctypes.data, counts.ctypes.data)
+        if rc != 0:
+            self._check(rc)
         return wrench, sdot, dw, dsd, counts
 
     def scatter_generalized(self, wrench, x_w_r2, body_1, body_2, jac, scene=None, n_scene: int = 1):
