@@ -423,3 +423,35 @@ def test_jacobian_chunks_on_small_scenes(pfc, cfg, poison):
     m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd, w.ins_ids)
     assert not m.last_dual_reused()
     m.close()
+
+
+def test_jacobian_chunks_without_ids_and_state(pfc):
+    """The reuse test compares the optional inputs too: ins_ids = NULL (item i is instruction i) and s = NULL (no bristle
+    instruction) on the small-scene paths, and a call that differs from the previous one ONLY in having ins_ids (same
+    mapping) or s (zeros) must still give the same results, reused or not."""
+    rng = np.random.default_rng(43)
+    w = pfc.configs.c1_boxes()
+    n = w.n_items
+    ids = np.arange(n, dtype=np.int32)
+    assert np.array_equal(w.ins_ids, ids)
+
+    def seeds(nd):
+        return (rng.standard_normal((n, nd, 24)) * 1e-2, rng.standard_normal((n, nd, 6)) * 0.1, None)
+
+    f = pfc.configs.build_scenario(w)
+    f.set_option("dual_reuse", 0)
+    f.set_option("fused", 0)
+    m = pfc.configs.build_scenario(w)
+    calls = [(None, None), (None, None), (None, None), (ids, None), (ids, None), (ids, np.zeros((n, 6))), (None, np.zeros((n, 6))),
+             (None, None)]
+    flags = []
+    for i_arg, s_arg in calls:
+        sd = seeds(6)
+        got = m.force_all_elastic_intersections_dual(w.pose, w.twist, s_arg, *sd, i_arg)
+        flags.append(m.last_dual_reused())
+        want = f.force_all_elastic_intersections_dual(w.pose, w.twist, None, *sd, None)
+        assert np.array_equal(got[4], want[4])
+        for x, y, tol in ((want[0], got[0], 1e-10), (want[1], got[1], 1e-6), (want[2], got[2], 1e-8), (want[3], got[3], 1e-5)):
+            np.testing.assert_allclose(y, x, rtol=tol, atol=tol * max(np.abs(x).max(), 1e-300))
+    assert flags[0] is False and flags[2] is True, flags
+    f.close(); m.close()
