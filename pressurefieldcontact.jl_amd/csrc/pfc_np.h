@@ -998,33 +998,14 @@ __global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
             const int nq = it->nq;
             const V3 w = ld3(it->w), vl = ld3(it->v);
             const double chi = it->chi, Ebar = it->Ebar;
-            bool contributed = false;
-            unsigned long long todo = __ballot(has);
-            while (todo) {     // the runs of equal items of this piece (one, two at a run boundary of the candidate list)
-                const int f = __builtin_ctzll(todo);
-                const int run_item = __builtin_amdgcn_readlane(item, f);
-                const bool in_run = has && item == run_item;
-                todo &= ~__ballot(in_run);
-                const bool reg = __builtin_amdgcn_readlane((int)lane_reg, f) != 0;
-                if (run_item != cur) {
-                    flush();
-                    cur = run_item;
-                    cur_reg = reg;
-                    c0 = mk3(readlane_f64(cen.x, f), readlane_f64(cen.y, f), readlane_f64(cen.z, f));
-                    n_tr = 0;
-#pragma unroll
-                    for (int k = 0; k < 10; ++k) s10[k] = 0.0;
-                    if (!reg) {
-#pragma unroll
-                        for (int k = 0; k < 27; ++k) m27[k * RS + lane] = 0.0;
-                    }
-                }
-                if (!in_run) continue;
-                int ntl = 0;
+            // ---- (A) the traction points of every polygon of the piece, ONCE: regularized lanes sum their wrench, bristle
+            // lanes W and the moments of w about their OWN polygon centroid (normal_wrench_cop, normal.jl:17-34) ----------
+            int ntl = 0;
+            double W = 0.0, wr1[3] = {0.0, 0.0, 0.0}, wrr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            double fs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (has) {
                 V3 v2 = mk3(o[(10 + 3 * (n - 1)) * P], o[(11 + 3 * (n - 1)) * P], o[(12 + 3 * (n - 1)) * P]);
                 V3 vn = mk3(o[10 * P], o[11 * P], o[12 * P]);
-                // TriTetQuadRule rules 1 and 2, literal decimals of src/clip/quadrature.jl:24-39; fillTractionCacheInnerLoop!
-                // (non_friction.jl:251-265): r, p and dA are the full kernel's expressions, operation for operation
                 PointParams pp;
                 pp.w = w; pp.vl = vl; pp.chi = chi; pp.Ebar = Ebar; pp.er0 = er0; pp.er1 = er1; pp.er2 = er2; pp.er3 = er3; pp.nq = nq;
                 auto points = [&](auto &&body) {
@@ -1036,10 +1017,9 @@ __global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
                         ntl += fan_triangle_points(pp, v1, v2, cen, nh, body);
                     }
                 };
-                if (reg) {
+                if (lane_reg) {
                     // yes_contact!(::Regularized) (friction.jl:50-72) fused, as in the full kernel
                     const double v_c = it->v_c, mu_s = it->mu_s, mu_d = it->mu_d;
-                    double fs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                     points([&](const V3 &r, const V3 &rdot, double p, double dA) {
                         const double p_dA = p * dA;
                         const V3 vt = vec_sub_vec_proj(rdot, nh);
@@ -1061,51 +1041,84 @@ __global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
                         fs[0] += ta.x; fs[1] += ta.y; fs[2] += ta.z;
                         fs[3] += tk.x; fs[4] += tk.y; fs[5] += tk.z;
                     });
-                    if (ntl > 0) {
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) s10[k] += fs[k];
-                    }
                 } else {
-                    // normal_wrench_cop (normal.jl:17-34), pass 1 of the bristle model: W and the moments of w about c0
-                    double W = 0.0, wr1[3] = {0.0, 0.0, 0.0}, wrr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                     points([&](const V3 &r, const V3 &, double p, double dA) {
                         const double p_dA = p * dA;
                         W += p_dA;
-                        const V3 rc = r - c0;
+                        const V3 rc = r - cen;
                         const double wx = p_dA * rc.x, wy = p_dA * rc.y, wz = p_dA * rc.z;
                         wr1[0] += wx; wr1[1] += wy; wr1[2] += wz;
                         wrr[0] = __builtin_fma(wx, rc.x, wrr[0]); wrr[1] = __builtin_fma(wx, rc.y, wrr[1]);
                         wrr[2] = __builtin_fma(wx, rc.z, wrr[2]); wrr[3] = __builtin_fma(wy, rc.y, wrr[3]);
                         wrr[4] = __builtin_fma(wy, rc.z, wrr[4]); wrr[5] = __builtin_fma(wz, rc.z, wrr[5]);
                     });
-                    if (ntl > 0) {
-                        // the polygon's share of the ten sums: torque (sum w r) x n̂, force n̂ W, W, sum w r
-                        const V3 Sr = mk3(wr1[0] + W * c0.x, wr1[1] + W * c0.y, wr1[2] + W * c0.z);
-                        const V3 ta = cross(Sr, nh);
-                        s10[0] += ta.x; s10[1] += ta.y; s10[2] += ta.z;
-                        s10[3] += nh.x * W; s10[4] += nh.y * W; s10[5] += nh.z * W;
-                        s10[6] += W; s10[7] += Sr.x; s10[8] += Sr.y; s10[9] += Sr.z;
-                        // and of the 27 moments about c0 (this lane's LDS column); n̂ is constant over the polygon:
-                        // sum w n n' = W n n', sum w (x x n) n' = (m1 x n) n', sum w (x x n)(x x n)' = [n]x Q [n]x'
-                        double *mc = m27 + lane;
-#define M27_(k, v) mc[(k) * RS] += (v)
-                        M27_(0, W * nh.x * nh.x); M27_(1, W * nh.x * nh.y); M27_(2, W * nh.x * nh.z);
-                        M27_(3, W * nh.y * nh.y); M27_(4, W * nh.y * nh.z); M27_(5, W * nh.z * nh.z);
-                        const V3 an = cross(mk3(wr1[0], wr1[1], wr1[2]), nh);
-                        M27_(6, an.x * nh.x); M27_(7, an.y * nh.x); M27_(8, an.z * nh.x);
-                        M27_(9, an.x * nh.y); M27_(10, an.y * nh.y); M27_(11, an.z * nh.y);
-                        M27_(12, an.x * nh.z); M27_(13, an.y * nh.z); M27_(14, an.z * nh.z);
-                        const V3 q0c = mk3(wrr[0], wrr[1], wrr[2]), q1c = mk3(wrr[1], wrr[3], wrr[4]), q2c = mk3(wrr[2], wrr[4], wrr[5]);
-                        const V3 m0 = cross(nh, q0c), m1c = cross(nh, q1c), m2c = cross(nh, q2c);       // M = [n]x Q
-                        const V3 r0 = cross(nh, mk3(m0.x, m1c.x, m2c.x)), r1 = cross(nh, mk3(m0.y, m1c.y, m2c.y));
-                        const V3 r2 = cross(nh, mk3(m0.z, m1c.z, m2c.z));
-                        M27_(15, r0.x); M27_(16, r0.y); M27_(17, r0.z); M27_(18, r1.y); M27_(19, r1.z); M27_(20, r2.z);
+                }
+            }
+            const bool contributed = ntl > 0;
+            // ---- (B) the runs of equal items of this piece (one; two at a run boundary of the candidate list; several when
+            // the items are small, as in a pile of boxes): each lane's sums join its run's, the moments shifted from the
+            // polygon centroid to the run's reference point c0 (parallel axis, |d| below the patch size) -------------------
+            unsigned long long todo = __ballot(has);
+            while (todo) {
+                const int f = __builtin_ctzll(todo);
+                const int run_item = __builtin_amdgcn_readlane(item, f);
+                const bool in_run = has && item == run_item;
+                todo &= ~__ballot(in_run);
+                const bool reg = __builtin_amdgcn_readlane((int)lane_reg, f) != 0;
+                if (run_item != cur) {
+                    flush();
+                    cur = run_item;
+                    cur_reg = reg;
+                    c0 = mk3(readlane_f64(cen.x, f), readlane_f64(cen.y, f), readlane_f64(cen.z, f));
+                    n_tr = 0;
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) M27_(21 + k, wrr[k]);
-#undef M27_
+                    for (int k = 0; k < 10; ++k) s10[k] = 0.0;
+                    if (!reg) {
+#pragma unroll
+                        for (int k = 0; k < 27; ++k) m27[k * RS + lane] = 0.0;
                     }
                 }
-                if (ntl > 0) { contributed = true; n_tr += ntl; }
+                if (!in_run || !contributed) continue;
+                n_tr += ntl;
+                if (reg) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) s10[k] += fs[k];
+                } else {
+                    // the polygon's share of the ten sums: torque (sum w r) x n̂, force n̂ W, W, sum w r
+                    const V3 Sr = mk3(wr1[0] + W * cen.x, wr1[1] + W * cen.y, wr1[2] + W * cen.z);
+                    const V3 ta = cross(Sr, nh);
+                    s10[0] += ta.x; s10[1] += ta.y; s10[2] += ta.z;
+                    s10[3] += nh.x * W; s10[4] += nh.y * W; s10[5] += nh.z * W;
+                    s10[6] += W; s10[7] += Sr.x; s10[8] += Sr.y; s10[9] += Sr.z;
+                    // moments about c0: x' = x + d, d = cen - c0
+                    const V3 d = cen - c0;
+                    const V3 m1 = mk3(wr1[0] + W * d.x, wr1[1] + W * d.y, wr1[2] + W * d.z);
+                    double q[6];
+                    q[0] = wrr[0] + 2.0 * wr1[0] * d.x + W * d.x * d.x;
+                    q[1] = wrr[1] + wr1[0] * d.y + wr1[1] * d.x + W * d.x * d.y;
+                    q[2] = wrr[2] + wr1[0] * d.z + wr1[2] * d.x + W * d.x * d.z;
+                    q[3] = wrr[3] + 2.0 * wr1[1] * d.y + W * d.y * d.y;
+                    q[4] = wrr[4] + wr1[1] * d.z + wr1[2] * d.y + W * d.y * d.z;
+                    q[5] = wrr[5] + 2.0 * wr1[2] * d.z + W * d.z * d.z;
+                    // and the 27 moments about c0 (this lane's LDS column); n̂ is constant over the polygon:
+                    // sum w n n' = W n n', sum w (x x n) n' = (m1 x n) n', sum w (x x n)(x x n)' = [n]x Q [n]x'
+                    double *mc = m27 + lane;
+#define M27_(k, v) mc[(k) * RS] += (v)
+                    M27_(0, W * nh.x * nh.x); M27_(1, W * nh.x * nh.y); M27_(2, W * nh.x * nh.z);
+                    M27_(3, W * nh.y * nh.y); M27_(4, W * nh.y * nh.z); M27_(5, W * nh.z * nh.z);
+                    const V3 an = cross(m1, nh);
+                    M27_(6, an.x * nh.x); M27_(7, an.y * nh.x); M27_(8, an.z * nh.x);
+                    M27_(9, an.x * nh.y); M27_(10, an.y * nh.y); M27_(11, an.z * nh.y);
+                    M27_(12, an.x * nh.z); M27_(13, an.y * nh.z); M27_(14, an.z * nh.z);
+                    const V3 q0c = mk3(q[0], q[1], q[2]), q1c = mk3(q[1], q[3], q[4]), q2c = mk3(q[2], q[4], q[5]);
+                    const V3 m0 = cross(nh, q0c), m1c = cross(nh, q1c), m2c = cross(nh, q2c);       // M = [n]x Q
+                    const V3 r0 = cross(nh, mk3(m0.x, m1c.x, m2c.x)), r1 = cross(nh, mk3(m0.y, m1c.y, m2c.y));
+                    const V3 r2 = cross(nh, mk3(m0.z, m1c.z, m2c.z));
+                    M27_(15, r0.x); M27_(16, r0.y); M27_(17, r0.z); M27_(18, r1.y); M27_(19, r1.z); M27_(20, r2.z);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) M27_(21 + k, q[k]);
+#undef M27_
+                }
             }
             // a polygon without a pressure point, or of a regularized item, is not for the friction pass
             if (has && (!contributed || lane_reg)) g.poly_item[idx] = 0;
