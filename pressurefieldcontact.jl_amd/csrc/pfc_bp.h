@@ -279,33 +279,6 @@ __device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, boo
     return verdict;
 }
 
-// Unit quaternion (Float32) of the item's R_a_b, formed in Float64 (largest of 4w^2, 4x^2, 4y^2, 4z^2 as pivot, no
-// square root before the normalisation), and the check the error bound above rests on, IN FLOAT64: the rounded quaternion
-// reproduces R_a_b to 4 u per entry and has |q|^2 within 2.25 u of 1.  A pose that fails it (not a proper rotation) returns
-// false: every node test of the item then goes to the exact Float64 test.
-__device__ __forceinline__ bool pose_quat(const double *R, float *qf) {
-    const double d0 = ((1.0 + R[0]) + R[4]) + R[8], d1 = ((1.0 + R[0]) - R[4]) - R[8];
-    const double d2 = ((1.0 - R[0]) + R[4]) - R[8], d3 = ((1.0 - R[0]) - R[4]) + R[8];
-    double q0, q1, q2, q3;
-    if (d0 >= d1 && d0 >= d2 && d0 >= d3) { q0 = d0; q1 = R[5] - R[7]; q2 = R[6] - R[2]; q3 = R[1] - R[3]; }
-    else if (d1 >= d2 && d1 >= d3) { q0 = R[5] - R[7]; q1 = d1; q2 = R[3] + R[1]; q3 = R[6] + R[2]; }
-    else if (d2 >= d3) { q0 = R[6] - R[2]; q1 = R[3] + R[1]; q2 = d2; q3 = R[7] + R[5]; }
-    else { q0 = R[1] - R[3]; q1 = R[6] + R[2]; q2 = R[7] + R[5]; q3 = d3; }
-    const double qn = __builtin_sqrt(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
-    qf[0] = (float)(q0 / qn); qf[1] = (float)(q1 / qn); qf[2] = (float)(q2 / qn); qf[3] = (float)(q3 / qn);
-    const double w = qf[0], x = qf[1], y = qf[2], z = qf[3];
-    const double Rq[9] = {1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w),
-                          2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w),
-                          2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)};
-    double worst = 0.0;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) worst = fmax(worst, __builtin_fabs(Rq[j] - R[j]));
-    const double n2 = ((w * w + x * x) + y * y) + z * z;
-    const double u = 5.9604644775390625e-8;
-    // written so that a NaN anywhere fails the check
-    return (worst <= 4.0 * u) && (__builtin_fabs(n2 - 1.0) <= 2.25 * u);
-}
-
 constexpr int kDfsBlock = 256;
 constexpr int kDfsWaves = kDfsBlock / 64;
 constexpr int kDfsStack32 = 2560;   // node pairs per workgroup (20 KiB)
@@ -428,7 +401,7 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
     __shared__ double xs[(kDfsBlock / 16) * 33];
     __shared__ int s_seed, s_base, s_def[2];   // s_def: parked-pair counters, alternating by iteration parity
     __shared__ double s_pose[12];         // R_a_b (9, column-major), t_a_b (3) of the current seed's item
-    __shared__ float s_q12[4];            // unit quaternion of R_a_b (Float32), formed once per seed
+    __shared__ float s_q12[4];            // unit quaternion of R_a_b (Float32), from the item record
     __shared__ int s_pose_exact;          // the pose failed pose_quat's check: every test of the seed is settled exactly
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n_seed = *g.n_seed;
@@ -448,15 +421,8 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
         // stay live across the call of the exact test
         if (tid < 9) s_pose[tid] = it->R12[tid];
         else if (tid < 12) s_pose[tid] = it->t12[tid - 9];
-        else if (tid == 64) {   // first lane of wave 1: runs beside wave 0's loads
-            double R[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) R[k] = it->R12[k];
-            float qf[4];
-            const bool ok = pose_quat(R, qf);
-            s_q12[0] = qf[0]; s_q12[1] = qf[1]; s_q12[2] = qf[2]; s_q12[3] = qf[3];
-            s_pose_exact = ok ? 0 : 1;
-        }
+        else if (tid < 16) s_q12[tid - 12] = it->q12[tid - 12];     // formed and checked once per item (k_setup_items, pose_quat)
+        else if (tid == 16) s_pose_exact = it->pose_exact;
         const NodeF *n1 = it->nf1, *n2 = it->nf2;
         int sp = 1, n_out = 0, n_test = 0, n_cand = 0, n_def = 0, n_und = 0;
         if (tid == 0) {

@@ -108,6 +108,8 @@ __global__ void k_setup_items(EvalArgs g) {
     r.tet1 = m1.tri ? nullptr : m1.tet; r.eps1 = m1.tet_eps; r.eps2 = m2.tet_eps; r.Ebar1 = m1.Ebar;
     r.model = in.model; r.nq = (in.nq == 1) ? 1 : 3;  // quadrature POINTS of rule 1 / rule 2 (quadrature.jl:22,31)
     r.ins = id; r.pad = 0;
+    r.pose_exact = pose_quat(r.R12, r.q12) ? 0 : 1;
+    r.pad2[0] = r.pad2[1] = r.pad2[2] = 0;
     bool finite = true;
 #pragma unroll
     for (int k = 0; k < 24; ++k) finite &= (__builtin_fabs(p[k]) <= 1.79769313486231570815e308);

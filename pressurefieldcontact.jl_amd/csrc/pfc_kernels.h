@@ -112,6 +112,11 @@ struct alignas(16) ItemRec {  // per (instruction, pose) item: outputs of refres
     const double *eps1, *eps2;
     double Ebar1;
     int model, nq, ins, pad;  // nq = number of quadrature points (1 or 3)
+    // the broadphase's single-precision filter composes rotations as quaternions: R_a_b as a unit quaternion, formed and
+    // checked in Float64 once per item (pose_quat); pose_exact: the pose is not a proper rotation, every node test of the
+    // item is settled by the exact Float64 test
+    float q12[4];
+    int pose_exact, pad2[3];
 };
 
 struct alignas(16) WorkRec {  // frontier entry (item, node_a, node_b) or candidate (item, i_1, i_2)
@@ -336,6 +341,33 @@ __device__ __forceinline__ int sat15_f32(const double *ea64, const double *eb64,
 #undef R_
 #undef AR_
     return sep ? 0 : (hit ? 1 : 2);
+}
+
+// Unit quaternion (Float32) of the item's R_a_b, formed in Float64 (largest of 4w^2, 4x^2, 4y^2, 4z^2 as pivot, no
+// square root before the normalisation), and the check the error bound above rests on, IN FLOAT64: the rounded quaternion
+// reproduces R_a_b to 4 u per entry and has |q|^2 within 2.25 u of 1.  A pose that fails it (not a proper rotation) returns
+// false: every node test of the item then goes to the exact Float64 test.
+__device__ __forceinline__ bool pose_quat(const double *R, float *qf) {
+    const double d0 = ((1.0 + R[0]) + R[4]) + R[8], d1 = ((1.0 + R[0]) - R[4]) - R[8];
+    const double d2 = ((1.0 - R[0]) + R[4]) - R[8], d3 = ((1.0 - R[0]) - R[4]) + R[8];
+    double q0, q1, q2, q3;
+    if (d0 >= d1 && d0 >= d2 && d0 >= d3) { q0 = d0; q1 = R[5] - R[7]; q2 = R[6] - R[2]; q3 = R[1] - R[3]; }
+    else if (d1 >= d2 && d1 >= d3) { q0 = R[5] - R[7]; q1 = d1; q2 = R[3] + R[1]; q3 = R[6] + R[2]; }
+    else if (d2 >= d3) { q0 = R[6] - R[2]; q1 = R[3] + R[1]; q2 = d2; q3 = R[7] + R[5]; }
+    else { q0 = R[1] - R[3]; q1 = R[6] + R[2]; q2 = R[7] + R[5]; q3 = d3; }
+    const double qn = __builtin_sqrt(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
+    qf[0] = (float)(q0 / qn); qf[1] = (float)(q1 / qn); qf[2] = (float)(q2 / qn); qf[3] = (float)(q3 / qn);
+    const double w = qf[0], x = qf[1], y = qf[2], z = qf[3];
+    const double Rq[9] = {1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w),
+                          2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w),
+                          2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)};
+    double worst = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) worst = fmax(worst, __builtin_fabs(Rq[j] - R[j]));
+    const double n2 = ((w * w + x * x) + y * y) + z * z;
+    const double u = 5.9604644775390625e-8;
+    // written so that a NaN anywhere fails the check
+    return (worst <= 4.0 * u) && (__builtin_fabs(n2 - 1.0) <= 2.25 * u);
 }
 
 // The traction points of ONE fan triangle (v1, v2, polygon centroid): fillTractionCacheForTriangle! +
