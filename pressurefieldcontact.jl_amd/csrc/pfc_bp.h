@@ -180,7 +180,7 @@ __device__ __forceinline__ int next_ticket(int *ctr) {
 //
 // For a node pair it forms v = R_a_b c_b + (t_a_b - c_a) in Float64 (the centre offset, of the order of the box
 // sizes), everything else in Float32 on unit quaternions: q = conj(q_a) (x) q_a_b (x) q_b (q_a, q_b from the node
-// records, q_a_b formed once per seed from the item's pose; each is checked in Float64 to reproduce its matrix to 4 u per
+// records, q_a_b formed once per item from its pose (k_setup_items); each is checked in Float64 to reproduce its matrix to 4 u per
 // entry, u = 2^-24), R = matrix of q, t = R_a' v by the rotation formula, then the 15 axes d = |T.L| - (r_a + r_b).
 // The error of R is below 142 u, so |d_float - d_reference| < 320 u S with S = |v|_1 + sum e_a + sum e_b
 // (internal-internal pairs carry identity quaternions and only the pose's error: 24 u S).  d > E proves
