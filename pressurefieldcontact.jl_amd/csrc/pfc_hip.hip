@@ -447,10 +447,13 @@ int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
         // big trees (a traversal is ~1.5 node tests per leaf) want >= 1 024 seeds, or 4 096 when there are only a few
         // items; small trees are done in a few iterations per seed, so 64 seeds suffice (C4: 200 -> 144 us).  A large
         // batch over small trees is usually a sparse-contact pile where a few pairs carry the work: one level spreads them.
+        // Round 2 re-sweep for big trees (scripts/sweep_bfs_small.sh, C3 meshes: 1 pose 139 -> 125 us, 4 poses 167 -> 155,
+        // 16 poses 215 -> 202, 64 poses 367 -> 309, 200 poses 519 -> 460): the fewer the items, the more seeds pay.
         const bool big = h->max_leaves >= 8192, mid = h->max_leaves >= 1024;
-        const double target = big ? (n_items >= 256 ? 1024.0 : 4096.0) : (mid ? 1024.0 : 64.0);
+        const double target = big ? (n_items >= 256 ? 1024.0 : (n_items >= 128 ? 3072.0 : (n_items >= 32 ? 16384.0 : 49152.0)))
+                                  : (mid ? 1024.0 : 64.0);
         double seeds = (double)n_items;
-        while (seeds < target && L < 8) { seeds *= 4.0; ++L; }
+        while (seeds < target && L < 9) { seeds *= 4.0; ++L; }
         if (L == 0 && !big && n_items >= 1024) L = 1;
     }
     return L > levels ? levels : L;
