@@ -23,6 +23,12 @@ for fused in (1, 0):
         return float(np.median(ts)), r
     tv, out = med(lambda: m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids))
     pv = m.last_parts()
+    # the first chunk of a Jacobian (a value evaluation at another point precedes it, as in Radau), then its further chunks
+    def first():
+        m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        return m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *dz, w.ins_ids)
+    t1, _ = med(first, blocks=6, per=10)
     td, _ = med(lambda: m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *dz, w.ins_ids))
-    print(f"fused={fused}: value {tv*1e6:.1f} us (path {pv}), Dual(6) {td*1e6:.1f} us (path {m.last_parts()}); counts {out[2].sum(axis=0)}")
+    print(f"fused={fused}: value {tv*1e6:.1f} us (path {pv}), Dual(6) first chunk {(t1 - tv)*1e6:.1f} us, further chunks {td*1e6:.1f} us "
+          f"(value pass reused: {m.last_dual_reused()}); counts {out[2].sum(axis=0)}")
     m.close()
