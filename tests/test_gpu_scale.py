@@ -113,10 +113,13 @@ def test_rigid_motion_invariance(pfc):
     m.close()
 
 
-def test_overflow_growth_is_transparent(pfc):
-    """Work lists start small and double on overflow (VectorCache semantics); results must not depend on it."""
+@pytest.mark.parametrize("clip_min", [0, 1])
+def test_overflow_growth_is_transparent(pfc, clip_min):
+    """Work lists start small and double on overflow (VectorCache semantics); results must not depend on it -- in the
+    one-kernel narrowphase and in the clip-only kernel + k_integ form (whose moment records overflow on their own)."""
     w = pfc.configs.c3_blob_tool(300, n_div_blob=8, n_div_tool=6)
     m = pfc.configs.build_scenario(w)                      # fresh handle: minimal capacities, must grow
+    m.set_option("clip_min", clip_min)
     wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
     st = m.stats()
     assert st["candidates"] > 65536 or st["n_items"] == 300
