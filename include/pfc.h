@@ -190,6 +190,19 @@ int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, con
                             const int *body_2, const int *scene, int n_scene, int n_body, int nv, const double *jac,
                             double *f_out);
 
+/*
+ * pfc_scatter_generalized with every buffer resident in device memory, enqueued on `stream` without a host
+ * synchronisation: the wrenches are the ones pfc_eval_device left in HBM, f_generalized stays there for the next consumer
+ * ("keep f_generalized resident").  accumulate = 0: d_f (n_scene x nv) is cleared first; 1: the
+ * contact forces are added to what d_f holds (the reference adds to the f_generalized of the other force sources,
+ * src/contact_algorithms_non_friction.jl:40-52).  Body / scene ids are NOT range-checked here (they are device data): an id
+ * outside [-1, n_body) / [0, n_scene) is undefined behaviour, as with any device pointer of the wrong size.  d_scene may
+ * be NULL (one mechanism).
+ */
+int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wrench, const double *d_x_w_r2, const int *d_body_1,
+                                   const int *d_body_2, const int *d_scene, int n_scene, int nv, const double *d_jac, double *d_f,
+                                   int accumulate, void *stream);
+
 /* Options: "debug" (1: keep per-pair clip counts and materialise traction points of every item so that the
  * pfc_debug_* calls work), "profile" (1: bracket each stage with HIP events), "max_levels" (0 = automatic),
  * "bfs_levels" (-1 = automatic: level-synchronous seed expansion only until there are >= 2048 seed pairs),

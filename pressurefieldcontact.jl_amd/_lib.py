@@ -51,6 +51,8 @@ SIGNATURES = {
     "pfc_build_tree": (C.c_int, [C.c_int, _dp, C.c_int, C.c_int, _ip, _dp, C.c_int, _dp, _dp, _dp, _ip, _ip]),
     "pfc_tree_last_error": (C.c_char_p, []),
     "pfc_scatter_generalized": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _ip, _ip, _ip, C.c_int, C.c_int, C.c_int, _dp, _dp]),
+    "pfc_scatter_generalized_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                  C.c_int, C.c_void_p]),
     "pfc_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     "pfc_selftest_math": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
 }

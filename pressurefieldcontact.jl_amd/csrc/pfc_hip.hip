@@ -2056,6 +2056,27 @@ int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, con
     return PFC_OK;
 }
 
+int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wrench, const double *d_x_w_r2, const int *d_body_1,
+                                   const int *d_body_2, const int *d_scene, int n_scene, int nv, const double *d_jac, double *d_f,
+                                   int accumulate, void *stream) {
+    if (!h || n_items < 0 || nv <= 0 || n_scene <= 0 || !d_f)
+        return fail(h, PFC_ERR_BAD_ARG, "pfc_scatter_generalized_device: bad argument");
+    if (n_items > 0 && (!d_wrench || !d_x_w_r2 || !d_body_1 || !d_body_2 || !d_jac))
+        return fail(h, PFC_ERR_BAD_ARG, "pfc_scatter_generalized_device: null buffer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    if (!accumulate) HIP_TRY(h, hipMemsetAsync(d_f, 0, sizeof(double) * (size_t)n_scene * nv, st));
+    if (n_items > 0) {
+        ScatterArgs a;
+        a.n_items = n_items; a.nv = nv; a.wrench = d_wrench; a.x_w_r2 = d_x_w_r2; a.body_1 = d_body_1; a.body_2 = d_body_2;
+        a.scene = d_scene; a.jac = d_jac; a.f = d_f;
+        const long long tot = (long long)n_items * nv;
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return PFC_OK;
+}
+
 int pfc_debug_stamps(pfc_handle h, long long *out16) {
     if (!h || !out16) return PFC_ERR_BAD_ARG;
     if (h->pending) { int rc = check_eval(h); if (rc) return rc; }

@@ -357,6 +357,13 @@ class MechanismScenario:
                                                        f.ctypes.data_as(_dp)))
         return f
 
+    def scatter_generalized_device(self, n_items: int, d_wrench: int, d_x_w_r2: int, d_body_1: int, d_body_2: int, d_scene: int,
+                                   n_scene: int, nv: int, d_jac: int, d_f: int, accumulate: bool = False, stream: int = 0):
+        """pfc_scatter_generalized_device: raw device addresses, asynchronous on `stream`; f_generalized stays in HBM."""
+        self._check(_lib.lib().pfc_scatter_generalized_device(self._h, int(n_items), d_wrench, d_x_w_r2, d_body_1, d_body_2,
+                                                              d_scene or None, int(n_scene), int(nv), d_jac, d_f,
+                                                              1 if accumulate else 0, stream or None))
+
     def eval_device(self, n_items: int, d_ins_ids: int, d_pose: int, d_twist: int, d_s: int, d_wrench: int,
                     d_sdot: int, d_counts: int, stream: int = 0):
         """pfc_eval_device: raw device addresses (e.g. torch.Tensor.data_ptr()); asynchronous."""

@@ -195,6 +195,50 @@ def test_scatter_generalized_third_law(pfc):
     m.close()
 
 
+def test_scatter_generalized_device_resident(pfc):
+    """pfc_scatter_generalized_device: the wrenches pfc_eval_device left in HBM are projected on the Jacobians and added to a
+    device-resident f_generalized, all on one stream and without a host synchronisation in between ("keep
+    f_generalized resident"); overwrite and accumulate modes against the host-buffer entry point."""
+    import torch
+    w = pfc.configs.c2_box_on_plane(64, montecarlo=True)
+    m = pfc.configs.build_scenario(w)
+    rng = np.random.default_rng(14)
+    n, nv, n_body, n_scene = w.n_items, 6, 2, 16
+    x_w_r2 = np.zeros((n, 12))
+    for k in range(n):
+        R = pfc.configs.random_rotation(rng)
+        x_w_r2[k, :9] = R.reshape(-1, order="F"); x_w_r2[k, 9:] = rng.standard_normal(3)
+    jac = rng.standard_normal((n_body, nv, 6))
+    body_1 = np.full(n, -1, dtype=np.int32)
+    body_2 = np.where(np.arange(n) % 3 == 0, 1, 0).astype(np.int32)
+    scene = (np.arange(n) // 4).astype(np.int32)
+    wrench, _, _ = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    want = m.scatter_generalized(wrench, x_w_r2, body_1, body_2, jac, scene, n_scene=n_scene)
+    dev = torch.device("cuda", 0)
+    T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    t_ins, t_pose, t_tw, t_s = T(w.ins_ids, torch.int32), T(w.pose), T(w.twist), T(w.s)
+    o_w, o_sd = torch.zeros((n, 6), dtype=torch.float64, device=dev), torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    o_ct = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    t_x, t_b1, t_b2, t_sc, t_j = T(x_w_r2), T(body_1, torch.int32), T(body_2, torch.int32), T(scene, torch.int32), T(jac)
+    f = torch.full((n_scene, nv), 7.0, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    m.eval_device(n, t_ins.data_ptr(), t_pose.data_ptr(), t_tw.data_ptr(), t_s.data_ptr(), o_w.data_ptr(), o_sd.data_ptr(),
+                  o_ct.data_ptr(), st)
+    m.scatter_generalized_device(n, o_w.data_ptr(), t_x.data_ptr(), t_b1.data_ptr(), t_b2.data_ptr(), t_sc.data_ptr(), n_scene, nv,
+                                 t_j.data_ptr(), f.data_ptr(), False, st)          # same stream: ordered behind the evaluation
+    assert m.check() == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(f.cpu().numpy(), want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+    m.scatter_generalized_device(n, o_w.data_ptr(), t_x.data_ptr(), t_b1.data_ptr(), t_b2.data_ptr(), 0, 1, nv, t_j.data_ptr(),
+                                 f.data_ptr(), True, st)                           # accumulate, one mechanism: row 0 only
+    torch.cuda.synchronize()
+    one = m.scatter_generalized(wrench, x_w_r2, body_1, body_2, jac, None, 1)
+    got = f.cpu().numpy()
+    np.testing.assert_allclose(got[0], want[0] + one[0], rtol=1e-12, atol=1e-12 * np.abs(one).max())
+    np.testing.assert_allclose(got[1:], want[1:], rtol=1e-12, atol=1e-12 * np.abs(want).max())
+    m.close()
+
+
 def test_split_evaluation_equals_unsplit(pfc):
     """Batches of >= split_min items run as two concurrent halves on two streams (pfc_set_option "split_min"): same
     per-item integers, same wrenches up to summation order, merged totals, and growth of the work lists of BOTH halves
