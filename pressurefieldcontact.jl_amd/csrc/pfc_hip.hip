@@ -210,6 +210,9 @@ struct pfc_context {
     size_t pin_din_cap = 0, pin_dout_cap = 0;
     long long dual_hint = -1;                     // contributing pairs of the last Dual evaluation (-1: none yet)
     bool pending_dual = false;                    // pfc_eval_dual_device enqueued: pfc_check also checks the speculative polygon capacity
+    bool pending_dual_hyb = false;                // ... through the small-scene kernel (value pass + hand-over) and the batched Dual passes
+    bool dual_reuse_emit = false;                 // the reusable value pass is a hand-over of the small-scene kernel (pair count: emit_ctr)
+    int dual_dev_hyb_skip = 0;                    // evaluations for which pfc_eval_dual_device leaves that path alone after a miss
     // Reuse of a value pass by further Dual evaluations at the same point (the chunks of one Jacobian,
     // src/radau/radau_functions.jl:2-14): set by pfc_check after a Dual evaluation on the device path, cleared by every
     // other evaluation and option change
@@ -1204,6 +1207,23 @@ int pfc_check(pfc_handle h) {
         HIP_TRY(h, hipStreamSynchronize(h->last_stream));
         return PFC_OK;
     }
+    if (h->pending_dual_hyb) {
+        h->pending_dual_hyb = false; h->pending_dual = false; h->dual_reuse_ok = false;
+        const int rch = check_eval(h);            // the fused kernel's per-item words (copied down, stream synchronised)
+        if (rch != PFC_OK) { h->dual_dev_hyb_skip = 64; return rch; }
+        if (h->stats[6] & kStCandOvf) {
+            h->dual_dev_hyb_skip = 64;
+            return fail(h, PFC_ERR_OVERFLOW, "hand-over list of the small-scene kernel overflowed: re-issue (batched path)");
+        }
+        if ((unsigned)h->h_emit[2] & kStHole) return fail(h, PFC_ERR_STATE, "internal error: a work-list slot was read before it was written");
+        const long long pairs_h = h->h_emit[0];
+        h->dual_hint = pairs_h;
+        const int cpw_h = 64 / h->pending_ndir;
+        if (h->any_bristle && (size_t)((pairs_h + cpw_h - 1) / cpw_h) * 64 + 64 > h->pending_dpcap)
+            return fail(h, PFC_ERR_OVERFLOW, "Dual evaluation: %lld contributing pairs exceed the speculative polygon capacity: re-issue", pairs_h);
+        h->dual_reuse_ok = true; h->dual_reuse_n = h->last_n_items; h->dual_reuse_emit = true;
+        return PFC_OK;
+    }
     const bool dual = h->pending_dual;
     h->pending_dual = false;
     h->dual_reuse_ok = false;
@@ -1216,7 +1236,7 @@ int pfc_check(pfc_handle h) {
     const int cpw = 64 / h->pending_ndir;
     if (h->any_bristle && (size_t)((pairs + cpw - 1) / cpw) * 64 + 64 > h->pending_dpcap)
         return fail(h, PFC_ERR_OVERFLOW, "Dual evaluation: %lld contributing pairs exceed the speculative polygon capacity: re-issue", pairs);
-    h->dual_reuse_ok = true; h->dual_reuse_n = h->last_n_items;
+    h->dual_reuse_ok = true; h->dual_reuse_n = h->last_n_items; h->dual_reuse_emit = false;
     return PFC_OK;
 }
 
@@ -1320,6 +1340,9 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     a.n_items = n_items; a.n_dir = n_dir; a.d_pose = dp; a.d_twist = dt; a.d_s = dsd; a.icnt = h->icnt.p;
     a.dacc = h->dual_acc.p; a.dres = h->dual_res.p; a.d_wrench = dw; a.d_sdot = dsdot;
     a.status = h->status.p;
+    // Hand-over: the passes report into the word behind the pair count (cleared and read back with it).  The status word
+    // of the batched value pass is read by its k_final only, so a flag raised here would surface in a later evaluation.
+    if (pair_count) a.status = reinterpret_cast<unsigned *>(h->emit_ctr.p) + 2;
     const int cpw = 64 / n_dir;
     const int grid = grid_for((n_pairs_bound + cpw - 1) / cpw, 1, 256 * 16);
     const int kgrid = grid_for(nk, 64, 1 << 20);
@@ -1487,7 +1510,7 @@ int eval_dual_hybrid(pfc_context *h, int n_items, int n_dir, const int *ins_ids,
                      h->emit_ctr.p);
     if (rc != PFC_OK) return rc;
     if (!zc) HIP_TRY(h, hipMemcpyAsync(h->pin_dout, ddo, sizeof(double) * nk * 12, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipMemcpyAsync(h->h_emit, h->emit_ctr.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(h->h_emit, h->emit_ctr.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
     h->fout_host = reinterpret_cast<const int *>((const double *)h->pin_out + out_d) + n * 4;
     // check_fused would poll; here the stream is synchronised (the completion words of the fused kernel are long written)
     HIP_TRY(h, hipStreamSynchronize(st));
@@ -1495,6 +1518,7 @@ int eval_dual_hybrid(pfc_context *h, int n_items, int n_dir, const int *ins_ids,
     h->fout_host = nullptr;
     if (rc != PFC_OK) return rc;
     if (h->stats[6] & kStCandOvf) return fail(h, PFC_ERR_OVERFLOW, "hand-over list of the small-scene kernel overflowed: batched path");
+    if ((unsigned)h->h_emit[2] & kStHole) return fail(h, PFC_ERR_STATE, "internal error: a work-list slot was read before it was written");
     const long long pairs = h->h_emit[0];
     h->dual_hint = pairs;
     const int cpw = 64 / n_dir;
@@ -1691,7 +1715,34 @@ int pfc_eval_dual_device(pfc_handle h, int n_items, int n_dir, const int *d_ins_
         d_ds = h->dual_zero.p;
     }
     HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
-    h->split_n0 = 0; h->pending_fused = false;
+    h->split_n0 = 0; h->pending_fused = false; h->pending_dual_hyb = false;
+    // Small scenes: the value pass in the one-workgroup-per-item kernel, which hands item records and lists to the batched
+    // Dual passes (what pfc_eval_dual does for host buffers, eval_dual_hybrid).  A miss (an item that does not fit, a
+    // hand-over list or a speculation that fell short) is reported by pfc_check as PFC_ERR_OVERFLOW and the re-issue takes
+    // the batched value pass below.
+    if (fused_ok(h, n_items) && nk <= 4096 && (h->dual_hint >= 0 || !h->any_bristle) && std::getenv("PFC_NO_HYBRID") == nullptr) {
+        if (h->dual_dev_hyb_skip > 0) {
+            --h->dual_dev_hyb_skip;
+        } else {
+            HIP_TRY(h, ensure_work(h, n_items));
+            HIP_TRY(h, h->emit_ctr.ensure(4));
+            if (!h->h_emit) HIP_TRY(h, hipHostMalloc((void **)&h->h_emit, sizeof(int) * 4));
+            size_t bh = 64;
+            while (bh < (size_t)(h->dual_hint > 0 ? h->dual_hint : 0) * 2 + 64) bh *= 2;
+            HIP_TRY(h, hipMemsetAsync(h->emit_ctr.p, 0, sizeof(int) * 4, st));
+            h->fu_emit = true; h->fout_dev = nullptr; h->fout_host = nullptr;
+            int rcf = enqueue_fused(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
+            h->fu_emit = false;
+            if (rcf != PFC_OK) return rcf;
+            h->last_levels = eff_levels(h);
+            size_t dpcap_h = 0;
+            rcf = launch_dual(h, n_items, n_dir, h->tail.p, d_dpose, d_dtwist, d_ds, d_dwrench, d_dsdot, bh, st, &dpcap_h, true, h->emit_ctr.p);
+            if (rcf != PFC_OK) return rcf;
+            HIP_TRY(h, hipMemcpyAsync(h->h_emit, h->emit_ctr.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+            h->pending_dual_hyb = true; h->pending_dpcap = dpcap_h; h->pending_ndir = n_dir;
+            return PFC_OK;
+        }
+    }
     h->want_surv = true;         // the value pass also lists the contributing candidates; batched path, one part
     int rc = enqueue_eval(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
     h->want_surv = false;
@@ -1725,7 +1776,8 @@ int pfc_eval_dual_device_more(pfc_handle h, int n_dir, const double *d_dpose, co
     HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
     // the contributing pairs are known exactly (dual_hint, from the value pass pfc_check has seen): no speculation
     const size_t bound = (size_t)(h->dual_hint > 0 ? h->dual_hint : 0) + 64;
-    const int rc = launch_dual(h, n_items, n_dir, h->tail.p, d_dpose, d_dtwist, d_ds, d_dwrench, d_dsdot, bound, st, nullptr, true);
+    const int rc = launch_dual(h, n_items, n_dir, h->tail.p, d_dpose, d_dtwist, d_ds, d_dwrench, d_dsdot, bound, st, nullptr, true,
+                               h->dual_reuse_emit ? h->emit_ctr.p : nullptr);
     if (rc != PFC_OK) return rc;
     h->pending_more = true; h->last_stream = st; h->last_dual_reused = true;
     return PFC_OK;
@@ -1767,6 +1819,7 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
         const int rc_h = eval_dual_hybrid(h, n_items, n_dir, ins_ids, pose, twist, s, d_pose, d_twist, d_s, wrench, sdot, d_wrench,
                                           d_sdot, counts);
         if (rc_h != PFC_ERR_OVERFLOW) return rc_h;           // else: batched paths below (lists grown / speculation short)
+        if (h->dual_dev_hyb_skip < 1) h->dual_dev_hyb_skip = 1;   // (not the same sequence again inside pfc_eval_dual_device)
     }
     if (h->finalized && n_items > 0 && n_items <= 512 && (size_t)n_items * n_dir <= 4096 && h->dual_hint >= 0 && pose && twist &&
         wrench && sdot && !h->opt_debug && !(h->opt_split_min > 0 && n_items >= h->opt_split_min)) {

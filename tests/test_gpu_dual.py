@@ -375,6 +375,82 @@ def test_dual_device_more_directions(pfc):
 
 
 @pytest.mark.parametrize("poison", [0, 1])
+@pytest.mark.parametrize("cfg", ["c1", "c2", "pencil", "tight"])
+def test_dual_device_on_small_scenes(pfc, cfg, poison):
+    """pfc_eval_dual_device on scenes the one-workgroup-per-item kernel takes: its value pass hands item records and lists
+    to the batched Dual passes, pfc_check reads one counter; pfc_eval_dual_device_more extends it.  "tight": more
+    contributing pairs than a fresh handle's hand-over lists hold -- the miss must come back as PFC_ERR_OVERFLOW and the
+    re-issue (batched value pass, which grows the lists) must succeed with the same numbers.  Every evaluation equals a fresh handle's host-buffer evaluation."""
+    import torch
+    rng = np.random.default_rng(43)
+    if cfg == "c1":
+        w = pfc.configs.c1_boxes()
+    elif cfg == "c2":
+        w = pfc.configs.c2_box_on_plane(3, montecarlo=True)
+    elif cfg == "pencil":
+        w = pfc.configs.c3_blob_tool(2, seed=3, n_div_blob=5, n_div_tool=4)
+    else:
+        w = pfc.configs.c2_box_on_plane(256, n_div=12, montecarlo=True)      # ~93k contributing pairs: a fresh handle's lists hold 65536
+    n = w.n_items
+    dev = torch.device("cuda", 0)
+    T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    t_ins, t_tw, t_s = T(w.ins_ids, torch.int32), T(w.twist), T(w.s)
+    o_w, o_sd = torch.zeros((n, 6), dtype=torch.float64, device=dev), torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    o_ct = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    m = pfc.configs.build_scenario(w)
+    m.set_option("poison", poison)
+
+    def seeds(nd):
+        return (rng.standard_normal((n, nd, 24)) * 1e-2, rng.standard_normal((n, nd, 6)) * 0.1,
+                rng.standard_normal((n, nd, 6)) * 1e-3)
+
+    def fresh(pose, sd):
+        f = pfc.configs.build_scenario(w)
+        f.set_option("dual_reuse", 0)
+        f.set_option("fused", 0)
+        out = f.force_all_elastic_intersections_dual(pose, w.twist, w.s, *sd, w.ins_ids)
+        f.close()
+        return out
+
+    def same(got, want, nd):
+        assert np.array_equal(got[4], want[4])
+        for x, y, tol in ((want[0], got[0], 1e-10), (want[1], got[1], 1e-6), (want[2], got[2], 1e-8), (want[3], got[3], 1e-5)):
+            np.testing.assert_allclose(y, x, rtol=tol, atol=tol * max(np.abs(x).max(), 1e-300))
+
+    reissued = 0
+    for k in range(4):
+        pose = w.pose.copy()
+        pose[:, 21:24] += rng.standard_normal((n, 3)) * 1e-4 * k        # another point each time
+        t_pose = T(pose)
+        sd = seeds(6)
+        t = [T(x) for x in sd]
+        dw = torch.zeros((n, 6, 6), dtype=torch.float64, device=dev); dsd = torch.zeros_like(dw)
+        for attempt in range(40):
+            m.eval_dual_device(n, 6, t_ins.data_ptr(), t_pose.data_ptr(), t_tw.data_ptr(), t_s.data_ptr(), t[0].data_ptr(),
+                               t[1].data_ptr(), t[2].data_ptr(), o_w.data_ptr(), o_sd.data_ptr(), dw.data_ptr(), dsd.data_ptr(),
+                               o_ct.data_ptr(), stream)
+            if m.check() == 0:
+                break
+            reissued += 1
+        else:
+            raise AssertionError("no success in 40 issues")
+        want = fresh(pose, sd)
+        same((o_w.cpu().numpy(), o_sd.cpu().numpy(), dw.cpu().numpy(), dsd.cpu().numpy(), o_ct.cpu().numpy()), want, 6)
+        for nd in (6, 3):
+            sd2 = seeds(nd)
+            t2 = [T(x) for x in sd2]
+            dw2 = torch.zeros((n, nd, 6), dtype=torch.float64, device=dev); dsd2 = torch.zeros_like(dw2)
+            m.eval_dual_device_more(nd, t2[0].data_ptr(), t2[1].data_ptr(), t2[2].data_ptr(), dw2.data_ptr(), dsd2.data_ptr(), stream)
+            assert m.check() == 0
+            want2 = fresh(pose, sd2)
+            same((o_w.cpu().numpy(), o_sd.cpu().numpy(), dw2.cpu().numpy(), dsd2.cpu().numpy(), o_ct.cpu().numpy()), want2, nd)
+    if cfg == "tight":
+        assert reissued >= 1
+    m.close()
+
+
+@pytest.mark.parametrize("poison", [0, 1])
 @pytest.mark.parametrize("cfg", ["c1", "c2", "pencil", "c3pose"])
 def test_jacobian_chunks_on_small_scenes(pfc, cfg, poison):
     """The same reuse on the small-scene paths: the first Dual evaluation of a point runs in the all-in-one kernel
