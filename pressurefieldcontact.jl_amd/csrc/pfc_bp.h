@@ -280,7 +280,6 @@ __device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, boo
 }
 
 constexpr int kDfsBlock = 256;
-constexpr int kDfsWaves = kDfsBlock / 64;
 constexpr int kDfsStack32 = 2560;   // node pairs per workgroup (20 KiB)
 constexpr int kDfsOut32 = 1280;     // staged candidates per workgroup (10 KiB)
 
@@ -291,11 +290,12 @@ constexpr int kDfsOut32 = 1280;     // staged candidates per workgroup (10 KiB)
 // bb_compose() / sat15(), so the boolean is the reference's bit for bit, and the per-lane register need is a few
 // dozen instead of the ~220 of the one-lane-per-pair Float64 test (which cost the kernel a third of its occupancy
 // when inlined, and as a no-inline call needed scratch).  xs: 33 doubles per 16-lane group.
+template <int BLK>
 __device__ __forceinline__ void exact_pairs_coop(const NodeRec *nodes1, const NodeRec *nodes2, const double *pose,
                                                  const int2 *und_l, int n_def, double *xs, int *und_v, int tid) {
     const int grp = tid >> 4, sub = tid & 15;
     double *T = xs + grp * 33, *tt = T + 9, *R = T + 12, *aR = T + 21, *t = T + 30;
-    for (int c0 = 0; c0 < n_def; c0 += kDfsBlock / 16) {
+    for (int c0 = 0; c0 < n_def; c0 += BLK / 16) {
         const int j = c0 + grp;
         const bool valid = j < n_def;
         int2 e = make_int2(0, 0);
@@ -372,6 +372,7 @@ __device__ __forceinline__ int next_ticket_block(int *ctr, int *slot, int n_seed
     return t;
 }
 
+template <int BLK>
 __device__ __forceinline__ void flush_candidates(const Dfs32Args &g, const int2 *ob, int n_out, int item, int tid,
                                                  int *s_base) {
     // all threads of the workgroup call this (n_out is uniform)
@@ -381,7 +382,7 @@ __device__ __forceinline__ void flush_candidates(const Dfs32Args &g, const int2 
     // On overflow the part of the run that still fits IS written: the narrowphase of an overflowing evaluation runs
     // over the first ccap slots (its results are discarded, the evaluation is re-issued with a longer list), and a
     // slot skipped here would hand it whatever the freshly allocated buffer held -- wild item / element indices.
-    for (int j = tid; j < n_out; j += kDfsBlock) {
+    for (int j = tid; j < n_out; j += BLK) {
         if (base + j < g.ccap) {
             WorkRec c;
             c.item = item; c.a = ob[j].x; c.b = ob[j].y; c.pad = 0;
@@ -392,13 +393,15 @@ __device__ __forceinline__ void flush_candidates(const Dfs32Args &g, const int2 
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
-    __shared__ int2 stk[kDfsStack32];
-    __shared__ int2 ob[kDfsOut32];
-    __shared__ int s_cnt[kDfsWaves][2];   // per wave: candidates, pushed pairs of the current iteration
-    __shared__ int2 und_l[kDfsBlock];     // node pairs the Float32 test left undecided in the last iteration
-    __shared__ int und_v[kDfsBlock];      // their exact verdicts
-    __shared__ double xs[(kDfsBlock / 16) * 33];
+template <int BLK>
+__global__ void __launch_bounds__(BLK, 4) k_bp_dfs32(Dfs32Args g) {
+    constexpr int kWaves = BLK / 64, kStack = BLK * 10, kOut = BLK * 5;
+    __shared__ int2 stk[kStack];
+    __shared__ int2 ob[kOut];
+    __shared__ int s_cnt[kWaves][2];      // per wave: candidates, pushed pairs of the current iteration
+    __shared__ int2 und_l[BLK];           // node pairs the Float32 test left undecided in the last iteration
+    __shared__ int und_v[BLK];            // their exact verdicts
+    __shared__ double xs[(BLK / 16) * 33];
     __shared__ int s_seed, s_base, s_def[2];   // s_def: parked-pair counters, alternating by iteration parity
     __shared__ double s_pose[12];         // R_a_b (9, column-major), t_a_b (3) of the current seed's item
     __shared__ float s_q12[4];            // unit quaternion of R_a_b (Float32), from the item record
@@ -445,13 +448,13 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
             unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0; (void)u0; (void)u1; (void)u2; (void)u3; (void)u4;
             STAMP(u0);
             const bool settle = n_def > 0;
-            int pw = (kDfsStack32 - g.reserve - sp) / 3;
-            int p = sp < kDfsBlock ? sp : kDfsBlock;
+            int pw = (kStack - g.reserve - sp) / 3;
+            int p = sp < BLK ? sp : BLK;
             if (pw < 1) pw = 1;
             if (p > pw) p = pw;
             if (settle) {
                 p = n_def;
-                exact_pairs_coop(it->nodes1, it->nodes2, s_pose, und_l, n_def, xs, und_v, tid);   // ends with a barrier
+                exact_pairs_coop<BLK>(it->nodes1, it->nodes2, s_pose, und_l, n_def, xs, und_v, tid);   // ends with a barrier
             }
             const bool act = tid < p;
             int2 e = make_int2(0, 0);
@@ -501,7 +504,7 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
             if (tid == 0) s_def[par ^ 1] = 0;       // the next iteration's counter: its last readers passed a barrier ago
             int c_off = 0, p_off = 0, c_tot = 0, p_tot = 0;
 #pragma unroll
-            for (int w = 0; w < kDfsWaves; ++w) {
+            for (int w = 0; w < kWaves; ++w) {
                 const int c = s_cnt[w][0], q = s_cnt[w][1];
                 if (w < wave) { c_off += c; p_off += q; }
                 c_tot += c; p_tot += q;
@@ -523,8 +526,8 @@ __global__ void __launch_bounds__(kDfsBlock, 4) k_bp_dfs32(Dfs32Args g) {
             n_out += c_tot;
             sp += p_tot;
             __syncthreads();
-            if (n_out > kDfsOut32 - kDfsBlock || (sp == 0 && n_def == 0 && n_out > 0)) {
-                flush_candidates(g, ob, n_out, item, tid, &s_base);
+            if (n_out > kOut - BLK || (sp == 0 && n_def == 0 && n_out > 0)) {
+                flush_candidates<BLK>(g, ob, n_out, item, tid, &s_base);
                 n_cand += n_out;
                 n_out = 0;
             }

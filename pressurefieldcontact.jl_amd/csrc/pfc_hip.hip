@@ -440,6 +440,8 @@ int eff_levels(const pfc_context *h) {
     return (h->opt_max_levels > 0 && h->opt_max_levels < h->max_levels) ? h->opt_max_levels : h->max_levels;
 }
 
+constexpr int kBpSmallBlockMin = 4096;   // items per launch from which k_bp_dfs32 runs in 128-thread workgroups
+
 int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
     int L = 0;
     if (h->opt_bfs_levels >= 0) {
@@ -514,7 +516,14 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
             f.seed_cap = (int)h->fcap; f.cand = h->cand.p; f.ccount = ccount; f.ccap = (int)h->ccap;
             f.ucount = ucount; f.icnt = h->icnt.p; f.status = h->status.p; f.stamps = h->stamps.p;
             f.reserve = 3 * h->max_levels + 3; f.n_items = n_items;
-            hipLaunchKernelGGL(k_bp_dfs32, dim3(grid_for(bound, 1, 256 * 6)), dim3(kDfsBlock), 0, st, f);
+            // Workgroups of 128 threads for the big launches (>= 4 096 items, i.e. the halves of a step of >= 8 192): the
+            // kernel alone runs as fast either way (2.08 ms), but next to the other half's narrowphase the finer grain
+            // shares the CUs better (8 192-pose step 4.53 -> 4.39 ms; 4 096: 2.33 vs 2.38, 2 048: 1.30 vs 1.45 -- a smaller
+            // launch needs the 256 pairs per iteration; profiles/r02_sweep_bp_block.txt).  Grid = resident workgroups.
+            if (n_items >= kBpSmallBlockMin && f.reserve <= 128 * 10 - 512)
+                hipLaunchKernelGGL((k_bp_dfs32<128>), dim3(grid_for(bound, 1, 256 * 8)), dim3(128), 0, st, f);
+            else
+                hipLaunchKernelGGL((k_bp_dfs32<kDfsBlock>), dim3(grid_for(bound, 1, 256 * 6)), dim3(kDfsBlock), 0, st, f);
         }
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));

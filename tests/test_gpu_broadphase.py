@@ -179,8 +179,10 @@ def test_filtered_and_exact_broadphase_agree_on_a_contact_scene(pfc):
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-9, atol=1e-9 * np.abs(res[0][0]).max())
 
 
-def test_poses_that_are_not_rotations_are_settled_exactly(pfc):
-    """The Float32 filter composes the pose as a quaternion, which only represents proper rotations.  A pose whose 3x3
+@pytest.mark.parametrize("n_pose", [400, 8800])
+def test_poses_that_are_not_rotations_are_settled_exactly(pfc, n_pose):
+    """(8 800 poses: two half-launches of 4 400 items, which run the depth-first kernel in its 128-thread form.)
+    The Float32 filter composes the pose as a quaternion, which only represents proper rotations.  A pose whose 3x3
     block is scaled, sheared or a reflection fails the per-item check (pose_quat) and every node test of that item goes
     to the exact Float64 test, which uses the matrix as given -- like the reference's BB_BB_intersect
     (src/obb/bb_intersection.jl:2-12), whose verdict the oracle supplies."""
@@ -195,7 +197,7 @@ def test_poses_that_are_not_rotations_are_settled_exactly(pfc):
     m.set_option("bfs_levels", 0)
     rng = np.random.default_rng(11)
     Rs, ts = [], []
-    for k in range(400):
+    for k in range(n_pose):
         R = _axis_angle(rng.random() * 2 * np.pi, rng.standard_normal(3))
         kind = k % 4
         if kind == 0:
