@@ -16,6 +16,11 @@ def newest_per_dir(pattern):
 
 
 
+def kname(full):
+    """kernel name without its argument list; the instantiations of k_bp_dfs32<BLK> under one name"""
+    return re.sub(r"^void (pfc::k_bp_dfs32)<\d+>$", r"\1", re.sub(r"\(.*", "", full))
+
+
 tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +31,7 @@ for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != ctr:
                 continue
-            name = re.sub(r"\(.*", "", row["Kernel_Name"])
+            name = kname(row["Kernel_Name"])
             a = acc.setdefault(name, {"calls": 0, "sum_KB": 0.0, "values_KB": []})
             a["calls"] += 1; a["sum_KB"] += float(row["Counter_Value"]); a["values_KB"].append(float(row["Counter_Value"]))
     for a in acc.values():
@@ -62,7 +67,7 @@ steady = {}
 for f in newest_per_dir(os.path.join(root, "gpurun_out", f"{tag}_stats", "**", "*kernel_trace.csv")):
     dur = {}
     for row in csv.DictReader(open(f)):
-        dur.setdefault(re.sub(r"\(.*", "", row["Kernel_Name"]), []).append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        dur.setdefault(kname(row["Kernel_Name"]), []).append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     for name, v in dur.items():
         if name.startswith(("pfc::", "void pfc::")):
             keep = [x for x in v if x >= 0.5 * max(v)]

@@ -15,6 +15,11 @@ def newest_per_dir(pattern):
     return sorted(best.values())
 
 
+def kname(full):
+    """kernel name without its argument list; the instantiations of k_bp_dfs32<BLK> under one name"""
+    return re.sub(r"^void (pfc::k_bp_dfs32)<\d+>$", r"\1", re.sub(r"\(.*", "", full))
+
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, bench = sys.argv[1], json.load(open(sys.argv[2]))
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -26,7 +31,7 @@ for tg in tag.split(","):
             if (tg, row["Counter_Name"]) in seen:
                 continue
             mine.add((tg, row["Counter_Name"]))
-            vals[re.sub(r"\(.*", "", row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            vals[kname(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
         seen |= mine
 
 
