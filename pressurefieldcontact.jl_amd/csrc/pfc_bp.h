@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(BLK, 4) k_bp_dfs32(Dfs32Args g) {
         }
         __syncthreads();
 #ifdef PFC_STAMPS
-        unsigned long long c_a = 0, c_b = 0, c_c = 0, c_d = 0, c_it = 0, c_p = 0;
+        unsigned long long c_a = 0, c_b = 0, c_c = 0, c_d = 0, c_it = 0, c_p = 0, c_w1 = 0, c_w2 = 0;   // c_w*: inside the two barriers, every wave
 #endif
         // every workgroup must reach its exit: the iteration guard stops a corrupt (cyclic) tree from spinning forever
         int par = 0;   // parity of the iteration: selects the parking counter
@@ -498,7 +498,13 @@ __global__ void __launch_bounds__(BLK, 4) k_bp_dfs32(Dfs32Args g) {
                 s_cnt[wave][0] = __builtin_popcountll(mc);
                 s_cnt[wave][1] = 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
             }
+#ifdef PFC_STAMPS
+            const unsigned long long w1a = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();
+#ifdef PFC_STAMPS
+            c_w1 += __builtin_amdgcn_s_memtime() - w1a;
+#endif
             STAMP(u3);
             n_def = s_def[par];                     // read by everyone between this barrier and the next
             if (tid == 0) s_def[par ^ 1] = 0;       // the next iteration's counter: its last readers passed a barrier ago
@@ -525,7 +531,13 @@ __global__ void __launch_bounds__(BLK, 4) k_bp_dfs32(Dfs32Args g) {
             }
             n_out += c_tot;
             sp += p_tot;
+#ifdef PFC_STAMPS
+            const unsigned long long w2a = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();
+#ifdef PFC_STAMPS
+            c_w2 += __builtin_amdgcn_s_memtime() - w2a;
+#endif
             if (n_out > kOut - BLK || (sp == 0 && n_def == 0 && n_out > 0)) {
                 flush_candidates<BLK>(g, ob, n_out, item, tid, &s_base);
                 n_cand += n_out;
@@ -539,6 +551,7 @@ __global__ void __launch_bounds__(BLK, 4) k_bp_dfs32(Dfs32Args g) {
 #endif
         }
 #ifdef PFC_STAMPS
+        if (lane == 0 && g.stamps) { atomicAdd(&g.stamps[0], c_w1); atomicAdd(&g.stamps[1], c_w2); atomicAdd(&g.stamps[2], c_it); }
         if (tid == 0 && g.stamps) {
             atomicAdd(&g.stamps[8], c_a); atomicAdd(&g.stamps[9], c_b); atomicAdd(&g.stamps[10], c_c);
             atomicAdd(&g.stamps[13], c_d); atomicAdd(&g.stamps[11], c_it); atomicAdd(&g.stamps[12], c_p);

@@ -12,15 +12,21 @@ out = (C.c_longlong * 16)()
 pfc._lib.lib().pfc_debug_stamps(m._h, out)
 v = [int(x) for x in out]
 names = ["gather", "clip", "reserve", "integrate", "reduce"]
-tot = sum(v[:5])
-print("rounds", v[5], "cycles/round", tot / max(v[5], 1))
+if v[5] == 0:      # the clip-only narrowphase of a big batch carries no stamps; slots 0..2 then hold the broadphase barrier waits
+    names = []
+tot = sum(v[:5]) if names else 0
+if names:
+    print("rounds", v[5], "cycles/round", tot / max(v[5], 1))
 for k, nm in enumerate(names):
     print(f"  {nm:10s} {v[k] / max(v[5], 1):10.0f} cycles/round  {100.0 * v[k] / max(tot, 1):5.1f} %")
 
-print("  reduce sub-phases (cycles/round): slot atomic + polygon store %.0f, ten sums %.0f, moments + record %.0f, counters %.0f" % (
+if names:
+  print("  reduce sub-phases (cycles/round): slot atomic + polygon store %.0f, ten sums %.0f, moments + record %.0f, counters %.0f" % (
     v[6] / max(v[5], 1), v[7] / max(v[5], 1), v[14] / max(v[5], 1), (v[4] - v[6] - v[7] - v[14]) / max(v[5], 1)))
 it = max(v[11], 1)
 print("broadphase workgroup iterations", v[11], "pairs/iteration %.1f" % (v[12] / it))
 tb = v[8] + v[9] + v[10] + v[13]
 for k, nm in ((8, "pop + node loads"), (9, "single-precision test"), (10, "ballots + barrier"), (13, "prefix + push + barrier")):
     print(f"  {nm:24s} {v[k] / it:10.0f} cycles/iteration  {100.0 * v[k] / max(tb, 1):5.1f} %")
+if v[2] and not names:
+    print("  inside the barriers (mean over the waves of a workgroup): first %.0f, second %.0f cycles/iteration" % (v[0] / v[2], v[1] / v[2]))
