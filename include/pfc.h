@@ -124,6 +124,8 @@ int pfc_check(pfc_handle h);
  * src/contact_algorithms_non_friction.jl:95); every branch compares values, as ForwardDiff's comparisons do.  The one
  * step that is not the reference's operation sequence is eigen!(Hermitian{Dual}) (src/contact_algorithms_friction.jl:88,
  * GenericLinearAlgebra): the partials of K̄^{-1/2} are its analytic Frechet derivative ("Dual path").
+ * An (item, direction) whose 36 seed components (d_pose 24, d_twist 6, d_s 6) are all zero has zero partials by
+ * linearity and is not evaluated: the cost of a chunk follows the instructions its seeded state variables touch.
  * Host buffers, synchronous.
  */
 int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, const double *pose, const double *twist,

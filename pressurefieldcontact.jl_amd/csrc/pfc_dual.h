@@ -121,6 +121,31 @@ struct DualArgs {
 };
 constexpr int kDpFields = 64;
 
+// Zero seeds.  Every output partial of a key (item, direction) is LINEAR in that key's 36 seed components (d_pose 24,
+// d_twist 6, d_s 6), so a key whose seeds are all zero has zero partials, whatever the values.  A chunk of a Radau
+// Jacobian seeds N_chunk state variables (src/radau/radau_functions.jl:2-14) and a contact instruction only depends on
+// the states of its two bodies (and its own bristle state), so for a scene of many bodies nearly all keys of nearly all
+// chunks are such zeros: the passes skip them (no gather, no clip, no kept polygon, no eigen-derivative) and
+// k_dual_final writes the zeros.  NaN != 0, so a non-finite seed is still evaluated.  The three kernels that decide
+// (k_narrow_dual per lane, k_dual_eig per wave, k_dual_final per thread) read the same 36 numbers: one verdict.
+__device__ __forceinline__ bool seed_nonzero(const DualArgs &g, int key) {
+    const double *p = g.d_pose + (size_t)key * 24, *t = g.d_twist + (size_t)key * 6, *s = g.d_s + (size_t)key * 6;
+    bool nz = false;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) nz |= p[k] != 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) nz |= (t[k] != 0.0) | (s[k] != 0.0);
+    return nz;
+}
+// the same verdict formed by a wave: lane k < 36 looks at one component
+__device__ __forceinline__ bool seed_nonzero_wave(const DualArgs &g, int key, int lane) {
+    double x = 0.0;
+    if (lane < 24) x = g.d_pose[(size_t)key * 24 + lane];
+    else if (lane < 30) x = g.d_twist[(size_t)key * 6 + (lane - 24)];
+    else if (lane < 36) x = g.d_s[(size_t)key * 6 + (lane - 30)];
+    return __ballot(x != 0.0) != 0ull;
+}
+
 // fan quadrature of one Dual polygon (integrate_over_polygon_patch!, non_friction.jl:217-265) with the pass-specific
 // integrand: MODE 0 normal wrench + regularized friction + cop sums, 1 patch stiffness about the cop, 2 bristle force
 // [k0, k1): the fan triangles (v_{k-1}, v_k, centroid) this lane integrates: all of them (0, n) with one lane per
@@ -259,6 +284,74 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
 __host__ __device__ inline int dual_pv_stride(int n_dir) { return 64 / n_dir <= 16 ? 16 : 64; }
 __host__ inline size_t dual_lds_bytes(int n_dir) { return sizeof(double) * (size_t)(8 * 4 * 64 + 8 * 4 * dual_pv_stride(n_dir)); }
 
+// Selection of the contributing pairs a chunk has work for (scenes of many items): k_dual_flags marks the items with a
+// non-zero seed in any direction (one wave per item), k_dual_select copies the contributing pairs of marked items into a
+// list of their own (compacted 2 048 entries at a time, order kept, so an item's pairs stay in runs).  The
+// passes then walk that list instead of all contributing pairs: the cost of a chunk follows the instructions its state
+// variables touch (C5, seeds of one body: 63 of 2 016 instructions).  Directions of a marked item whose own seeds are
+// zero are still skipped per key (seed_nonzero).
+__global__ void __launch_bounds__(64) k_dual_flags(DualArgs g, int *flag, int *selcount) {
+    const int item = blockIdx.x, lane = threadIdx.x;
+    if (item == 0 && lane == 0) *selcount = 0;      // k_dual_select runs behind this kernel on the stream
+    if (item >= g.n_items) return;
+    const size_t k0 = (size_t)item * g.n_dir;
+    const double *p = g.d_pose + k0 * 24, *t = g.d_twist + k0 * 6, *s = g.d_s + k0 * 6;
+    bool nz = false;
+    for (int k = lane; k < g.n_dir * 24; k += 64) nz |= p[k] != 0.0;
+    for (int k = lane; k < g.n_dir * 6; k += 64) nz |= (t[k] != 0.0) | (s[k] != 0.0);
+    const bool any = __ballot(nz) != 0ull;
+    if (lane == 0) flag[item] = any ? 1 : 0;
+}
+constexpr int kSelRounds = 8;      // a workgroup of k_dual_select compacts 256 x 8 consecutive list entries at a time
+__global__ void __launch_bounds__(256) k_dual_select(DualArgs g, const int *flag, int *sel, int *selcount) {
+    __shared__ int s_cnt[kSelRounds][4], s_base;
+    int n_c = *g.scount;
+    if (n_c > g.ccap) n_c = g.ccap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kChunk = 256 * kSelRounds;
+    // One returning atomic per 2 048 entries, and the entries of a chunk keep their order: the list stays in runs of an
+    // item's pairs in traversal order (a wave-granular append scattered 64-entry pieces over the list and cost the passes
+    // of a densely seeded 2 048-pose batch 7 %).
+    for (int c0 = (int)blockIdx.x * kChunk; c0 < n_c; c0 += (int)gridDim.x * kChunk) {      // uniform over the workgroup
+        int ci[kSelRounds];
+        unsigned keepm = 0;
+#pragma unroll
+        for (int r = 0; r < kSelRounds; ++r) {
+            const int idx = c0 + r * 256 + tid;
+            ci[r] = idx < n_c ? g.surv[idx] : -1;
+        }
+#pragma unroll
+        for (int r = 0; r < kSelRounds; ++r) {
+            bool keep = false;
+            if (ci[r] >= 0 && ci[r] < g.ccap) {
+                const int item = g.cand[ci[r]].item;
+                keep = (unsigned)item < (unsigned)g.n_items && flag[item] != 0;
+            }
+            const unsigned long long km = __ballot(keep);
+            if (keep) keepm |= 1u << r;
+            // position among the kept entries of this wave and round, kept in the upper bits of ci's companion
+            ci[r] = keep ? ci[r] : -1;
+            if (lane == 0) s_cnt[r][wave] = __popcll(km);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int r = 0; r < kSelRounds; ++r)
+                for (int w = 0; w < 4; ++w) { const int c = s_cnt[r][w]; s_cnt[r][w] = tot; tot += c; }
+            s_base = tot ? atomicAdd(selcount, tot) : 0;
+        }
+        __syncthreads();
+        const int base = s_base;
+#pragma unroll
+        for (int r = 0; r < kSelRounds; ++r) {
+            const bool keep = (keepm >> r) & 1u;
+            const unsigned long long km = __ballot(keep);
+            if (keep) sel[base + s_cnt[r][wave] + __popcll(km & ((1ull << lane) - 1ull))] = ci[r];
+        }
+        __syncthreads();      // s_cnt / s_base are rewritten by the next chunk
+    }
+}
+
 // Pass A: gather, clip and integrate in Dual arithmetic (normal wrench, regularized friction fused, cop sums); the
 // Dual polygon of every contributing bristle lane is kept for passes B and C (k_dual_poly).  TT as in k_narrow.
 template <bool TT>
@@ -292,7 +385,7 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
         const bool reg = it->model == PFC_REGULARIZED;
         const bool live = active && ci >= 0;
         const int key = live ? cw.item * n_dir + dir : -1;
-        const bool work = live && g.icnt[4 * (size_t)cw.item + 3] > 0;
+        const bool work = live && g.icnt[4 * (size_t)cw.item + 3] > 0 && seed_nonzero(g, key);   // zero seeds: zero partials (above)
         int n_poly = 0, rbase = 0;
         Du3 nh = dmk(du(0.0), du(0.0), du(0.0));
         if (work) {
@@ -645,6 +738,7 @@ __global__ void __launch_bounds__(64) k_dual_eig(DualArgs g) {
     const int item = key / g.n_dir;
     const ItemRec *it = g.items + item;
     if (it->model == PFC_REGULARIZED || g.icnt[4 * (size_t)item + 3] <= 0) return;   // uniform over the wave
+    if (!seed_nonzero_wave(g, key, lane)) return;      // zero seeds: the passes kept nothing for this key, k_dual_final writes zeros
     const double *a = g.dacc + (size_t)key * kDaStride;
     double *res = g.dres + (size_t)key * kDrStride;
     if (lane < 3) {
@@ -764,6 +858,10 @@ __global__ void __launch_bounds__(64) k_dual_final(DualArgs g) {
     const double *a = g.dacc + (size_t)key * kDaStride;
     double *ow = g.d_wrench + (size_t)key * 6, *os = g.d_sdot + (size_t)key * 6;
     const bool contact = g.icnt[4 * (size_t)item + 3] > 0;
+    if (!seed_nonzero(g, key)) {      // zero seeds: zero partials (the sums of this key were never formed)
+        for (int k = 0; k < 6; ++k) { ow[k] = 0.0; os[k] = 0.0; }
+        return;
+    }
     if (it->model == PFC_REGULARIZED) {
         for (int k = 0; k < 6; ++k) { ow[k] = contact ? a[kDaA + 10 + k] : 0.0; os[k] = 0.0; }
         return;

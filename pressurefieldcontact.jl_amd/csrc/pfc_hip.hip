@@ -262,6 +262,7 @@ struct pfc_context {
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     DevBuf<double> dual_in, dual_acc, dual_res, dual_out, dual_poly;   // pfc_eval_dual
     DevBuf<int2> dual_pkey;
+    DevBuf<int> dual_sel, dual_flag;                        // pairs a chunk has work for; per-item marks (+ the list's counter)
     DevBuf<double> scat_d;                                  // pfc_scatter_generalized
     DevBuf<int> scat_i;
     DevBuf<int> surv;                                       // candidate indices of contributing pairs
@@ -440,6 +441,7 @@ int eff_levels(const pfc_context *h) {
     return (h->opt_max_levels > 0 && h->opt_max_levels < h->max_levels) ? h->opt_max_levels : h->max_levels;
 }
 
+constexpr int kDualSelectMin = 512;       // items from which a Dual evaluation first selects the pairs its seeds touch
 constexpr int kBpSmallBlockMin = 4096;   // items per launch from which k_bp_dfs32 runs in 128-thread workgroups
 
 int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
@@ -899,7 +901,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->pin_dout) (void)hipHostFree(h->pin_dout);
     h->tail.release();
     h->rgn.release(); h->poly_item.release(); h->pcnt.release(); h->poly_cand.release(); h->poly.release(); h->surv.release(); h->scat_d.release(); h->scat_i.release();
-    h->dual_poly.release(); h->dual_pkey.release();
+    h->dual_poly.release(); h->dual_pkey.release(); h->dual_sel.release(); h->dual_flag.release();
     h->dual_in.release(); h->dual_acc.release(); h->dual_res.release(); h->dual_out.release(); h->dual_zero.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1362,6 +1364,17 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     HIP_TRY(h, ensure_dual(h, h->dual_pkey, dpcap));
     a.dpoly = h->dual_poly.p; a.dpoly_key = h->dual_pkey.p; a.dpcap = (long long)dpcap;
     if (dpcap_out) *dpcap_out = dpcap;
+    // Scenes of many items: the passes walk only the contributing pairs of items this chunk seeds (pfc_dual.h, k_dual_select).
+    // Two short launches; a small scene's chunk is a handful of waves either way and keeps its few launches.
+    if (!pair_count && n_items >= kDualSelectMin && std::getenv("PFC_NO_SELECT") == nullptr) {
+        HIP_TRY(h, ensure_dual(h, h->dual_sel, h->ccap));
+        HIP_TRY(h, ensure_dual(h, h->dual_flag, (size_t)n_items + 1));
+        int *selcount = h->dual_flag.p + n_items;
+        hipLaunchKernelGGL(k_dual_flags, dim3(n_items), dim3(64), 0, st, a, h->dual_flag.p, selcount);
+        hipLaunchKernelGGL(k_dual_select, dim3(grid_for(n_pairs_bound, 256 * kSelRounds, 256 * 8)), dim3(256), 0, st, a, h->dual_flag.p,
+                           h->dual_sel.p, selcount);
+        a.surv = h->dual_sel.p; a.scount = selcount;
+    }
     if (tt) hipLaunchKernelGGL((k_narrow_dual<true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
     else hipLaunchKernelGGL((k_narrow_dual<false>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
     if (h->any_bristle) {

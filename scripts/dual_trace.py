@@ -13,7 +13,7 @@ m = pfc.configs.build_scenario(w)
 dev = torch.device("cuda", 0)
 T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
 ni = w.n_items
-t = [T(w.ins_ids, torch.int32), T(w.pose), T(w.twist), T(w.s), T(np.zeros((ni, nd, 24))), T(np.zeros((ni, nd, 6))), T(np.zeros((ni, nd, 6)))]
+t = [T(w.ins_ids, torch.int32), T(w.pose), T(w.twist), T(w.s), T(np.random.default_rng(7).standard_normal((ni, nd, 24)) * 1e-3), T(np.random.default_rng(8).standard_normal((ni, nd, 6)) * 1e-2), T(np.random.default_rng(9).standard_normal((ni, nd, 6)) * 1e-4)]      # dense seeds (zero keys are skipped)
 o = [torch.zeros((ni, 6), dtype=torch.float64, device=dev), torch.zeros((ni, 6), dtype=torch.float64, device=dev),
      torch.zeros((ni, nd, 6), dtype=torch.float64, device=dev), torch.zeros((ni, nd, 6), dtype=torch.float64, device=dev),
      torch.zeros((ni, 4), dtype=torch.int32, device=dev)]

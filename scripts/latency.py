@@ -31,10 +31,13 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
     st = m.stats()
     print(f"{name:45s} {dt*1e6:9.1f} us/eval   ops {st['candidates']:8d}  node tests {st['node_tests']:9d}  "
           f"-> {st['candidates']/dt:.3g} ops/s, {w.n_items/dt:.3g} contact pairs/s")
-    # the Dual evaluation of the same scene (6 partials, zero seeds: same work), alternating with value evaluations as
-    # Radau does
+    # the Dual evaluation of the same scene (6 partials, DENSE seeds: every (item, direction) carries non-zero partials --
+    # keys whose seeds are all zero are skipped by the Dual passes, see the sparse figures below), alternating with value
+    # evaluations as Radau does
     nd = 6
-    dz = (np.zeros((w.n_items, nd, 24)), np.zeros((w.n_items, nd, 6)), np.zeros((w.n_items, nd, 6)))
+    rng = np.random.default_rng(7)
+    dz = (rng.standard_normal((w.n_items, nd, 24)) * 1e-3, rng.standard_normal((w.n_items, nd, 6)) * 1e-2,
+          rng.standard_normal((w.n_items, nd, 6)) * 1e-4)
     for _ in range(3):
         m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *dz, w.ins_ids)
     def pair():
@@ -73,6 +76,31 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
             m.check()
         dual_dev()
         print(f"{'':45s} {med(more_dev, blocks=6, per=10)[0] * 1e6:9.1f} us/further Dual eval, device-resident (pfc_eval_dual_device_more)")
+        # What a chunk of a Radau Jacobian looks like for a scene of many bodies: N_chunk = 6 state variables of ONE body
+        # are seeded, so only the instructions that body takes part in carry non-zero partials (C5: 63 of 2 016; C4: the
+        # one scene of 256 the body belongs to); all other keys are zero and skipped.
+        act = None
+        if "n_body" in w.meta:
+            nb, k, pairs = w.meta["n_body"], 0, []
+            for i in range(nb):
+                for j in range(i + 1, nb):
+                    pairs.append((i, j))
+            act = np.array([5 in pr for pr in pairs])
+        elif ni == 256:
+            act = np.zeros(ni, dtype=bool); act[17] = True
+        if act is not None:
+            ds_ = [x * act[:, None, None] for x in dz]
+            ts = [T(x) for x in ds_]
+            def more_sparse():
+                m.eval_dual_device_more(nd, ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), st)
+                m.check()
+            dual_dev()
+            print(f"{'':45s} {med(more_sparse, blocks=6, per=10)[0] * 1e6:9.1f} us/further Dual eval, device-resident, seeds of one body's states "
+                  f"({int(act.sum())} of {ni} instructions carry partials)")
+            def again_sparse():
+                return m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *ds_, w.ins_ids)
+            again_sparse()
+            print(f"{'':45s} {med(again_sparse, blocks=6, per=10)[0] * 1e6:9.1f} us/further Dual eval, host buffers, the same seeds")
     except ImportError:
         pass
     m.close()

@@ -374,6 +374,86 @@ def test_dual_device_more_directions(pfc):
     m.close()
 
 
+@pytest.mark.parametrize("cfg", ["pile", "c3batch", "c4", "volvol"])
+def test_zero_seeds_are_skipped_and_give_zero_partials(pfc, cfg):
+    """Every partial of an (item, direction) is linear in that key's 36 seed components, so the Dual passes skip keys
+    whose seeds are all zero (what nearly all keys of a Radau chunk are in a scene of many bodies: a contact instruction
+    depends on the states of its two bodies only).  Checked: a sparsely seeded evaluation returns exact zeros for the
+    zero keys and, for the others, what the densely seeded evaluation returns for the same seeds (the keys do not mix);
+    values and counters do not depend on the seeds; a key seeded in its bristle state alone is evaluated; the same on the
+    reused value pass and through the device entry points."""
+    import torch
+    rng = np.random.default_rng(47)
+    if cfg == "pile":
+        w = pfc.configs.c5_pile(n_side=3, n_divs=(1, 2, 3))        # 351 bristle instructions over different meshes
+    elif cfg == "c3batch":
+        w = pfc.configs.c3_blob_tool(300, seed=5, n_div_blob=6, n_div_tool=4)     # beyond the small-scene limits
+    elif cfg == "c4":
+        w = pfc.configs.c2_box_on_plane(40, montecarlo=True)       # regularized
+    else:
+        w = pfc.configs.vol_vol(6, model="bristle")                # tet-tet
+    n, nd = w.n_items, 6
+    w.s[:] = rng.standard_normal((n, 6)) * 1e-3
+    dense = (rng.standard_normal((n, nd, 24)) * 1e-2, rng.standard_normal((n, nd, 6)) * 0.1, rng.standard_normal((n, nd, 6)) * 1e-3)
+    mask = rng.random((n, nd)) < 0.15          # keys that keep their seeds
+    mask[rng.integers(0, n, 5)] = False        # some items without any seeded direction
+    sparse = [x * mask[:, :, None] for x in dense]
+    only_s = np.zeros((n, nd), dtype=bool)     # keys seeded in the bristle state alone
+    only_s[rng.integers(0, n, 7), rng.integers(0, nd, 7)] = True
+    only_s &= ~mask
+    sparse[2] = sparse[2] + dense[2] * only_s[:, :, None]
+    live = mask | only_s
+
+    def fresh(sd):
+        f = pfc.configs.build_scenario(w)
+        f.set_option("dual_reuse", 0)
+        out = f.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd, w.ins_ids)
+        f.close()
+        return out
+
+    want_dense = fresh(dense)
+    # the s-only keys against a dense evaluation of exactly those seeds
+    s_only_seeds = (dense[0] * mask[:, :, None], dense[1] * mask[:, :, None], sparse[2])
+    m = pfc.configs.build_scenario(w)
+    got = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sparse, w.ins_ids)
+    again = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sparse, w.ins_ids)       # the reused value pass
+    for g in (got, again):
+        assert np.array_equal(g[4], want_dense[4])
+        np.testing.assert_allclose(g[0], want_dense[0], rtol=1e-12, atol=1e-12 * np.abs(want_dense[0]).max())
+        np.testing.assert_allclose(g[1], want_dense[1], rtol=1e-9, atol=1e-9 * max(np.abs(want_dense[1]).max(), 1e-300))
+        assert np.all(g[2][~live] == 0.0) and np.all(g[3][~live] == 0.0)
+        # seeded in pose / twist / state exactly as in the dense evaluation: the same partials
+        same = mask & (np.abs(dense[2]).max(axis=2) >= 0)      # (all of mask: d_s is kept with the other seeds)
+        np.testing.assert_allclose(g[2][same], want_dense[2][same], rtol=1e-10, atol=1e-10 * np.abs(want_dense[2]).max())
+        np.testing.assert_allclose(g[3][same], want_dense[3][same], rtol=1e-7, atol=1e-7 * max(np.abs(want_dense[3]).max(), 1e-300))
+    # linearity for the s-only keys: d sdot = -(K^-1/2 ... + I) ds / tau is what a dense evaluation with the other seeds
+    # removed gives
+    zp = (np.zeros_like(dense[0]), np.zeros_like(dense[1]), dense[2] * only_s[:, :, None])
+    want_s = fresh(zp)
+    np.testing.assert_allclose(got[3][only_s], want_s[3][only_s], rtol=1e-9, atol=1e-9 * max(np.abs(want_s[3]).max(), 1e-300))
+    np.testing.assert_allclose(got[2][only_s], want_s[2][only_s], rtol=1e-9, atol=1e-9 * max(np.abs(want_dense[2]).max(), 1e-300))
+    # device entry points
+    dev = torch.device("cuda", 0)
+    T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    t = [T(w.ins_ids, torch.int32), T(w.pose), T(w.twist), T(w.s)] + [T(x) for x in sparse]
+    o = [torch.zeros((n, 6), dtype=torch.float64, device=dev), torch.zeros((n, 6), dtype=torch.float64, device=dev),
+         torch.full((n, nd, 6), 7.0, dtype=torch.float64, device=dev), torch.full((n, nd, 6), 7.0, dtype=torch.float64, device=dev),
+         torch.zeros((n, 4), dtype=torch.int32, device=dev)]
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(40):
+        m.eval_dual_device(n, nd, *[x.data_ptr() for x in t], *[x.data_ptr() for x in o], st)
+        if m.check() == 0:
+            break
+    np.testing.assert_allclose(o[2].cpu().numpy(), got[2], rtol=1e-10, atol=1e-10 * np.abs(want_dense[2]).max())
+    np.testing.assert_allclose(o[3].cpu().numpy(), got[3], rtol=1e-7, atol=1e-7 * max(np.abs(want_dense[3]).max(), 1e-300))
+    o[2].fill_(7.0); o[3].fill_(7.0)
+    m.eval_dual_device_more(nd, t[4].data_ptr(), t[5].data_ptr(), t[6].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), st)
+    assert m.check() == 0
+    assert np.all(o[2].cpu().numpy()[~live] == 0.0) and np.all(o[3].cpu().numpy()[~live] == 0.0)
+    np.testing.assert_allclose(o[2].cpu().numpy(), got[2], rtol=1e-10, atol=1e-10 * np.abs(want_dense[2]).max())
+    m.close()
+
+
 @pytest.mark.parametrize("poison", [0, 1])
 @pytest.mark.parametrize("cfg", ["c1", "c2", "pencil", "tight"])
 def test_dual_device_on_small_scenes(pfc, cfg, poison):
