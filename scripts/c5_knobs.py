@@ -25,7 +25,7 @@ def med(f, blocks=6, per=20):
     return float(np.median(ts)) * 1e6
 
 
-for bfs, clip in itertools.product((-1, 0, 1, 3), (1024,)):
+for bfs, clip in itertools.product((-1, 0, 1, 2), (1024, 0)):
     m = pfc.configs.build_scenario(w)
     m.set_option("bfs_levels", bfs)
     m.set_option("clip_min", clip)
