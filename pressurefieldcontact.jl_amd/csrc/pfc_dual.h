@@ -118,6 +118,7 @@ struct DualArgs {
     double *dpoly;
     int2 *dpoly_key;         // (item * n_dir + dir, n_poly)
     long long dpcap;
+    int tri_split;           // k_dual_poly: 1 = one lane per (kept polygon, fan triangle) instead of one per polygon (small scenes)
 };
 constexpr int kDpFields = 64;
 
@@ -680,15 +681,24 @@ __global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
     const size_t P = (size_t)g.dpcap;
     const long long stride = (long long)gridDim.x * 64;
     constexpr int NS = MODE == 1 ? 21 : 6;
+    // Smallest scenes (tri_split): a lane takes ONE fan triangle of a kept polygon (8 lanes per slot) -- a chunk of a
+    // pencil-scale bristle pair is a few waves whose time is the serial walk of a lane over its polygon's <= 8 triangles x 3
+    // points of Dual arithmetic; the sums are linear, so the per-key reduction below adds the triangles up.  Everything
+    // larger keeps one lane per polygon (header and vertices loaded once, an eighth of the waves and of their atomics).
+    const int ts = g.tri_split ? 8 : 1;
+    n_p *= ts;
     for (long long idx0 = (long long)blockIdx.x * 64; idx0 < n_p; idx0 += stride) {
-        const long long idx = idx0 + lane;
-        const bool active = idx < n_p;
+        const long long lidx = idx0 + lane;
+        const bool active = lidx < n_p;
+        const long long idx = ts == 8 ? (lidx >> 3) : lidx;      // the slot
+        const int tri = ts == 8 ? (int)(lidx & 7) : 0;
         Du sum[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) sum[k] = du(0.0);
         int key = -1, n_trac = 0;
         int2 kn = make_int2(-1, 0);
         if (active) kn = g.dpoly_key[idx];
+        if (ts == 8 && tri >= kn.y) kn.x = -1;      // this polygon has fewer fan triangles
         if (kn.x >= 0) {
             key = kn.x;
             const int n = kn.y;
@@ -713,7 +723,7 @@ __global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
                     const double *q = o + (size_t)(16 + 6 * k) * P;
                     return dmk(du(q[0], q[3 * P]), du(q[P], q[4 * P]), du(q[2 * P], q[5 * P]));
                 },
-                n, nh, cen, er, it, g.d_twist + (size_t)key * 6, false, cop, Da, Dl, sum, n_trac, 0, n);
+                n, nh, cen, er, it, g.d_twist + (size_t)key * 6, false, cop, Da, Dl, sum, n_trac, ts == 8 ? tri : 0, ts == 8 ? tri + 1 : n);
         }
         double flat[2 * NS];
 #pragma unroll

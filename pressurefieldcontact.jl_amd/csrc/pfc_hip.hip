@@ -1377,8 +1377,11 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     }
     if (tt) hipLaunchKernelGGL((k_narrow_dual<true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
     else hipLaunchKernelGGL((k_narrow_dual<false>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+    // a few dozen kept polygons only (pencil-scale pair: 116 -> 103 us per chunk): with more, the eightfold number of
+    // waves costs more in per-key atomics on the same few rows than the shorter walk saves (single C3 pose: 97 -> 113 us)
+    a.tri_split = (h->any_bristle && dpcap * 8 <= 16384) ? 1 : 0;
     if (h->any_bristle) {
-        const int pgrid = grid_for(dpcap, 64, 256 * 16);
+        const int pgrid = grid_for(dpcap * (a.tri_split ? 8 : 1), 64, 256 * 16);
         hipLaunchKernelGGL((k_dual_poly<1>), dim3(pgrid), dim3(64), 0, st, a);
         hipLaunchKernelGGL(k_dual_eig, dim3((unsigned)nk), dim3(64), 0, st, a);   // one wave per (item, direction)
         hipLaunchKernelGGL((k_dual_poly<2>), dim3(pgrid), dim3(64), 0, st, a);
