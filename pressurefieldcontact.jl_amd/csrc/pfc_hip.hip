@@ -1366,7 +1366,11 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     if (dpcap_out) *dpcap_out = dpcap;
     // Scenes of many items: the passes walk only the contributing pairs of items this chunk seeds (pfc_dual.h, k_dual_select).
     // Two short launches; a small scene's chunk is a handful of waves either way and keeps its few launches.
-    if (!pair_count && n_items >= kDualSelectMin && std::getenv("PFC_NO_SELECT") == nullptr) {
+    // (not while the stream is being captured -- the one-graph path of up to 512 items records these launches, and the
+    // lists below may have to be allocated; a captured chunk keeps the per-key skip only)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (!pair_count && n_items >= kDualSelectMin && cap == hipStreamCaptureStatusNone && std::getenv("PFC_NO_SELECT") == nullptr) {
         HIP_TRY(h, ensure_dual(h, h->dual_sel, h->ccap));
         HIP_TRY(h, ensure_dual(h, h->dual_flag, (size_t)n_items + 1));
         int *selcount = h->dual_flag.p + n_items;

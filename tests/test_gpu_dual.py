@@ -374,6 +374,42 @@ def test_dual_device_more_directions(pfc):
     m.close()
 
 
+def test_one_graph_path_at_the_selection_threshold(pfc):
+    """512 items: the largest scene of the one-graph Dual path and the smallest that selects the pairs its seeds touch.
+    A fresh handle records that graph with the selection lists still unallocated (an allocation inside a stream capture
+    fails: found by scripts/soak_threads.py) -- the captured sequence must do without the selection; later chunks at the
+    same point, launched eagerly, use it.  All equal a handle that never reuses."""
+    rng = np.random.default_rng(53)
+    w = pfc.configs.c3_blob_tool(512, seed=6, n_div_blob=5, n_div_tool=4)
+    n, nd = w.n_items, 6
+    w.s[:] = rng.standard_normal((n, 6)) * 1e-3
+
+    def seeds():
+        return (rng.standard_normal((n, nd, 24)) * 1e-2, rng.standard_normal((n, nd, 6)) * 0.1, rng.standard_normal((n, nd, 6)) * 1e-3)
+
+    m = pfc.configs.build_scenario(w)
+    f = pfc.configs.build_scenario(w)
+    f.set_option("dual_reuse", 0)
+    # a Dual evaluation of a few items first: the pair count it leaves opens the one-graph path for the 512 that follow,
+    # and nothing so far has allocated the selection lists
+    sd0 = seeds()
+    m.force_all_elastic_intersections_dual(w.pose[:64], w.twist[:64], w.s[:64], sd0[0][:64], sd0[1][:64], sd0[2][:64], w.ins_ids[:64])
+    for k in range(5):
+        pose = w.pose.copy()
+        if k in (1, 2):
+            pose[:, 21:24] += 1e-5 * k       # new points: the graph is recorded / replayed; k = 3, 4 repeat the point of k = 2
+        elif k > 2:
+            pose[:, 21:24] += 2e-5
+        sd = seeds()
+        got = m.force_all_elastic_intersections_dual(pose, w.twist, w.s, *sd, w.ins_ids)
+        want = f.force_all_elastic_intersections_dual(pose, w.twist, w.s, *sd, w.ins_ids)
+        assert np.array_equal(got[4], want[4])
+        for x, y, tol in ((want[0], got[0], 1e-10), (want[1], got[1], 1e-6), (want[2], got[2], 1e-8), (want[3], got[3], 1e-5)):
+            np.testing.assert_allclose(y, x, rtol=tol, atol=tol * max(np.abs(x).max(), 1e-300))
+    assert m.last_dual_reused()
+    m.close(); f.close()
+
+
 @pytest.mark.parametrize("cfg", ["pile", "c3batch", "c4", "volvol"])
 def test_zero_seeds_are_skipped_and_give_zero_partials(pfc, cfg):
     """Every partial of an (item, direction) is linear in that key's 36 seed components, so the Dual passes skip keys
