@@ -6,7 +6,8 @@ import test_gpu_parity as T
 import pfc_pkg
 pfc = pfc_pkg.load()
 bad = 0
-for seed in range(200, 212):
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 12      # 4 x 400 fuzz items per seed, each against the CPU oracle
+for seed in range(200, 200 + n_seeds):
     for degenerate in (False, True):
         for tet_tet in (False, True):
             rng = np.random.default_rng(seed)
@@ -24,4 +25,4 @@ for seed in range(200, 212):
                     print("MISMATCH", seed, degenerate, tet_tet, k, counts[k], ref[k].counts)
             m.close()
     print("seed", seed, "done, mismatches so far", bad, flush=True)
-print("total mismatches", bad)
+print(f"{n_seeds * 4 * 400} fuzz items ({n_seeds} seeds x regular / degenerate x tri-tet / tet-tet), total mismatches", bad)
