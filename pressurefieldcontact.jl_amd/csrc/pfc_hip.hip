@@ -1375,7 +1375,8 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
         HIP_TRY(h, ensure_dual(h, h->dual_flag, (size_t)n_items + 1));
         int *selcount = h->dual_flag.p + n_items;
         hipLaunchKernelGGL(k_dual_flags, dim3(n_items), dim3(64), 0, st, a, h->dual_flag.p, selcount);
-        hipLaunchKernelGGL(k_dual_select, dim3(grid_for(n_pairs_bound, 256 * kSelRounds, 256 * 8)), dim3(256), 0, st, a, h->dual_flag.p,
+        // (grid from the list's capacity, not from n_pairs_bound: the first evaluation of a handle has no pair count to go by)
+        hipLaunchKernelGGL(k_dual_select, dim3(grid_for(h->ccap, 256 * kSelRounds, 256 * 8)), dim3(256), 0, st, a, h->dual_flag.p,
                            h->dual_sel.p, selcount);
         a.surv = h->dual_sel.p; a.scount = selcount;
     }
