@@ -5,8 +5,11 @@
 //   pfc_bp.h       broadphase: k_bp_expand (seed levels), k_bp_dfs32 (single-precision workgroup descent with the
 //                  cooperative exact test), k_bp_dfs (all-Float64 descent, A/B option)         [tree_types.jl:88-111]
 //   pfc_np.h       narrowphase: k_narrow (gather, clip in an LDS polygon ring, fan quadrature, pressure, regularized
-//                  friction, bristle moments, kept polygons), k_fric (bristle friction over kept polygons)
-//   pfc_dual.h     the same path on (value, partial) numbers: k_narrow_dual, k_dual_poly, k_dual_eig, k_dual_final
+//                  friction, bristle moments, kept polygons; MODE 2 = clip only for big batches), k_integ (quadrature
+//                  and per-item sums over the compacted polygons), k_fric (bristle friction over kept polygons)
+//   pfc_fused.h    k_fused: a small scene's whole evaluation in one launch, one workgroup per item
+//   pfc_dual.h     the same path on (value, partial) numbers: k_dual_flags / k_dual_select (the pairs a chunk's seeds
+//                  touch), k_narrow_dual, k_dual_poly, k_dual_eig, k_dual_final
 //   pfc_br.h       k_shift, k_eig (6x6 Jacobi, one wave per item), k_final (+ result packing), k_scatter, k_selftest
 // This file: mesh record preparation (k_prep_tri, k_prep_tet), per-item setup (k_setup_items), work-list management,
 // hipGraph capture / replay, the two-half evaluation and every extern "C" entry point.
