@@ -170,3 +170,29 @@ def test_tet_tet_normal_force(pfc, backend):
     # the side tets carry their own field near the rim, so the flat-punch value holds to O(pene / box_rad)
     assert -out[0][5] == pytest.approx(f_ana, rel=5e-3)
     np.testing.assert_allclose(out[0][3:], out[1][3:], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_tet_tet_frictionless_spin_is_conserved(pfc, backend):
+    """test/test_vol_vol.jl: a compliant box spinning about z (w_z = 1.14) on the compliant half-plane with μd = 0 and
+    χ = 0 keeps its spin over 5 s of simulation (`data_state[end, 9] ≈ w_z_0`).  At the boundary of this path that is:
+    the contact wrench of the spinning box has no component about z -- neither at the plane's origin nor about the box's
+    axis when the box sits off-centre -- and equals the wrench of the box at rest (χ = 0: no damping)."""
+    G = pfc.geometry
+    box_rad, Ebar, w_z = 0.05, 1.0e6, 1.14
+    plane = G.as_tet_emesh(G.emesh_half_plane())
+    box = G.as_tet_emesh(G.emesh_box(box_rad))
+    ins = dict(model="regularized", chi=0.0, n_quad=2, mu_s=0.0, mu_d=0.0, v_c=0.01)
+    for shift in ((0.0, 0.0), (0.07, -0.03)):
+        pose = pfc.scenario.relative_pose(np.eye(3), [shift[0], shift[1], 2 * box_rad - box_rad - 0.001], np.eye(3), np.zeros(3))
+        # relative twist of the box about its own vertical axis, expressed at the plane frame's origin: v = -w x c
+        c = np.array([shift[0], shift[1], 0.0])
+        tw = np.concatenate([[0.0, 0.0, w_z], -np.cross([0.0, 0.0, w_z], c)])
+        spin = H.eval_scene(backend, pfc, box, Ebar, plane, Ebar, ins, pose, tw, None)
+        rest = H.eval_scene(backend, pfc, box, Ebar, plane, Ebar, ins, pose, np.zeros(6), None)
+        assert spin.status == 0 and spin.counts[3] > 0
+        f = spin.wrench[3:]
+        tau_axis = spin.wrench[:3] - np.cross(c, f)          # torque about the box's axis
+        assert abs(spin.wrench[2]) < 1e-9 * abs(f[2]) * box_rad and abs(tau_axis[2]) < 1e-9 * abs(f[2]) * box_rad
+        np.testing.assert_allclose(spin.wrench, rest.wrench, rtol=1e-12, atol=1e-12 * abs(f[2]))
+
