@@ -482,7 +482,16 @@ __global__ void __launch_bounds__(BLK, 4) k_bp_dfs32(Dfs32Args g) {
                     for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) q12[k] = s_q12[k];
+                    // Issue priority: the ~250 instructions of the test run at the default level, everything else of an
+                    // iteration (ballots, prefix, push, pop, the next node loads: a few dozen instructions between two
+                    // barriers and two memory round trips) one level above it.  In-kernel stamps had shown those short
+                    // phases taking as long as the test itself because they queue behind the tests of the other three
+                    // workgroups on the SIMD; with the raised level a wave reaches its barrier / gets its loads out
+                    // first (exclusive 2.06 -> 1.95 ms for the 8 192-pose batch, step 4.40 -> 4.27 ms; levels 1, 2, 3
+                    // alike).  The same in the clip kernel and k_integ changed nothing.
+                    __builtin_amdgcn_s_setprio(0);
                     verdict = test_pair_f32(a, b, la || lb, R12, q12, t12);
+                    __builtin_amdgcn_s_setprio(1);
                     if (s_pose_exact) verdict = 2;
                 }
             }
