@@ -210,12 +210,12 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
  * "bfs_levels" (-1 = automatic: level-synchronous seed expansion only until there are >= 2048 seed pairs),
  * "graph" (1 = capture the launch sequence into a hipGraph per evaluation shape and replay it; default 1),
  * "no_filter" (1 = run the whole broadphase in the exact Float64 kernel instead of the Float32 filter + Float64
- * resolver; same candidate set, for A/B checks), "split_min" (default 1024; 0 = never: an evaluation of at least
+ * resolver; same candidate set, for A/B checks), "split_min" (default 1152; 0 = never: an evaluation of at least
  * this many items with ins_ids given is run as two concurrent halves on two streams with their own work lists, the
  * vector-ALU-bound broadphase of one half sharing the CUs with the latency-bound narrowphase of the other; results,
  * counters and stream ordering are those of the unsplit call), "dual_reuse" (default 1: pfc_eval_dual compares the
  * value inputs of a call above the small-scene limits with those of the previous call and, if they are bitwise equal,
- * runs only the Dual passes on the previous call's value pass -- the chunks of one Jacobian), "clip_min" (default 1024; 0 = never: a launch of at
+ * runs only the Dual passes on the previous call's value pass -- the chunks of one Jacobian), "clip_min" (default 512; 0 = never: a launch of at
  * least this many items runs the narrowphase as a clip-only kernel that keeps every clipped polygon, followed by the
  * integration over the compacted polygons; same results up to the order of the sums), "poison" (diagnostic, default 0: before every
  * evaluation the work lists are filled with entries whose item index is -1; the kernels never follow an item index

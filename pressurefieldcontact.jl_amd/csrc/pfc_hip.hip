@@ -299,8 +299,8 @@ struct pfc_context {
     double *fu_dwrench = nullptr, *fu_dsdot = nullptr;
     int fu_ndir = 0;
     bool pending_fused = false, last_fused = false;
-    int opt_split_min = 1024;          // 0: never split
-    int opt_clip_min = 1024;           // items per launch from which the narrowphase runs as clip-only kernel + k_integ (break-even between 512 and 1024 C3 poses, scripts/sweep_clip.sh); 0: never
+    int opt_split_min = 1152;          // 0: never split.  (Paired sweep at the end of round 2, clip_min 512: 1 024 poses 0.81 ms unsplit / 0.90 split, 1 152 equal, 1 280 1.08 / 1.04, 2 048 1.50 / 1.29.)
+    int opt_clip_min = 512;            // items per launch from which the narrowphase runs as clip-only kernel + k_integ; 0: never.  (First set at 1 024 from scripts/sweep_clip.sh; a paired sweep with the final kernels: 512 poses 0.61 vs 0.63 ms, 768 0.80 vs 0.83, 1 536 as 2 x 768 1.14 vs 1.19, 1 920 1.33 vs 1.40; 384 poses and below are indifferent.)
     int opt_poison = 0;                // diagnostic: fill (re)allocated work lists with 0xFF bytes (item index -1)
     int split_n0 = 0;                  // items in the first half of the pending evaluation (0: not split)
     int last_parts = 1;                // 2 if the last checked evaluation ran as two halves
@@ -445,7 +445,7 @@ int eff_levels(const pfc_context *h) {
 }
 
 constexpr int kDualSelectMin = 512;       // items from which a Dual evaluation first selects the pairs its seeds touch
-constexpr int kBpSmallBlockMin = 4096;   // items per launch from which k_bp_dfs32 runs in 128-thread workgroups
+constexpr int kBpSmallBlockMin = 3072;   // items per launch from which k_bp_dfs32 runs in 128-thread workgroups (paired A/B: 2 048 per launch 2.31 vs 2.36 ms for 256 / 128 threads, 3 072 per launch 3.39 vs 3.30)
 
 int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
     int L = 0;
@@ -521,7 +521,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
             f.seed_cap = (int)h->fcap; f.cand = h->cand.p; f.ccount = ccount; f.ccap = (int)h->ccap;
             f.ucount = ucount; f.icnt = h->icnt.p; f.status = h->status.p; f.stamps = h->stamps.p;
             f.reserve = 3 * h->max_levels + 3; f.n_items = n_items;
-            // Workgroups of 128 threads for the big launches (>= 4 096 items, i.e. the halves of a step of >= 8 192): the
+            // Workgroups of 128 threads for the big launches (>= 3 072 items, i.e. the halves of a step of >= 6 144): the
             // kernel alone runs as fast either way (2.08 ms), but next to the other half's narrowphase the finer grain
             // shares the CUs better (8 192-pose step 4.53 -> 4.39 ms; 4 096: 2.33 vs 2.38, 2 048: 1.30 vs 1.45 -- a smaller
             // launch needs the 256 pairs per iteration; profiles/r02_sweep_bp_block.txt).  Grid = resident workgroups.
