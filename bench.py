@@ -157,7 +157,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the small-scene latency block")
     ap.add_argument("--friction", choices=["bristle", "regularized"], default="bristle",
                     help="friction model of the C3 instruction (BASELINE: bristle; regularized is an experiment knob)")
-    ap.add_argument("--split-min", type=int, default=-1, help="library option split_min (-1: library default 1152; 0: never split)")
+    ap.add_argument("--split-min", type=int, default=-1, help="library option split_min (-1: library default 1025; 0: never split)")
     ap.add_argument("--clip-min", type=int, default=-1, help="library option clip_min (-1: library default 512; 0: one-kernel narrowphase)")
     ap.add_argument("--bfs-levels", type=int, default=-1, help="broadphase BFS levels before the DFS kernel (-1 = auto)")
     args = ap.parse_args()

@@ -210,7 +210,7 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
  * "bfs_levels" (-1 = automatic: level-synchronous seed expansion only until there are >= 2048 seed pairs),
  * "graph" (1 = capture the launch sequence into a hipGraph per evaluation shape and replay it; default 1),
  * "no_filter" (1 = run the whole broadphase in the exact Float64 kernel instead of the Float32 filter + Float64
- * resolver; same candidate set, for A/B checks), "split_min" (default 1152; 0 = never: an evaluation of at least
+ * resolver; same candidate set, for A/B checks), "split_min" (default 1025; 0 = never: an evaluation of at least
  * this many items with ins_ids given is run as two concurrent halves on two streams with their own work lists, the
  * vector-ALU-bound broadphase of one half sharing the CUs with the latency-bound narrowphase of the other; results,
  * counters and stream ordering are those of the unsplit call), "dual_reuse" (default 1: pfc_eval_dual compares the

@@ -299,7 +299,7 @@ struct pfc_context {
     double *fu_dwrench = nullptr, *fu_dsdot = nullptr;
     int fu_ndir = 0;
     bool pending_fused = false, last_fused = false;
-    int opt_split_min = 1152;          // 0: never split.  (Paired sweep at the end of round 2, clip_min 512: 1 024 poses 0.81 ms unsplit / 0.90 split, 1 152 equal, 1 280 1.08 / 1.04, 2 048 1.50 / 1.29.)
+    int opt_split_min = 1025;          // 0: never split.  (Paired sweeps at the end of round 2: 1 024 poses -- one seed per resident broadphase workgroup -- 0.80 ms unsplit / 0.90 split; 1 100 0.95 / 0.93, 1 280 1.09 / 1.01, 2 048 1.50 / 1.28.)
     int opt_clip_min = 512;            // items per launch from which the narrowphase runs as clip-only kernel + k_integ; 0: never.  (First set at 1 024 from scripts/sweep_clip.sh; a paired sweep with the final kernels: 512 poses 0.61 vs 0.63 ms, 768 0.80 vs 0.83, 1 536 as 2 x 768 1.14 vs 1.19, 1 920 1.33 vs 1.40; 384 poses and below are indifferent.)
     int opt_poison = 0;                // diagnostic: fill (re)allocated work lists with 0xFF bytes (item index -1)
     int split_n0 = 0;                  // items in the first half of the pending evaluation (0: not split)
@@ -460,7 +460,9 @@ int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
         // Round 2 re-sweep for big trees (scripts/sweep_bfs_small.sh, C3 meshes: 1 pose 139 -> 125 us, 4 poses 167 -> 155,
         // 16 poses 215 -> 202, 64 poses 367 -> 309, 200 poses 519 -> 460): the fewer the items, the more seeds pay.
         const bool big = h->max_leaves >= 8192, mid = h->max_leaves >= 1024;
-        const double target = big ? (n_items >= 256 ? 1024.0 : (n_items >= 128 ? 3072.0 : (n_items >= 32 ? 16384.0 : 49152.0)))
+        // (end of round 2, final kernels: from ~600 items a seed level only costs -- 640 poses 0.71 vs 0.74 ms without /
+        // with one level, 768 0.73 vs 0.80, 1 023 0.80 vs 0.92; 512 and below are indifferent or gain)
+        const double target = big ? (n_items >= 600 ? 1.0 : (n_items >= 256 ? 1024.0 : (n_items >= 128 ? 3072.0 : (n_items >= 32 ? 16384.0 : 49152.0))))
                                   : (mid ? 1024.0 : 64.0);
         double seeds = (double)n_items;
         while (seeds < target && L < 9) { seeds *= 4.0; ++L; }
