@@ -462,7 +462,7 @@ int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
         const bool big = h->max_leaves >= 8192, mid = h->max_leaves >= 1024;
         // (end of round 2, final kernels: from ~600 items a seed level only costs -- 640 poses 0.71 vs 0.74 ms without /
         // with one level, 768 0.73 vs 0.80, 1 023 0.80 vs 0.92; 512 and below are indifferent or gain)
-        const double target = big ? (n_items >= 600 ? 1.0 : (n_items >= 256 ? 1024.0 : (n_items >= 128 ? 3072.0 : (n_items >= 32 ? 16384.0 : 49152.0))))
+        const double target = big ? (n_items >= 600 ? 1.0 : (n_items >= 256 ? 1024.0 : (n_items >= 128 ? 2048.0 : (n_items >= 32 ? 16384.0 : 49152.0))))
                                   : (mid ? 1024.0 : 64.0);
         double seeds = (double)n_items;
         while (seeds < target && L < 9) { seeds *= 4.0; ++L; }
