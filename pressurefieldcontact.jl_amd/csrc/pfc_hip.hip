@@ -303,6 +303,7 @@ struct pfc_context {
     int opt_clip_min = 512;            // items per launch from which the narrowphase runs as clip-only kernel + k_integ; 0: never.  (First set at 1 024 from scripts/sweep_clip.sh; a paired sweep with the final kernels: 512 poses 0.61 vs 0.63 ms, 768 0.80 vs 0.83, 1 536 as 2 x 768 1.14 vs 1.19, 1 920 1.33 vs 1.40; 384 poses and below are indifferent.)
     int opt_poison = 0;                // diagnostic: fill (re)allocated work lists with 0xFF bytes (item index -1)
     int split_n0 = 0;                  // items in the first half of the pending evaluation (0: not split)
+    bool in_split = false;             // this context's launches are one half of a two-half evaluation (set while they are enqueued)
     int last_parts = 1;                // 2 if the last checked evaluation ran as two halves
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -553,8 +554,16 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, 0>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
         else hipLaunchKernelGGL((k_narrow<false, 0>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
     } else {
-        if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, 2>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
-        else hipLaunchKernelGGL((k_narrow<false, 2>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        // a half of a two-half evaluation clips on the compacted ring (MODE 3, 12 KiB of LDS per wave: shares the CUs with the
+        // other half's kernels), a launch that has the chip to itself on a column per lane (MODE 2)
+        // (and a launch that does not quite fill the chip: 768 poses 0.72 vs 0.74 ms; 512 poses the other way, 0.63 vs 0.62)
+        if (h->in_split || (n_items >= 640 && n_items < 1024)) {
+            if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, 3>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+            else hipLaunchKernelGGL((k_narrow<false, 3>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        } else {
+            if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, 2>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+            else hipLaunchKernelGGL((k_narrow<false, 2>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        }
         IntegArgs ig;
         ig.items = h->items.p; ig.n_items = n_items; ig.ccount = ccount; ig.ccap = (int)h->ccap; ig.chunk_switch = kNpChunkSwitch;
         ig.pcnt = h->pcnt.p; ig.poly_item = h->poly_item.p; ig.poly = h->poly.p; ig.pcap = np.pcap;
@@ -611,7 +620,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
 #endif
     if (use_graph) {
         pfc_context::GraphKey key = {};
-        key.n_items = n_items; key.levels = levels; key.L = L; key.debug = h->opt_debug;
+        key.n_items = n_items; key.levels = levels; key.L = L; key.debug = (h->opt_debug ? 1 : 0) | (h->in_split ? 2 : 0);
         key.bristle = (h->any_bristle ? 1 : 0) | (h->any_tet_tet ? 2 : 0);
         key.surv = h->want_surv ? 1 : 0;
         key.p[0] = d_ins_ids; key.p[1] = d_pose; key.p[2] = d_twist; key.p[3] = d_s; key.p[4] = d_wrench;
@@ -1204,7 +1213,9 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
     // the second half starts when the caller's stream has reached this point and joins it again at the end
     HIP_TRY(h, hipEventRecord(h->ev_fork, st));
     HIP_TRY(h, hipStreamWaitEvent(t->stream, h->ev_fork, 0));
+    h->in_split = true; t->in_split = true;
     rc = enqueue_eval(h, n0, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
+    h->in_split = false;
     if (rc != PFC_OK) return rc;
     rc = enqueue_eval(t, n1, d_ins_ids + n0, d_pose + 24 * (size_t)n0, d_twist + 6 * (size_t)n0,
                       d_s ? d_s + 6 * (size_t)n0 : nullptr, d_wrench + 6 * (size_t)n0, d_sdot + 6 * (size_t)n0,

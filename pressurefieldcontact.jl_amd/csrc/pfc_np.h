@@ -72,8 +72,14 @@ __device__ __forceinline__ int np_chunk(int n_c, int chunk_switch) {
 
 // weightPoly (src/math_kernel/utility.jl:21-26) on 4-vectors held in LDS slots
 // polygon ring in LDS: 8 physical slots x 4 coords per lane, [slot][coord][lane] layout (conflict-free per-lane
-// dynamic indexing); logical vertex k of a lane lives in physical slot (rbase + k) & 7
-#define PR(k, c) poly[((((rbase) + (k)) & 7) * 4 + (c)) * kNpBlock + lane]
+// dynamic indexing); logical vertex k of a lane lives in physical slot (rbase + k) & 7.  RC columns, a lane uses column
+// rcol: its own lane number (RC = 64, 16 KiB: MODE 0, 1, 2), or its rank among the round's survivors of the trivial
+// reject (MODE 3, the clip-only kernel of a half of a two-half evaluation: RC = kRingColsClip = 48, 12 KiB -- ~35 of 64
+// candidates survive in the C3 batch, a round with more than 48 survivors takes a second pass for the rest).  The smaller
+// footprint lets the kernel share CUs with the other half's broadphase (8 192-pose step 4.22 -> 4.14 ms); a launch that has
+// the chip to itself is faster with a column per lane (2.01 vs 2.13 ms for the unsplit batch), hence both forms.
+constexpr int kRingColsClip = 48;
+#define PR(k, c) poly[((((rbase) + (k)) & 7) * 4 + (c)) * RC + rcol]
 
 __device__ __forceinline__ double readlane_f64(double v, int src) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
@@ -186,8 +192,9 @@ __device__ __forceinline__ double lds_row_sums(double *buf, const double *v, boo
 // every lane busy (here 46 % of the lanes are rejected candidates and a lane waits for the longest fan of its wave).
 template <bool TT, int MODE>
 __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
-    constexpr bool DBG = MODE == 1, CLIP = MODE == 2;
-    __shared__ double poly[8 * 4 * kNpBlock];
+    constexpr bool DBG = MODE == 1, CLIP = MODE == 2 || MODE == 3, COMPACT = MODE == 3;
+    constexpr int RC = COMPACT ? kRingColsClip : kNpBlock;
+    __shared__ double poly[8 * 4 * RC];
     const int lane = threadIdx.x;
     int n_c = *g.ccount;
     if (n_c > g.ccap) n_c = g.ccap;
@@ -219,8 +226,87 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         const bool reg = it->model == PFC_REGULARIZED;
         const bool materialise = DBG && active;
         const bool work = active;
-        int n_poly = 0, rbase = 0;
+        int n_poly = 0, rbase = 0, rcol = lane;
         V3 nh = mk3(0.0, 0.0, 0.0);
+        // input polygon (3 or 4 vertices) in the coordinates of tet 2, its normal, and whether it passed the trivial reject
+        double z[4][4];
+        int n_in = 0;
+        V3 nh_in = mk3(0.0, 0.0, 0.0);
+        bool survivor = false;
+        // ---- clip_in_tet_coordinates (static_clip.jl:7-23,34-201), polygon ring in LDS (column rcol), clipped in place ----
+        auto clip_ring = [&]() {
+            int n = n_in;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < n_in) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) PR(k, i) = z[k][i];
+                }
+            bool err = false;
+            for (int i = 0; i < 4 && n > 0; ++i) {
+                unsigned nonpos = 0, nonneg = 0;
+                for (int k = 0; k < n; ++k) {
+                    double sv = PR(k, i);
+                    nonpos |= (unsigned)(sv <= 0.0) << k;
+                    nonneg |= (unsigned)(0.0 <= sv) << k;
+                }
+                const unsigned full = (1u << n) - 1u;
+                if (nonpos == full) { n = 0; break; }       // :44
+                if (nonneg == full) continue;               // :45-46
+                // first k with is_non_pos[k] && !is_non_pos[k+1] (cyclic) (:48-50)
+                unsigned nxt = ((nonpos >> 1) | ((nonpos & 1u) << (n - 1))) & full;
+                unsigned cand_start = nonpos & ~nxt & full;
+                if (cand_start == 0) { err = true; n = 0; break; }  // "Non-finite vertex likely" (:52)
+                const int st = __builtin_ctz(cand_start);
+                // cut_clip (:135-195): drop trailing vertices while z_{m-1} is non-positive
+                int m = n;
+                while (m > 3) {
+                    int k2 = st + m - 2; if (k2 >= n) k2 -= n;
+                    if ((nonpos >> k2) & 1u) --m; else break;
+                }
+                int k1 = st + 1; if (k1 >= n) k1 -= n;
+                int kl = st + m - 1; if (kl >= n) kl -= n;   // z_m (last)
+                int kp = st + m - 2; if (kp >= n) kp -= n;   // z_{m-1}
+                // inside test of the last vertex: 0 < z for arity 3..5 (:140,150,162), 0 <= z for 6..7 (:176,188)
+                const bool inside = (m <= 5) ? (((nonpos >> kl) & 1u) == 0) : (((nonneg >> kl) & 1u) != 0);
+                // z_start = clip_node(z1, z2); z_end = clip_node(z1, z_m) or clip_node(z_m, z_{m-1}); both are
+                // formed in registers before the ring is touched
+                double zs[4], ze[4];
+                {
+                    double w1 = PR(st, i), w2 = PR(k1, i);
+                    double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) zs[c] = c1 * PR(k1, c) - c2 * PR(st, c);
+                }
+                {
+                    const int kn = inside ? st : kl, kq = inside ? kl : kp;
+                    double w1 = PR(kn, i), w2 = PR(kq, i);
+                    double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ze[c] = c1 * PR(kq, c) - c2 * PR(kn, c);
+                }
+                const int ncopy = inside ? (m - 1) : (m - 2);   // z2 .. z_m  or  z2 .. z_{m-1} stay in the polygon
+                // In place: the new polygon starts at old logical st.  Kept vertices st+1 .. n-1 do not move;
+                // kept vertices that wrapped around (old logical 0 .. ) move up by n slots, in increasing order
+                // (a destination is either a free slot or the source of an earlier move).
+                for (int q = n - st - 1; q < ncopy; ++q) {
+                    const int src = st + 1 + q - n, dst = st + 1 + q;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const double t = PR(src, c); PR(dst, c) = t; }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { PR(st, c) = zs[c]; PR(st + ncopy + 1, c) = ze[c]; }
+                rbase = (rbase + st) & 7;
+                n = ncopy + 2;
+                if (m == 7) break;  // the 7-vertex method returns the polygon directly (:185-195)
+            }
+            if (err) atomicOr(g.status, kStNonFinite);
+            n_poly = n;
+#if PFC_EXP == 4
+            if (nh_in.x > -1e300) n_poly = 0;
+#endif
+            if (n >= 3) nh = nh_in;
+        };
         // ==== phase 1 (divergent): gather, transform to tet coordinates, clip ========================================
         if (work) {
             double R21[9], t21[3];
@@ -228,9 +314,6 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             for (int k = 0; k < 9; ++k) R21[k] = it->R21[k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) t21[k] = it->t21[k];
-            double z[4][4];      // input polygon (3 or 4 vertices) in the coordinates of tet 2
-            int n_in = 0;
-            V3 nh_in = mk3(0.0, 0.0, 0.0);
             double Z[16];        // x_ζ2_r2
 #pragma unroll
             for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
@@ -367,86 +450,32 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
 #endif
             if (!reject) {
                 STAMP(t1);
-                // ---- clip_in_tet_coordinates (static_clip.jl:7-23,34-201), polygon ring in LDS, clipped in place ---
-                int n = n_in;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < n_in) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) PR(k, i) = z[k][i];
-                    }
-                bool err = false;
-                for (int i = 0; i < 4 && n > 0; ++i) {
-                    unsigned nonpos = 0, nonneg = 0;
-                    for (int k = 0; k < n; ++k) {
-                        double sv = PR(k, i);
-                        nonpos |= (unsigned)(sv <= 0.0) << k;
-                        nonneg |= (unsigned)(0.0 <= sv) << k;
-                    }
-                    const unsigned full = (1u << n) - 1u;
-                    if (nonpos == full) { n = 0; break; }       // :44
-                    if (nonneg == full) continue;               // :45-46
-                    // first k with is_non_pos[k] && !is_non_pos[k+1] (cyclic) (:48-50)
-                    unsigned nxt = ((nonpos >> 1) | ((nonpos & 1u) << (n - 1))) & full;
-                    unsigned cand_start = nonpos & ~nxt & full;
-                    if (cand_start == 0) { err = true; n = 0; break; }  // "Non-finite vertex likely" (:52)
-                    const int st = __builtin_ctz(cand_start);
-                    // cut_clip (:135-195): drop trailing vertices while z_{m-1} is non-positive
-                    int m = n;
-                    while (m > 3) {
-                        int k2 = st + m - 2; if (k2 >= n) k2 -= n;
-                        if ((nonpos >> k2) & 1u) --m; else break;
-                    }
-                    int k1 = st + 1; if (k1 >= n) k1 -= n;
-                    int kl = st + m - 1; if (kl >= n) kl -= n;   // z_m (last)
-                    int kp = st + m - 2; if (kp >= n) kp -= n;   // z_{m-1}
-                    // inside test of the last vertex: 0 < z for arity 3..5 (:140,150,162), 0 <= z for 6..7 (:176,188)
-                    const bool inside = (m <= 5) ? (((nonpos >> kl) & 1u) == 0) : (((nonneg >> kl) & 1u) != 0);
-                    // z_start = clip_node(z1, z2); z_end = clip_node(z1, z_m) or clip_node(z_m, z_{m-1}); both are
-                    // formed in registers before the ring is touched
-                    double zs[4], ze[4];
-                    {
-                        double w1 = PR(st, i), w2 = PR(k1, i);
-                        double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) zs[c] = c1 * PR(k1, c) - c2 * PR(st, c);
-                    }
-                    {
-                        const int kn = inside ? st : kl, kq = inside ? kl : kp;
-                        double w1 = PR(kn, i), w2 = PR(kq, i);
-                        double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) ze[c] = c1 * PR(kq, c) - c2 * PR(kn, c);
-                    }
-                    const int ncopy = inside ? (m - 1) : (m - 2);   // z2 .. z_m  or  z2 .. z_{m-1} stay in the polygon
-                    // In place: the new polygon starts at old logical st.  Kept vertices st+1 .. n-1 do not move;
-                    // kept vertices that wrapped around (old logical 0 .. ) move up by n slots, in increasing order
-                    // (a destination is either a free slot or the source of an earlier move).
-                    for (int q = n - st - 1; q < ncopy; ++q) {
-                        const int src = st + 1 + q - n, dst = st + 1 + q;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) { const double t = PR(src, c); PR(dst, c) = t; }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { PR(st, c) = zs[c]; PR(st + ncopy + 1, c) = ze[c]; }
-                    rbase = (rbase + st) & 7;
-                    n = ncopy + 2;
-                    if (m == 7) break;  // the 7-vertex method returns the polygon directly (:185-195)
-                }
-                if (err) atomicOr(g.status, kStNonFinite);
-                n_poly = n;
-#if PFC_EXP == 4
-                if (nh_in.x > -1e300) n_poly = 0;
-#endif
-                if (n >= 3) nh = nh_in;
+                survivor = true;
+                if constexpr (!COMPACT) clip_ring();      // (MODE 3 clips below, on the compacted ring)
             }
         }
         if (DBG && g.clip_n && active) g.clip_n[idx] = n_poly;
         STAMP(t2);
         if constexpr (CLIP) {
             // ==== clip-only mode: polygon set-up, kept polygon, non-empty count; k_integ does the rest ==================
-            const bool has_poly = work && n_poly >= 3;
-            const unsigned long long km = __ballot(has_poly), am = __ballot(active);
+            const unsigned long long sm = COMPACT ? __ballot(survivor) : 1ull, am = __ballot(active);
+            const int rank = COMPACT ? __popcll(sm & ((1ull << lane) - 1ull)) : 0, n_surv = __popcll(sm);
+            unsigned long long km_all = 0ull;
+            bool has_poly_any = false;
+            // MODE 3: wave-uniform passes over the survivors, RC at a time (a second pass is rare: > 48 survivors of 64);
+            // MODE 2: one pass, every lane clipped above on its own column
+            for (int pass0 = 0; pass0 < n_surv; pass0 += RC) {
+            bool mine = survivor;
+            if constexpr (COMPACT) {
+                mine = survivor && rank >= pass0 && rank < pass0 + RC;
+                rcol = rank - pass0;
+                rbase = 0; n_poly = 0;
+                if (mine) clip_ring();
+            }
+            const bool has_poly = mine && n_poly >= 3;
+            has_poly_any |= has_poly;
+            const unsigned long long km = __ballot(has_poly);
+            km_all |= km;
             const int slot = ch * C + pc + __popcll(km & ((1ull << lane) - 1ull));
             pc += __popcll(km);
             if (has_poly) {
@@ -487,12 +516,14 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                 if (g.poly_cand) NT_(&g.poly_cand[slot], idx);
 #undef NT_
             }
-            if (km) {
+            // (the LDS unit serves a wave's instructions in order: the next pass may overwrite the ring)
+            }
+            if (km_all) {
                 const int item_first = __builtin_amdgcn_readlane(cw.item, __builtin_ctzll(am));
                 if (__all(!active || cw.item == item_first)) {
-                    if (lane == 0) atomicAdd(&g.icnt[4 * (size_t)item_first + 2], __popcll(km));
+                    if (lane == 0) atomicAdd(&g.icnt[4 * (size_t)item_first + 2], __popcll(km_all));
                 } else {
-                    count_per_item(g.icnt, cw.item, 2, active, has_poly);
+                    count_per_item(g.icnt, cw.item, 2, active, has_poly_any);
                 }
             }
             continue;

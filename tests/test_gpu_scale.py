@@ -434,6 +434,38 @@ def test_clip_and_integrate_split_equals_the_one_kernel_narrowphase(pfc):
         assert np.abs(out[1][1] - sref).max() <= 1e-6 * max(np.abs(sref).max(), 1e-300), w.name
 
 
+@pytest.mark.parametrize("n_scene", [700, 1300])
+def test_clip_on_the_compacted_ring(pfc, n_scene):
+    """The clip-only kernel of a half of a two-half evaluation (1 300 scenes) and of a launch of 640 .. 1 023 items (700)
+    keeps its polygon ring by survivor rank, 48 columns: a round in which more than 48 of the 64 candidates pass the trivial
+    reject takes a second pass.  Box-on-plane scenes let 63 % of the candidates through (2 % of the rounds are such) and
+    a fuzz batch mixes models, tet-tet items and degenerate poses.  Equal counters and sums to reduction-order accuracy
+    against the one-kernel narrowphase (clip_min = 0); oracle on a sample."""
+    import helpers as H
+    from test_gpu_parity import _fuzz_workload
+    rng = np.random.default_rng(79)
+    worlds = [pfc.configs.c2_box_on_plane(n_scene, montecarlo=True, n_div=5), _fuzz_workload(pfc, rng, n_scene, False, tet_tet=True)]
+    for w in worlds:
+        out = []
+        for cm in (0, -1):
+            m = pfc.configs.build_scenario(w)
+            m.set_option("fused", 0)
+            if cm >= 0:
+                m.set_option("clip_min", cm)
+            out.append(m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids))
+            if cm < 0 and n_scene > 1024:
+                assert m.last_parts() == 2
+            m.close()
+        assert np.array_equal(out[0][2], out[1][2]), w.name
+        scale = max(np.abs(out[0][0]).max(), 1e-300)
+        assert np.abs(out[0][0] - out[1][0]).max() <= 1e-11 * scale, w.name
+        sample = [0, 1, w.n_items // 2, w.n_items - 1] + [int(k) for k in rng.integers(0, w.n_items, 12)]
+        ref = H.oracle_run(pfc, w, items=sample, debug=False)
+        for k, r in zip(sample, ref):
+            assert np.array_equal(out[1][2][k], r.counts), (w.name, k)
+            assert np.abs(out[1][0][k] - r.wrench).max() <= 1e-9 * max(np.abs(r.wrench).max(), 1e-300), (w.name, k)
+
+
 def test_dual_evaluation_over_the_split_narrowphase(pfc):
     """pfc_eval_dual with the value pass in clip-only + k_integ form (the list of contributing candidates is then written
     by k_integ from the candidate index kept with every polygon): partials equal to those of the one-kernel value pass."""
