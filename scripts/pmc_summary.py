@@ -18,7 +18,8 @@ def newest_per_dir(pattern):
 
 def kname(full):
     """kernel name without its argument list; the instantiations of k_bp_dfs32<BLK> under one name"""
-    return re.sub(r"^void (pfc::k_bp_dfs32)<\d+>$", r"\1", re.sub(r"\(.*", "", full))
+    n = re.sub(r"^void (pfc::k_bp_dfs32)<\d+>$", r"\1", re.sub(r"\(.*", "", full))
+    return n.replace("k_narrow<false, 3>", "k_narrow<false, 2>")      # the two clip-only forms (ring by lane / by survivor rank) under one name
 
 
 tag = sys.argv[1]
