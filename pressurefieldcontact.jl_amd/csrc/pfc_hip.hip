@@ -233,6 +233,8 @@ struct pfc_context {
     bool last_dual_reused = false;                // the last Dual evaluation ran on a reused value pass (pfc_last_dual_reused)
     int opt_dual_reuse = 1;
     bool pin_din_valid = false;                   // pin_din / pin_dout still hold the value inputs / outputs of that evaluation
+    unsigned long long value_serial = 0;          // bumped by every value pass that overwrites the device lists (record_eval, enqueue_eval, enqueue_fused)
+    unsigned long long pin_din_serial = 0;        // value_serial of the evaluation pin_din / pin_dout belong to: the host cache is only valid for THAT value pass
     bool pin_din_ids = false;                     // ... which had ins_ids
     size_t pin_din_nk36 = 0;                      // doubles of seeds between the value block and the ids in pin_din
     std::vector<int> dual_counts_cache;           // its per-item counters
@@ -293,6 +295,7 @@ struct pfc_context {
     int fused_seq = 0;                 // sequence number of the last fused launch (completion word of the polled path)
     DevBuf<int> emit_ctr;              // pair counter of the fused kernel's hand-over to the batched Dual passes
     int *h_emit = nullptr;             // pinned mirror
+    unsigned *h_more = nullptr;        // pinned: status word of the Dual passes of pfc_eval_dual_device_more (device word: status.p + 1)
     bool fu_emit = false;              // set by eval_dual_hybrid around enqueue_fused
     int dual_fused_skip = 0;           // Dual evaluations left for which the in-kernel Dual passes stay off (an item had too many polygons)
     const double *fu_dpose = nullptr, *fu_dtwist = nullptr;    // set by eval_dual_fused around enqueue_fused
@@ -476,6 +479,7 @@ int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
 int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
                 const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st, bool prof) {
     h->dual_reuse_ok = false; h->hyb_reuse_ok = false; h->small_reuse_ok = false; h->pending_more = false; h->last_dual_reused = false;
+    ++h->value_serial;
     const int levels = eff_levels(h);
     int *ccount = h->ctr.p, *tcount = h->ctr.p + 1, *next_seed = h->ctr.p + 2;   // ctr[3]: total records, filled by k_final
     int *ucount = h->ctr.p + 4, *fcount = h->ctr.p + 6;
@@ -606,6 +610,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
 int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
                  const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st) {
     h->dual_reuse_ok = false; h->pending_more = false;     // a new value pass overwrites what a Dual evaluation could reuse
+    ++h->value_serial;
     h->hyb_reuse_ok = false; h->small_reuse_ok = false;
     h->last_dual_reused = false;
     HIP_TRY(h, ensure_work(h, n_items));
@@ -730,6 +735,7 @@ bool fused_ok(const pfc_context *h, int n_items) {
 int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
                   const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st) {
     h->dual_reuse_ok = false; h->pending_more = false; h->last_dual_reused = false; h->hyb_reuse_ok = false; h->small_reuse_ok = false;
+    ++h->value_serial;
     FuArgs a;
     a.n_items = n_items; a.n_ins = (int)h->ins.size(); a.ins_ids = d_ins_ids; a.pose = d_pose; a.twist = d_twist; a.s = d_s;
     a.ins = h->d_insfull; a.wrench = d_wrench; a.sdot = d_sdot; a.counts = d_counts;
@@ -745,6 +751,14 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
     }
     if (++h->fused_seq == 0) h->fused_seq = 1;
     a.seq = h->fused_seq;
+    if (h->fout_host) {
+        // polled path: the completion words live in pinned host memory that several block layouts share (offsets depend on
+        // n_items and the number of levels), so a stale small integer of an earlier layout could equal this launch's
+        // sequence number -- clear this launch's n words before the kernel can write them (<= 256 host stores)
+        volatile int *vf = const_cast<volatile int *>(h->fout_host);
+        for (int i = 0; i < n_items; ++i) vf[8 * i + 5] = 0;
+        std::atomic_thread_fence(std::memory_order_release);
+    }
     a.n_dir = h->fu_ndir; a.d_pose = h->fu_dpose; a.d_twist = h->fu_dtwist; a.d_wrench = h->fu_dwrench; a.d_sdot = h->fu_dsdot;
     a.emit_items = nullptr; a.emit_cand = nullptr; a.emit_surv = nullptr; a.emit_icnt = nullptr; a.emit_ctr = nullptr; a.emit_cap = 0;
     if (h->fu_emit) {
@@ -898,6 +912,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->d_insfull) (void)hipFree(h->d_insfull);
     if (h->h_fout) (void)hipHostFree(h->h_fout);
     if (h->h_emit) (void)hipHostFree(h->h_emit);
+    if (h->h_more) (void)hipHostFree(h->h_more);
     h->emit_ctr.release();
     h->fout.release();
     h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
@@ -1233,6 +1248,10 @@ int pfc_check(pfc_handle h) {
     if (h->pending_more) {       // Dual passes on a value pass that was checked before: nothing to read back
         h->pending_more = false;
         HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+        if (h->h_more && (h->h_more[0] & kStHole)) {
+            h->dual_reuse_ok = false;
+            return fail(h, PFC_ERR_STATE, "internal error: a Dual pass on a reused value pass read a work-list slot out of range");
+        }
         return PFC_OK;
     }
     if (h->pending_dual_hyb) {
@@ -1356,7 +1375,7 @@ namespace {
 // the kept Dual polygons (the kernels take the actual count from the tail and guard against the capacity).
 int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const double *dp, const double *dt,
                 const double *dsd, double *dw, double *dsdot, size_t n_pairs_bound, hipStream_t st, size_t *dpcap_out,
-                bool acc_cleared = false, const int *pair_count = nullptr) {
+                bool acc_cleared = false, const int *pair_count = nullptr, unsigned *status_word = nullptr) {
     const size_t nk = (size_t)n_items * n_dir;
     HIP_TRY(h, ensure_dual(h, h->dual_acc, nk * kDaStride));
     HIP_TRY(h, ensure_dual(h, h->dual_res, nk * kDrStride));
@@ -1371,6 +1390,7 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     // Hand-over: the passes report into the word behind the pair count (cleared and read back with it).  The status word
     // of the batched value pass is read by its k_final only, so a flag raised here would surface in a later evaluation.
     if (pair_count) a.status = reinterpret_cast<unsigned *>(h->emit_ctr.p) + 2;
+    if (status_word) a.status = status_word;       // the passes of a reused value pass: a word pfc_check reads back
     const int cpw = 64 / n_dir;
     const int grid = grid_for((n_pairs_bound + cpw - 1) / cpw, 1, 256 * 16);
     const int kgrid = grid_for(nk, 64, 1 << 20);
@@ -1823,9 +1843,16 @@ int pfc_eval_dual_device_more(pfc_handle h, int n_dir, const double *d_dpose, co
     HIP_TRY(h, hipMemsetAsync(h->dual_acc.p, 0, sizeof(double) * nk * kDaStride, st));
     // the contributing pairs are known exactly (dual_hint, from the value pass pfc_check has seen): no speculation
     const size_t bound = (size_t)(h->dual_hint > 0 ? h->dual_hint : 0) + 64;
+    // The passes report (kStHole: a list entry out of range, capacity guards) into a word of their own, cleared here and read
+    // back by pfc_check in front of its synchronisation: neither the value pass's status word (read by ITS k_final only) nor
+    // the hand-over block (read with the pair count of a first chunk only) is looked at again on this path.
+    if (!h->h_more) HIP_TRY(h, hipHostMalloc((void **)&h->h_more, sizeof(unsigned) * 4));
+    unsigned *more_status = h->status.p + 1;
+    HIP_TRY(h, hipMemsetAsync(more_status, 0, sizeof(unsigned), st));
     const int rc = launch_dual(h, n_items, n_dir, h->tail.p, d_dpose, d_dtwist, d_ds, d_dwrench, d_dsdot, bound, st, nullptr, true,
-                               h->dual_reuse_emit ? h->emit_ctr.p : nullptr);
+                               h->dual_reuse_emit ? h->emit_ctr.p : nullptr, more_status);
     if (rc != PFC_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->h_more, more_status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     h->pending_more = true; h->last_stream = st; h->last_dual_reused = true;
     return PFC_OK;
 }
@@ -1902,7 +1929,9 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
         // if the value inputs equal, bit for bit, those still sitting in the pinned input block, the value pass on the
         // device is reused -- candidates, contributing pairs, per-item results -- and only the Dual passes run.
         static const double kZero6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        bool same = h->opt_dual_reuse && h->dual_reuse_ok && h->pin_din_valid && h->dual_reuse_n == n_items &&
+        // (the device lists must be those of the evaluation the pinned block belongs to: a pfc_eval_dual_device + pfc_check of
+        // the caller's own in between leaves dual_reuse_ok set for ITS point -- the serial tells the two apart)
+        bool same = h->opt_dual_reuse && h->dual_reuse_ok && h->pin_din_valid && h->pin_din_serial == h->value_serial && h->dual_reuse_n == n_items &&
                     h->pin_din_ids == (ins_ids != nullptr) && h->dual_counts_cache.size() == n * 4 &&
                     std::memcmp(pi, pose, sizeof(double) * n * 24) == 0 && std::memcmp(pi + n * 24, twist, sizeof(double) * n * 6) == 0;
         if (same && s) same = std::memcmp(pi + n * 30, s, sizeof(double) * n * 6) == 0;
@@ -1959,7 +1988,7 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
         if (counts) std::memcpy(counts, po + out_d, sizeof(int) * n * 4);
         // what a following call at the same point needs: the counters (the pinned blocks keep the rest)
         h->dual_counts_cache.assign(reinterpret_cast<const int *>(po + out_d), reinterpret_cast<const int *>(po + out_d) + n * 4);
-        h->pin_din_valid = true; h->pin_din_ids = ins_ids != nullptr; h->pin_din_nk36 = nk * 36;
+        h->pin_din_valid = true; h->pin_din_ids = ins_ids != nullptr; h->pin_din_nk36 = nk * 36; h->pin_din_serial = h->value_serial;
         return PFC_OK;
     }
     // two-stage path (debug option, or PFC_DUAL_TWO_STAGE set for A/B runs): values, candidate list and per-item counters
