@@ -95,6 +95,10 @@ def lib():
         L.pfo_poly_centroid.argtypes = [C.c_int, _dp, _dp, _dp]
         L.pfo_inv4.restype = C.c_int
         L.pfo_inv4.argtypes = [_dp, _dp]
+        L.pfo_set_inv4_variant.restype = C.c_int
+        L.pfo_set_inv4_variant.argtypes = [C.c_int]
+        L.pfo_set_ftz.restype = C.c_int
+        L.pfo_set_ftz.argtypes = [C.c_int]
         L.pfo_bb_bb_intersect.restype = C.c_int
         L.pfo_bb_bb_intersect.argtypes = [_dp] * 8
         L.pfo_decompose_K.argtypes = [_dp, C.c_double, _dp, _dp]

@@ -64,8 +64,9 @@ static m4 dh_from_Rt(const double R[9], const double t[3])
 }
 
 /* 4x4 inverse, adjugate x (1/det) from 2x2 minors.  Stands in for StaticArrays inv(::SMatrix{4,4}) at
- * src/contact_algorithms_non_friction.jl:160 (bit-level rounding unpinned, see header). */
-int pfo_inv4(const double a[16], double b[16])
+ * src/contact_algorithms_non_friction.jl:160 (bit-level rounding unpinned, see header).  Variant 0 of pfo_inv4 (the default of rounds 1-2;
+ * the Laplace-expansion form later StaticArrays versions adopted). */
+static int inv4_minors(const double a[16], double b[16])
 {
 #define A(i, j) a[(i) + 4 * (j)]
     double s0 = A(0, 0) * A(1, 1) - A(1, 0) * A(0, 1);
@@ -103,6 +104,120 @@ int pfo_inv4(const double a[16], double b[16])
 #undef B
     return isfinite(id) ? 0 : 1;
 }
+
+/* Variant 1: the explicit cofactor expansion x (1/det) -- the form StaticArrays published for inv(::SMatrix{4,4}) at the
+ * version the reference pins (0.10.3, Manifest.toml; src/inv.jl `_inv(::Size{(4,4)}, A)` with `idet = 1/det(A)` and
+ * src/det.jl `_det(::Size{(4,4)}, A)`): every entry is six left-to-right triple products times idet, the determinant 24
+ * left-to-right quadruple products.  StaticArrays is NOT vendored under /root/reference and there is no network, so the
+ * term ORDER below is written from the published source as recalled and cannot be diffed here; what the variant measures
+ * (tests/test_inv4_exposure.py) is how many predicate outcomes of the path depend on WHICH correctly-rounded-to-a-few-ulp
+ * inverse is used -- the only unpinned rounding of the oracle. */
+static int inv4_cofactor(const double a[16], double b[16])
+{
+#define A(i, j) a[((i) - 1) + 4 * ((j) - 1)]
+    /* det: linear (column-major) indices A[1..16] as in the published _det */
+#define L(k) a[(k) - 1]
+    double det =
+        L(13) * L(10) * L(7) * L(4) - L(9) * L(14) * L(7) * L(4) -
+        L(13) * L(6) * L(11) * L(4) + L(5) * L(14) * L(11) * L(4) +
+        L(9) * L(6) * L(15) * L(4) - L(5) * L(10) * L(15) * L(4) -
+        L(13) * L(10) * L(3) * L(8) + L(9) * L(14) * L(3) * L(8) +
+        L(13) * L(2) * L(11) * L(8) - L(1) * L(14) * L(11) * L(8) -
+        L(9) * L(2) * L(15) * L(8) + L(1) * L(10) * L(15) * L(8) +
+        L(13) * L(6) * L(3) * L(12) - L(5) * L(14) * L(3) * L(12) -
+        L(13) * L(2) * L(7) * L(12) + L(1) * L(14) * L(7) * L(12) +
+        L(5) * L(2) * L(15) * L(12) - L(1) * L(6) * L(15) * L(12) -
+        L(9) * L(6) * L(3) * L(16) + L(5) * L(10) * L(3) * L(16) +
+        L(9) * L(2) * L(7) * L(16) - L(1) * L(10) * L(7) * L(16) -
+        L(5) * L(2) * L(11) * L(16) + L(1) * L(6) * L(11) * L(16);
+#undef L
+    double idet = 1.0 / det;
+#define B(i, j) b[((i) - 1) + 4 * ((j) - 1)]
+    B(1, 1) = (A(2,3)*A(3,4)*A(4,2) - A(2,4)*A(3,3)*A(4,2) + A(2,4)*A(3,2)*A(4,3) - A(2,2)*A(3,4)*A(4,3) - A(2,3)*A(3,2)*A(4,4) + A(2,2)*A(3,3)*A(4,4)) * idet;
+    B(2, 1) = (A(2,4)*A(3,3)*A(4,1) - A(2,3)*A(3,4)*A(4,1) - A(2,4)*A(3,1)*A(4,3) + A(2,1)*A(3,4)*A(4,3) + A(2,3)*A(3,1)*A(4,4) - A(2,1)*A(3,3)*A(4,4)) * idet;
+    B(3, 1) = (A(2,2)*A(3,4)*A(4,1) - A(2,4)*A(3,2)*A(4,1) + A(2,4)*A(3,1)*A(4,2) - A(2,1)*A(3,4)*A(4,2) - A(2,2)*A(3,1)*A(4,4) + A(2,1)*A(3,2)*A(4,4)) * idet;
+    B(4, 1) = (A(2,3)*A(3,2)*A(4,1) - A(2,2)*A(3,3)*A(4,1) - A(2,3)*A(3,1)*A(4,2) + A(2,1)*A(3,3)*A(4,2) + A(2,2)*A(3,1)*A(4,3) - A(2,1)*A(3,2)*A(4,3)) * idet;
+    B(1, 2) = (A(1,4)*A(3,3)*A(4,2) - A(1,3)*A(3,4)*A(4,2) - A(1,4)*A(3,2)*A(4,3) + A(1,2)*A(3,4)*A(4,3) + A(1,3)*A(3,2)*A(4,4) - A(1,2)*A(3,3)*A(4,4)) * idet;
+    B(2, 2) = (A(1,3)*A(3,4)*A(4,1) - A(1,4)*A(3,3)*A(4,1) + A(1,4)*A(3,1)*A(4,3) - A(1,1)*A(3,4)*A(4,3) - A(1,3)*A(3,1)*A(4,4) + A(1,1)*A(3,3)*A(4,4)) * idet;
+    B(3, 2) = (A(1,4)*A(3,2)*A(4,1) - A(1,2)*A(3,4)*A(4,1) - A(1,4)*A(3,1)*A(4,2) + A(1,1)*A(3,4)*A(4,2) + A(1,2)*A(3,1)*A(4,4) - A(1,1)*A(3,2)*A(4,4)) * idet;
+    B(4, 2) = (A(1,2)*A(3,3)*A(4,1) - A(1,3)*A(3,2)*A(4,1) + A(1,3)*A(3,1)*A(4,2) - A(1,1)*A(3,3)*A(4,2) - A(1,2)*A(3,1)*A(4,3) + A(1,1)*A(3,2)*A(4,3)) * idet;
+    B(1, 3) = (A(1,3)*A(2,4)*A(4,2) - A(1,4)*A(2,3)*A(4,2) + A(1,4)*A(2,2)*A(4,3) - A(1,2)*A(2,4)*A(4,3) - A(1,3)*A(2,2)*A(4,4) + A(1,2)*A(2,3)*A(4,4)) * idet;
+    B(2, 3) = (A(1,4)*A(2,3)*A(4,1) - A(1,3)*A(2,4)*A(4,1) - A(1,4)*A(2,1)*A(4,3) + A(1,1)*A(2,4)*A(4,3) + A(1,3)*A(2,1)*A(4,4) - A(1,1)*A(2,3)*A(4,4)) * idet;
+    B(3, 3) = (A(1,2)*A(2,4)*A(4,1) - A(1,4)*A(2,2)*A(4,1) + A(1,4)*A(2,1)*A(4,2) - A(1,1)*A(2,4)*A(4,2) - A(1,2)*A(2,1)*A(4,4) + A(1,1)*A(2,2)*A(4,4)) * idet;
+    B(4, 3) = (A(1,3)*A(2,2)*A(4,1) - A(1,2)*A(2,3)*A(4,1) - A(1,3)*A(2,1)*A(4,2) + A(1,1)*A(2,3)*A(4,2) + A(1,2)*A(2,1)*A(4,3) - A(1,1)*A(2,2)*A(4,3)) * idet;
+    B(1, 4) = (A(1,4)*A(2,3)*A(3,2) - A(1,3)*A(2,4)*A(3,2) - A(1,4)*A(2,2)*A(3,3) + A(1,2)*A(2,4)*A(3,3) + A(1,3)*A(2,2)*A(3,4) - A(1,2)*A(2,3)*A(3,4)) * idet;
+    B(2, 4) = (A(1,3)*A(2,4)*A(3,1) - A(1,4)*A(2,3)*A(3,1) + A(1,4)*A(2,1)*A(3,3) - A(1,1)*A(2,4)*A(3,3) - A(1,3)*A(2,1)*A(3,4) + A(1,1)*A(2,3)*A(3,4)) * idet;
+    B(3, 4) = (A(1,4)*A(2,2)*A(3,1) - A(1,2)*A(2,4)*A(3,1) - A(1,4)*A(2,1)*A(3,2) + A(1,1)*A(2,4)*A(3,2) + A(1,2)*A(2,1)*A(3,4) - A(1,1)*A(2,2)*A(3,4)) * idet;
+    B(4, 4) = (A(1,2)*A(2,3)*A(3,1) - A(1,3)*A(2,2)*A(3,1) + A(1,3)*A(2,1)*A(3,2) - A(1,1)*A(2,3)*A(3,2) - A(1,2)*A(2,1)*A(3,3) + A(1,1)*A(2,2)*A(3,3)) * idet;
+#undef A
+#undef B
+    return isfinite(idet) ? 0 : 1;
+}
+
+/* Variant 2: Gauss-Jordan elimination with partial pivoting on [A | I] (what a LAPACK-style getrf/getri pair amounts to
+ * for a 4x4: a third, structurally different rounding). */
+static int inv4_lu(const double a[16], double b[16])
+{
+    double M[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { M[i][j] = a[i + 4 * j]; M[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int k = 0; k < 4; ++k) {
+        int p = k;
+        for (int i = k + 1; i < 4; ++i)
+            if (fabs(M[i][k]) > fabs(M[p][k])) p = i;
+        if (M[p][k] == 0.0) return 1;
+        if (p != k)
+            for (int j = 0; j < 8; ++j) { double t = M[k][j]; M[k][j] = M[p][j]; M[p][j] = t; }
+        double piv = M[k][k];
+        for (int j = 0; j < 8; ++j) M[k][j] = M[k][j] / piv;
+        for (int i = 0; i < 4; ++i) {
+            if (i == k) continue;
+            double f = M[i][k];
+            for (int j = 0; j < 8; ++j) M[i][j] = M[i][j] - f * M[k][j];
+        }
+    }
+    int bad = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { b[i + 4 * j] = M[i][4 + j]; bad |= !isfinite(M[i][4 + j]); }
+    return bad;
+}
+
+/* The inverse every caller of the oracle goes through.  Variant 1 (default since round 3) is the form StaticArrays 0.10.3
+ * published and the HIP path's form (k_prep_tet / inv4, pfc_kernels.h); 0 (rounds 1-2: 2x2 minors, the form later
+ * StaticArrays versions use) and 2 exist to MEASURE the path's exposure to the one rounding the reference takes from an
+ * un-vendored dependency. */
+static int g_inv4_variant = 1;
+int pfo_set_inv4_variant(int v)
+{
+    if (v < 0 || v > 2) return PFO_ERR_BAD_ARG;
+    g_inv4_variant = v;
+    return PFO_OK;
+}
+int pfo_inv4(const double a[16], double b[16])
+{
+    if (g_inv4_variant == 1) return inv4_cofactor(a, b);
+    if (g_inv4_variant == 2) return inv4_lu(a, b);
+    return inv4_minors(a, b);
+}
+
+/* The reference's tests run with set_zero_subnormals(true) (test/runtests.jl:13): flush-to-zero + denormals-are-zero in
+ * MXCSR for the duration of an evaluation (per calling thread), restored afterwards.  Off by default. */
+#if defined(__x86_64__) || defined(__i386__)
+#include <xmmintrin.h>
+static int g_ftz = 0;
+int pfo_set_ftz(int on) { g_ftz = on != 0; return PFO_OK; }
+static unsigned ftz_enter(void)
+{
+    unsigned old = _mm_getcsr();
+    if (g_ftz) _mm_setcsr(old | 0x8040u);   /* FTZ (bit 15) | DAZ (bit 6) */
+    return old;
+}
+static void ftz_leave(unsigned old) { _mm_setcsr(old); }
+#else
+int pfo_set_ftz(int on) { return on ? PFO_ERR_BAD_ARG : PFO_OK; }
+static unsigned ftz_enter(void) { return 0; }
+static void ftz_leave(unsigned old) { (void)old; }
+#endif
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* math kernel                                                                                                    */
@@ -849,8 +964,18 @@ static void yes_contact_bristle(ctx *c, const double s[6], double wrench[6], dou
 /* ------------------------------------------------------------------------------------------------------------ */
 /* force_single_elastic_intersection!: src/contact_algorithms_non_friction.jl:70-84                              */
 /* ------------------------------------------------------------------------------------------------------------ */
+static int eval_impl(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *twist,
+                     const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg);
 int pfo_eval(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *twist,
              const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg)
+{
+    const unsigned csr = ftz_enter();
+    const int rc = eval_impl(m1, m2, ins, pose, twist, s, wrench, sdot, counts, dbg);
+    ftz_leave(csr);
+    return rc;
+}
+static int eval_impl(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *twist,
+                     const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg)
 {
     ctx c;
     pfo_debug *own = NULL;

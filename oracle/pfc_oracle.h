@@ -10,7 +10,8 @@
  * by the reference's own analytic known-answer and property tests, restated in tests/test_oracle_*.py.
  * "parity unpinned" applies to exactly one thing: the bit-level rounding of the 4x4 inverse, which the
  * reference takes from StaticArrays 0.10.3 `inv(::SMatrix{4,4})` (not vendored under /root/reference); here it
- * is the adjugate x (1/det) form built from 2x2 minors.
+ * is the explicit cofactor expansion x (1/det) that StaticArrays 0.10.3 published (term order as recalled; variants 0 and
+ * 2 of pfo_set_inv4_variant and tests/test_inv4_exposure.py count how many predicate outcomes depend on the choice).
  *
  * Floating-point discipline: compile with -ffp-contract=off and without -ffast-math.  Julia never contracts
  * a*b+c on its own; the reference's explicit `muladd` sites are written here as fma().
@@ -101,6 +102,14 @@ int pfo_clip_plane_tet(const double plane[4], const double tet_cm[16], double *o
 void pfo_zero_small_coordinates(int n, double *z);
 double pfo_poly_centroid(int n, const double *v, const double nhat[3], double c[3]);   /* v: 8 x 3 */
 int pfo_inv4(const double a_cm[16], double b_cm[16]);
+/* Which 4x4 inverse pfo_inv4 (and with it every evaluation) uses: 0 = adjugate from 2x2 minors x 1/det (rounds 1-2),
+ * 1 = explicit cofactor expansion x 1/det (DEFAULT, and the HIP path's form: what StaticArrays 0.10.3 publishes for
+ * inv(::SMatrix{4,4}), the reference's call at src/contact_algorithms_non_friction.jl:160), 2 = Gauss-Jordan with partial pivoting.
+ * Process-wide; for tests/test_inv4_exposure.py, which counts the predicate outcomes that depend on it. */
+int pfo_set_inv4_variant(int v);
+/* 1: evaluate with flush-to-zero / denormals-are-zero, as the reference's tests do (set_zero_subnormals(true),
+ * test/runtests.jl:13); 0 (default): IEEE subnormals.  Process-wide flag, applied per pfo_eval call. */
+int pfo_set_ftz(int on);
 int pfo_bb_bb_intersect(const double ca[3], const double ea[3], const double Ra[9],
                         const double cb[3], const double eb[3], const double Rb[9],
                         const double R_a_b[9], const double t_a_b[3]);

@@ -183,44 +183,51 @@ __device__ __forceinline__ double clamped_piecewise(double x, double x1, double 
     return (y > y1) ? y1 : ((y < y2) ? y2 : y);
 }
 
-// 4x4 inverse by 2x2 minors, adjugate x (1/det); stands in for StaticArrays inv(::SMatrix{4,4})
-// (src/contact_algorithms_non_friction.jl:160).  a, b column-major.  Returns 1/det.
+// 4x4 inverse: explicit cofactor expansion x (1/det) -- the form StaticArrays 0.10.3 (the version the reference pins,
+// Manifest.toml) published for inv(::SMatrix{4,4}) (src/inv.jl, src/det.jl), the reference's call at
+// src/contact_algorithms_non_friction.jl:160: every entry six left-to-right triple products times idet, the determinant 24
+// left-to-right quadruple products.  StaticArrays is not vendored under the reference, so the term order is written from the
+// published source as recalled (the one unpinned rounding of the path: DESIGN.md section 2 counts the predicate outcomes
+// that depend on it; the test suite's CPU restatement uses the same expressions).  Rounds 1-2 used the adjugate from
+// 2x2 minors.  a, b column-major.  Returns 1/det.
 __device__ __forceinline__ double inv4(const double *a, double *b) {
-#define A_(i, j) a[(i) + 4 * (j)]
-#define B_(i, j) b[(i) + 4 * (j)]
-    double s0 = A_(0, 0) * A_(1, 1) - A_(1, 0) * A_(0, 1);
-    double s1 = A_(0, 0) * A_(1, 2) - A_(1, 0) * A_(0, 2);
-    double s2 = A_(0, 0) * A_(1, 3) - A_(1, 0) * A_(0, 3);
-    double s3 = A_(0, 1) * A_(1, 2) - A_(1, 1) * A_(0, 2);
-    double s4 = A_(0, 1) * A_(1, 3) - A_(1, 1) * A_(0, 3);
-    double s5 = A_(0, 2) * A_(1, 3) - A_(1, 2) * A_(0, 3);
-    double c5 = A_(2, 2) * A_(3, 3) - A_(3, 2) * A_(2, 3);
-    double c4 = A_(2, 1) * A_(3, 3) - A_(3, 1) * A_(2, 3);
-    double c3 = A_(2, 1) * A_(3, 2) - A_(3, 1) * A_(2, 2);
-    double c2 = A_(2, 0) * A_(3, 3) - A_(3, 0) * A_(2, 3);
-    double c1 = A_(2, 0) * A_(3, 2) - A_(3, 0) * A_(2, 2);
-    double c0 = A_(2, 0) * A_(3, 1) - A_(3, 0) * A_(2, 1);
-    double det = ((((s0 * c5 - s1 * c4) + s2 * c3) + s3 * c2) - s4 * c1) + s5 * c0;
-    double id = 1.0 / det;
-    B_(0, 0) = ((A_(1, 1) * c5 - A_(1, 2) * c4) + A_(1, 3) * c3) * id;
-    B_(0, 1) = ((-A_(0, 1) * c5 + A_(0, 2) * c4) - A_(0, 3) * c3) * id;
-    B_(0, 2) = ((A_(3, 1) * s5 - A_(3, 2) * s4) + A_(3, 3) * s3) * id;
-    B_(0, 3) = ((-A_(2, 1) * s5 + A_(2, 2) * s4) - A_(2, 3) * s3) * id;
-    B_(1, 0) = ((-A_(1, 0) * c5 + A_(1, 2) * c2) - A_(1, 3) * c1) * id;
-    B_(1, 1) = ((A_(0, 0) * c5 - A_(0, 2) * c2) + A_(0, 3) * c1) * id;
-    B_(1, 2) = ((-A_(3, 0) * s5 + A_(3, 2) * s2) - A_(3, 3) * s1) * id;
-    B_(1, 3) = ((A_(2, 0) * s5 - A_(2, 2) * s2) + A_(2, 3) * s1) * id;
-    B_(2, 0) = ((A_(1, 0) * c4 - A_(1, 1) * c2) + A_(1, 3) * c0) * id;
-    B_(2, 1) = ((-A_(0, 0) * c4 + A_(0, 1) * c2) - A_(0, 3) * c0) * id;
-    B_(2, 2) = ((A_(3, 0) * s4 - A_(3, 1) * s2) + A_(3, 3) * s0) * id;
-    B_(2, 3) = ((-A_(2, 0) * s4 + A_(2, 1) * s2) - A_(2, 3) * s0) * id;
-    B_(3, 0) = ((-A_(1, 0) * c3 + A_(1, 1) * c1) - A_(1, 2) * c0) * id;
-    B_(3, 1) = ((A_(0, 0) * c3 - A_(0, 1) * c1) + A_(0, 2) * c0) * id;
-    B_(3, 2) = ((-A_(3, 0) * s3 + A_(3, 1) * s1) - A_(3, 2) * s0) * id;
-    B_(3, 3) = ((A_(2, 0) * s3 - A_(2, 1) * s1) + A_(2, 2) * s0) * id;
-#undef A_
-#undef B_
-    return id;
+#define A(i, j) a[((i) - 1) + 4 * ((j) - 1)]
+#define B(i, j) b[((i) - 1) + 4 * ((j) - 1)]
+#define L(k) a[(k) - 1]
+    const double det =
+        L(13) * L(10) * L(7) * L(4) - L(9) * L(14) * L(7) * L(4) -
+        L(13) * L(6) * L(11) * L(4) + L(5) * L(14) * L(11) * L(4) +
+        L(9) * L(6) * L(15) * L(4) - L(5) * L(10) * L(15) * L(4) -
+        L(13) * L(10) * L(3) * L(8) + L(9) * L(14) * L(3) * L(8) +
+        L(13) * L(2) * L(11) * L(8) - L(1) * L(14) * L(11) * L(8) -
+        L(9) * L(2) * L(15) * L(8) + L(1) * L(10) * L(15) * L(8) +
+        L(13) * L(6) * L(3) * L(12) - L(5) * L(14) * L(3) * L(12) -
+        L(13) * L(2) * L(7) * L(12) + L(1) * L(14) * L(7) * L(12) +
+        L(5) * L(2) * L(15) * L(12) - L(1) * L(6) * L(15) * L(12) -
+        L(9) * L(6) * L(3) * L(16) + L(5) * L(10) * L(3) * L(16) +
+        L(9) * L(2) * L(7) * L(16) - L(1) * L(10) * L(7) * L(16) -
+        L(5) * L(2) * L(11) * L(16) + L(1) * L(6) * L(11) * L(16);
+    const double idet = 1.0 / det;
+    B(1, 1) = (A(2,3)*A(3,4)*A(4,2) - A(2,4)*A(3,3)*A(4,2) + A(2,4)*A(3,2)*A(4,3) - A(2,2)*A(3,4)*A(4,3) - A(2,3)*A(3,2)*A(4,4) + A(2,2)*A(3,3)*A(4,4)) * idet;
+    B(2, 1) = (A(2,4)*A(3,3)*A(4,1) - A(2,3)*A(3,4)*A(4,1) - A(2,4)*A(3,1)*A(4,3) + A(2,1)*A(3,4)*A(4,3) + A(2,3)*A(3,1)*A(4,4) - A(2,1)*A(3,3)*A(4,4)) * idet;
+    B(3, 1) = (A(2,2)*A(3,4)*A(4,1) - A(2,4)*A(3,2)*A(4,1) + A(2,4)*A(3,1)*A(4,2) - A(2,1)*A(3,4)*A(4,2) - A(2,2)*A(3,1)*A(4,4) + A(2,1)*A(3,2)*A(4,4)) * idet;
+    B(4, 1) = (A(2,3)*A(3,2)*A(4,1) - A(2,2)*A(3,3)*A(4,1) - A(2,3)*A(3,1)*A(4,2) + A(2,1)*A(3,3)*A(4,2) + A(2,2)*A(3,1)*A(4,3) - A(2,1)*A(3,2)*A(4,3)) * idet;
+    B(1, 2) = (A(1,4)*A(3,3)*A(4,2) - A(1,3)*A(3,4)*A(4,2) - A(1,4)*A(3,2)*A(4,3) + A(1,2)*A(3,4)*A(4,3) + A(1,3)*A(3,2)*A(4,4) - A(1,2)*A(3,3)*A(4,4)) * idet;
+    B(2, 2) = (A(1,3)*A(3,4)*A(4,1) - A(1,4)*A(3,3)*A(4,1) + A(1,4)*A(3,1)*A(4,3) - A(1,1)*A(3,4)*A(4,3) - A(1,3)*A(3,1)*A(4,4) + A(1,1)*A(3,3)*A(4,4)) * idet;
+    B(3, 2) = (A(1,4)*A(3,2)*A(4,1) - A(1,2)*A(3,4)*A(4,1) - A(1,4)*A(3,1)*A(4,2) + A(1,1)*A(3,4)*A(4,2) + A(1,2)*A(3,1)*A(4,4) - A(1,1)*A(3,2)*A(4,4)) * idet;
+    B(4, 2) = (A(1,2)*A(3,3)*A(4,1) - A(1,3)*A(3,2)*A(4,1) + A(1,3)*A(3,1)*A(4,2) - A(1,1)*A(3,3)*A(4,2) - A(1,2)*A(3,1)*A(4,3) + A(1,1)*A(3,2)*A(4,3)) * idet;
+    B(1, 3) = (A(1,3)*A(2,4)*A(4,2) - A(1,4)*A(2,3)*A(4,2) + A(1,4)*A(2,2)*A(4,3) - A(1,2)*A(2,4)*A(4,3) - A(1,3)*A(2,2)*A(4,4) + A(1,2)*A(2,3)*A(4,4)) * idet;
+    B(2, 3) = (A(1,4)*A(2,3)*A(4,1) - A(1,3)*A(2,4)*A(4,1) - A(1,4)*A(2,1)*A(4,3) + A(1,1)*A(2,4)*A(4,3) + A(1,3)*A(2,1)*A(4,4) - A(1,1)*A(2,3)*A(4,4)) * idet;
+    B(3, 3) = (A(1,2)*A(2,4)*A(4,1) - A(1,4)*A(2,2)*A(4,1) + A(1,4)*A(2,1)*A(4,2) - A(1,1)*A(2,4)*A(4,2) - A(1,2)*A(2,1)*A(4,4) + A(1,1)*A(2,2)*A(4,4)) * idet;
+    B(4, 3) = (A(1,3)*A(2,2)*A(4,1) - A(1,2)*A(2,3)*A(4,1) - A(1,3)*A(2,1)*A(4,2) + A(1,1)*A(2,3)*A(4,2) + A(1,2)*A(2,1)*A(4,3) - A(1,1)*A(2,2)*A(4,3)) * idet;
+    B(1, 4) = (A(1,4)*A(2,3)*A(3,2) - A(1,3)*A(2,4)*A(3,2) - A(1,4)*A(2,2)*A(3,3) + A(1,2)*A(2,4)*A(3,3) + A(1,3)*A(2,2)*A(3,4) - A(1,2)*A(2,3)*A(3,4)) * idet;
+    B(2, 4) = (A(1,3)*A(2,4)*A(3,1) - A(1,4)*A(2,3)*A(3,1) + A(1,4)*A(2,1)*A(3,3) - A(1,1)*A(2,4)*A(3,3) - A(1,3)*A(2,1)*A(3,4) + A(1,1)*A(2,3)*A(3,4)) * idet;
+    B(3, 4) = (A(1,4)*A(2,2)*A(3,1) - A(1,2)*A(2,4)*A(3,1) - A(1,4)*A(2,1)*A(3,2) + A(1,1)*A(2,4)*A(3,2) + A(1,2)*A(2,1)*A(3,4) - A(1,1)*A(2,2)*A(3,4)) * idet;
+    B(4, 4) = (A(1,2)*A(2,3)*A(3,1) - A(1,3)*A(2,2)*A(3,1) + A(1,3)*A(2,1)*A(3,2) - A(1,1)*A(2,3)*A(3,2) - A(1,2)*A(2,1)*A(3,3) + A(1,1)*A(2,2)*A(3,3)) * idet;
+#undef A
+#undef B
+#undef L
+    return idet;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -104,3 +104,36 @@ def eval_scene(backend, pfc, mesh_1, Ebar_1, mesh_2, Ebar_2, ins, pose, twist, s
     r.K, r.Kbar_inv_sqrt, r.Sinv, r.cop = st if st is not None else (None, None, None, None)
     m.close()
     return r
+
+
+def fuzz_workload(pfc, rng, n_items, degenerate, tet_tet=False):
+    """Random small meshes in random relative poses: a box surface (12 triangles), a sphere surface and a tet box /
+    tet sphere with random scales; poses put the surfaces at random depths through the tets.  degenerate: poses
+    snapped to axis-aligned rotations and lattice offsets, so that triangle vertices and edges land exactly on tet
+    faces (the strict / non-strict inside tests of static_clip.jl:140-188 and the zero ties of the trivial reject)."""
+    G, Cf = pfc.geometry, pfc.configs
+    box_tet = G.as_tet_emesh(G.emesh_box_div(np.array([0.5, 0.5, 0.5]), 2))
+    sph_tet = G.as_tet_emesh(G.emesh_sphere(0.5, 3))
+    box_tri = G.as_tri_emesh(G.emesh_box(np.array([0.25, 0.25, 0.25])))
+    sph_tri = G.as_tri_emesh(G.emesh_sphere(0.3, 2))
+    meshes = [Cf._mesh("box_tri", box_tri), Cf._mesh("sph_tri", sph_tri), Cf._mesh("box_tet", box_tet, 1.0e6),
+              Cf._mesh("sph_tet", sph_tet, 2.0e6)]
+    ins = [Cf.InsSpec(0, 2, "regularized", chi=0.5, mu_d=0.3, v_tol=1e-2), Cf.InsSpec(1, 2, "bristle", chi=0.3, mu_d=0.4),
+           Cf.InsSpec(0, 3, "bristle", chi=0.5, mu_d=0.3, n_quad_rule=1), Cf.InsSpec(1, 3, "regularized", chi=0.1, mu_d=0.2, v_tol=1e-3)]
+    if tet_tet:    # volume-volume instructions in the same scenario: the TT kernel variants serve all six
+        ins += [Cf.InsSpec(2, 3, "regularized", chi=0.5, mu_d=0.3, v_tol=1e-2), Cf.InsSpec(3, 2, "bristle", chi=0.4, mu_d=0.3)]
+    ids = rng.integers(0, len(ins), n_items).astype(np.int32)
+    pose, twist, s = [], [], []
+    quarter = [np.eye(3), np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]]), np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0.0]]),
+               np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0.0]])]
+    for k in range(n_items):
+        if degenerate:
+            R = quarter[rng.integers(0, 4)] @ quarter[rng.integers(0, 4)]
+            t = rng.integers(-3, 4, 3) * 0.125
+        else:
+            R = Cf.random_rotation(rng)
+            t = rng.uniform(-0.6, 0.6, 3)
+        pose.append(pfc.scenario.relative_pose(R, t, np.eye(3), np.zeros(3)))
+        twist.append(rng.standard_normal(6) * np.array([1, 1, 1, 0.1, 0.1, 0.1]))
+        s.append(rng.standard_normal(6) * 1e-3)
+    return Cf.Workload("fuzz", meshes, ins, ids, np.array(pose), np.array(twist), np.array(s))

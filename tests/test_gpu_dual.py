@@ -647,3 +647,58 @@ def test_jacobian_chunks_without_ids_and_state(pfc):
             np.testing.assert_allclose(y, x, rtol=tol, atol=tol * max(np.abs(x).max(), 1e-300))
     assert flags[0] is False and flags[2] is True, flags
     f.close(); m.close()
+
+
+def test_host_chunk_cache_is_tied_to_its_value_pass(pfc):
+    """A caller's own pfc_eval_dual_device(Y) + pfc_check between two host-buffer Dual evaluations at X (same item count)
+    leaves a checked Dual value pass on the handle -- Y's.  The host-side cache of X (pinned value inputs / outputs) must
+    not be paired with it: the second call at X is a full evaluation (last_dual_reused() false) and equals a fresh handle's."""
+    import torch
+    rng = np.random.default_rng(41)
+    w = pfc.configs.c3_blob_tool(700, n_div_blob=6, n_div_tool=5)
+    n, nd = w.n_items, 6
+    dev = torch.device("cuda", 0)
+    T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+
+    def seeds():
+        return (rng.standard_normal((n, nd, 24)) * 1e-2, rng.standard_normal((n, nd, 6)) * 0.1,
+                rng.standard_normal((n, nd, 6)) * 1e-3)
+
+    def same(a, b):
+        assert np.array_equal(a[4], b[4])
+        for x, y, tol in ((a[0], b[0], 1e-11), (a[1], b[1], 1e-7), (a[2], b[2], 1e-9), (a[3], b[3], 1e-6)):
+            np.testing.assert_allclose(y, x, rtol=tol, atol=tol * max(np.abs(x).max(), 1e-300))
+
+    # Y: other poses of the same scene (the blob turned by a few degrees: other candidates, other wrenches)
+    wy = pfc.configs.c3_blob_tool(700, seed=777, n_div_blob=6, n_div_tool=5)
+    m = pfc.configs.build_scenario(w)
+    sd1, sd2, sdy = seeds(), seeds(), seeds()
+    m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd1, w.ins_ids)          # host Dual at X
+    t_ins, t_pose, t_tw, t_s = T(w.ins_ids, torch.int32), T(wy.pose), T(wy.twist), T(wy.s)
+    ty = [T(x) for x in sdy]
+    o_w = torch.zeros((n, 6), dtype=torch.float64, device=dev); o_sd = torch.zeros_like(o_w)
+    o_ct = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    o_dw = torch.zeros((n, nd, 6), dtype=torch.float64, device=dev); o_dsd = torch.zeros_like(o_dw)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(40):                                                                       # device Dual at Y, checked
+        m.eval_dual_device(n, nd, t_ins.data_ptr(), t_pose.data_ptr(), t_tw.data_ptr(), t_s.data_ptr(), ty[0].data_ptr(),
+                           ty[1].data_ptr(), ty[2].data_ptr(), o_w.data_ptr(), o_sd.data_ptr(), o_dw.data_ptr(), o_dsd.data_ptr(),
+                           o_ct.data_ptr(), stream)
+        if m.check() == 0:
+            break
+    got = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd2, w.ins_ids)    # host Dual at X again
+    assert not m.last_dual_reused()
+    f = pfc.configs.build_scenario(w)
+    f.set_option("dual_reuse", 0)
+    want = f.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd2, w.ins_ids)
+    f.close()
+    same(want, got)
+    # and the chunk after it does reuse (the cache now belongs to the value pass on the device)
+    sd3 = seeds()
+    got3 = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd3, w.ins_ids)
+    assert m.last_dual_reused()
+    f = pfc.configs.build_scenario(w)
+    f.set_option("dual_reuse", 0)
+    same(f.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd3, w.ins_ids), got3)
+    f.close()
+    m.close()

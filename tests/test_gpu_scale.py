@@ -526,3 +526,66 @@ def test_split_narrowphase_on_many_small_mixed_items(pfc):
     for r, k in zip(ref, items):
         assert np.array_equal(out[1][2][k], r.counts), k
         assert np.abs(out[1][0][k] - r.wrench).max() <= 1e-9 * max(np.abs(r.wrench).max(), 1e-300), k
+
+
+def _sampled_items_vs_oracle(pfc, w, wrench, sdot, counts, n_sample, seed):
+    """n_sample random items of a batch against the CPU oracle: counts bit-equal, wrench 1e-9, ṡ 1e-6 (1e-3 for items whose
+    K̄ has two or more eigenvalues at the rounding level: DESIGN.md §5.7)."""
+    pick = np.sort(np.random.default_rng(seed).choice(w.n_items, size=n_sample, replace=False))
+    ref = H.oracle_run(pfc, w, items=pick, debug=False)
+    for k, r in zip(pick, ref):
+        assert np.array_equal(counts[k], r.counts), (k, counts[k], r.counts)
+        assert H.rel_err(wrench[k], r.wrench) < TOL, (k, wrench[k], r.wrench)
+        t = 1e-6
+        if r.has_K:
+            Kb = np.diag(r.Sinv) @ r.K @ np.diag(r.Sinv)
+            ev = np.linalg.eigvalsh((Kb + Kb.T) / 2)
+            if np.sum(ev < 1e-12 * ev[-1]) >= 2:
+                t = 1e-3
+        assert H.rel_err(sdot[k], r.sdot) < t, (k, sdot[k], r.sdot)
+    return pick
+
+
+@pytest.mark.parametrize("n_poses, parts", [(1100, 2), (700, 1)])
+def test_c3_full_size_at_bench_scale_default_options(pfc, n_poses, parts):
+    """The path bench.py times, at full C3 size (9 680 tets x 5 120 triangles, bristle) with DEFAULT options: 1 100 poses run
+    as two concurrent halves (k_bp_dfs32, clip-only k_narrow<.., 3> on the compacted ring, k_integ, k_fric per half);
+    700 poses as one launch sequence with the clip-only narrowphase.  12 sampled items against the CPU oracle."""
+    w = pfc.configs.c3_blob_tool(n_poses)
+    assert w.meta["n_tet"] == 9680 and w.meta["n_tri"] == 5120
+    m = pfc.configs.build_scenario(w)
+    wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert m.last_parts() == parts
+    _sampled_items_vs_oracle(pfc, w, wr, sd, ct, 12, seed=n_poses)
+    # a second evaluation (grown lists, replayed graphs): integers reproducible, sums to summation order
+    wr2, sd2, ct2 = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert np.array_equal(ct2, ct)
+    np.testing.assert_allclose(wr2, wr, rtol=1e-11, atol=1e-11 * np.abs(wr).max())
+    assert ct[:, 1].sum() > 1500 * n_poses        # ~1.9 k candidate pairs per pose
+    m.close()
+
+
+def test_bench_two_ranks_share_the_gpu_gloo_rehearsal():
+    """bench.py --config C5 --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with both
+    ranks on GPU 0 and the exchange through host memory (PFC_BENCH_BACKEND=gloo): the product sharding code
+    (parallel.shard_by_cost, pack_rows, all_gather_rows) around the HIP evaluator in two fresh processes, the JSON line of
+    rank 0 with its oracle validation.  The measured configuration is nccl (= RCCL) with one rank per GPU."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PFC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--config", "C5", "--steps", "2",
+           "--warmup", "1", "--reps", "1", "--cpu-seconds", "0", "--no-extras"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["validated_items"] >= 1 and out["validation"].startswith("counts bit-equal"), out.get("validation")
