@@ -159,6 +159,7 @@ def main():
                     help="friction model of the C3 instruction (BASELINE: bristle; regularized is an experiment knob)")
     ap.add_argument("--split-min", type=int, default=-1, help="library option split_min (-1: library default 1025; 0: never split)")
     ap.add_argument("--clip-min", type=int, default=-1, help="library option clip_min (-1: library default 512; 0: one-kernel narrowphase)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option for A/B runs (pfc_set_option), e.g. --opt clip_dense=0")
     ap.add_argument("--bfs-levels", type=int, default=-1, help="broadphase BFS levels before the DFS kernel (-1 = auto)")
     args = ap.parse_args()
 
@@ -221,6 +222,9 @@ def main():
         m.set_option("split_min", args.split_min)
     if args.clip_min >= 0:
         m.set_option("clip_min", args.clip_min)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        m.set_option(name, int(val))
     if os.environ.get("PFC_NO_FILTER"):
         m.set_option("no_filter", int(os.environ["PFC_NO_FILTER"]))     # experiment knob (1: FP64 only)
     n = int(len(mine))

@@ -34,6 +34,25 @@ __device__ __forceinline__ Du operator/(Du a, Du b) {
     const double q = a.v / b.v;
     return Du{q, __builtin_fma(-q, b.d, a.d) / b.v};
 }
+
+// Ring accessor of the shared clip (pfc_clip.h) for a polygon of (value, partial) pairs: values in one LDS ring (column
+// vcol of VS columns; shared by the directions of a candidate in k_narrow_dual), partials in another (column dcol of DS).
+template <int VS_STATIC = 0>
+struct RingDu {
+    typedef Du scalar;
+    double *pv, *pd;
+    int vs, vcol, ds, dcol, rbase;
+    __device__ __forceinline__ int iv(int k, int c) const { return ((((rbase + k) & 7) * 4 + c) * (VS_STATIC ? VS_STATIC : vs)) + vcol; }
+    __device__ __forceinline__ int id(int k, int c) const { return ((((rbase + k) & 7) * 4 + c) * ds) + dcol; }
+    __device__ __forceinline__ double val(int k, int c) const { return pv[iv(k, c)]; }
+    __device__ __forceinline__ Du get(int k, int c) const { return Du{pv[iv(k, c)], pd[id(k, c)]}; }
+    __device__ __forceinline__ void set(int k, int c, Du x) const { pv[iv(k, c)] = x.v; pd[id(k, c)] = x.d; }
+    __device__ __forceinline__ void move(int src, int dst, int c) const {
+        const double tv = pv[iv(src, c)], td = pd[id(src, c)];
+        pv[iv(dst, c)] = tv; pd[id(dst, c)] = td;
+    }
+    __device__ __forceinline__ void rotate(int st) { rbase = (rbase + st) & 7; }
+};
 __device__ __forceinline__ Du operator/(Du a, double b) { return Du{a.v / b, a.d / b}; }
 __device__ __forceinline__ Du dsqrt(Du a) {
     const double s = __builtin_sqrt(a.v);
@@ -528,60 +547,11 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) { PV(k, i) = z[k][i].v; PD(k, i) = z[k][i].d; }
                     }
-                for (int i = 0; i < 4 && n > 0; ++i) {
-                    unsigned nonpos = 0, nonneg = 0;
-                    for (int k = 0; k < n; ++k) {
-                        const double sv = PV(k, i);
-                        nonpos |= (unsigned)(sv <= 0.0) << k;
-                        nonneg |= (unsigned)(0.0 <= sv) << k;
-                    }
-                    const unsigned full = (1u << n) - 1u;
-                    if (nonpos == full) { n = 0; break; }
-                    if (nonneg == full) continue;
-                    const unsigned nxt = ((nonpos >> 1) | ((nonpos & 1u) << (n - 1))) & full;
-                    const unsigned cand_start = nonpos & ~nxt & full;
-                    if (cand_start == 0) { n = 0; break; }   // the value pass has reported it
-                    const int st = __builtin_ctz(cand_start);
-                    int m = n;
-                    while (m > 3) {
-                        int k2 = st + m - 2; if (k2 >= n) k2 -= n;
-                        if ((nonpos >> k2) & 1u) --m; else break;
-                    }
-                    int k1 = st + 1; if (k1 >= n) k1 -= n;
-                    int kl = st + m - 1; if (kl >= n) kl -= n;
-                    int kp = st + m - 2; if (kp >= n) kp -= n;
-                    const bool inside = (m <= 5) ? (((nonpos >> kl) & 1u) == 0) : (((nonneg >> kl) & 1u) != 0);
-                    Du zs[4], ze[4];
-                    {
-                        const Du w1 = du(PV(st, i), PD(st, i)), w2 = du(PV(k1, i), PD(k1, i));
-                        const Du sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) zs[c] = c1 * du(PV(k1, c), PD(k1, c)) - c2 * du(PV(st, c), PD(st, c));
-                    }
-                    {
-                        const int kn = inside ? st : kl, kq = inside ? kl : kp;
-                        const Du w1 = du(PV(kn, i), PD(kn, i)), w2 = du(PV(kq, i), PD(kq, i));
-                        const Du sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) ze[c] = c1 * du(PV(kq, c), PD(kq, c)) - c2 * du(PV(kn, c), PD(kn, c));
-                    }
-                    const int ncopy = inside ? (m - 1) : (m - 2);
-                    for (int q = n - st - 1; q < ncopy; ++q) {
-                        const int src = st + 1 + q - n, dst = st + 1 + q;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const double tv = PV(src, c), td = PD(src, c);
-                            PV(dst, c) = tv; PD(dst, c) = td;
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        PV(st, c) = zs[c].v; PD(st, c) = zs[c].d;
-                        PV(st + ncopy + 1, c) = ze[c].v; PD(st + ncopy + 1, c) = ze[c].d;
-                    }
-                    rbase = (rbase + st) & 7;
-                    n = ncopy + 2;
-                    if (m == 7) break;
+                {
+                    bool err = false;      // "Non-finite vertex likely": the value pass has reported it
+                    RingDu<> ring{pv, pd, pvs, pvi, 64, lane, rbase};
+                    n = clip_ring_in_tet_coordinates(ring, n_in, err);     // pfc_clip.h
+                    rbase = ring.rbase;
                 }
                 n_poly = n;
                 if (n >= 3) nh = nh_in;

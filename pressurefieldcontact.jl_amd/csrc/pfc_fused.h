@@ -631,55 +631,9 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                                 for (int i = 0; i < 4; ++i) FR(tid, rbase, k, i) = z[k][i];
                             }
                         bool err = false;
-                        for (int i = 0; i < 4 && n > 0; ++i) {
-                            unsigned nonpos = 0, nonneg = 0;
-                            for (int k = 0; k < n; ++k) {
-                                const double sv = FR(tid, rbase, k, i);
-                                nonpos |= (unsigned)(sv <= 0.0) << k;
-                                nonneg |= (unsigned)(0.0 <= sv) << k;
-                            }
-                            const unsigned full = (1u << n) - 1u;
-                            if (nonpos == full) { n = 0; break; }       // :44
-                            if (nonneg == full) continue;               // :45-46
-                            const unsigned nxt = ((nonpos >> 1) | ((nonpos & 1u) << (n - 1))) & full;
-                            const unsigned cand_start = nonpos & ~nxt & full;
-                            if (cand_start == 0) { err = true; n = 0; break; }  // "Non-finite vertex likely" (:52)
-                            const int st = __builtin_ctz(cand_start);
-                            int m = n;
-                            while (m > 3) {
-                                int k2 = st + m - 2; if (k2 >= n) k2 -= n;
-                                if ((nonpos >> k2) & 1u) --m; else break;
-                            }
-                            int k1 = st + 1; if (k1 >= n) k1 -= n;
-                            int kl = st + m - 1; if (kl >= n) kl -= n;
-                            int kp = st + m - 2; if (kp >= n) kp -= n;
-                            const bool inside = (m <= 5) ? (((nonpos >> kl) & 1u) == 0) : (((nonneg >> kl) & 1u) != 0);
-                            double zs[4], ze[4];
-                            {
-                                const double w1 = FR(tid, rbase, st, i), w2 = FR(tid, rbase, k1, i);
-                                const double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) zs[c] = c1 * FR(tid, rbase, k1, c) - c2 * FR(tid, rbase, st, c);
-                            }
-                            {
-                                const int kn = inside ? st : kl, kq = inside ? kl : kp;
-                                const double w1 = FR(tid, rbase, kn, i), w2 = FR(tid, rbase, kq, i);
-                                const double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) ze[c] = c1 * FR(tid, rbase, kq, c) - c2 * FR(tid, rbase, kn, c);
-                            }
-                            const int ncopy = inside ? (m - 1) : (m - 2);
-                            for (int q = n - st - 1; q < ncopy; ++q) {
-                                const int src = st + 1 + q - n, dst = st + 1 + q;
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) { const double t = FR(tid, rbase, src, c); FR(tid, rbase, dst, c) = t; }
-                            }
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) { FR(tid, rbase, st, c) = zs[c]; FR(tid, rbase, st + ncopy + 1, c) = ze[c]; }
-                            rbase = (rbase + st) & 7;
-                            n = ncopy + 2;
-                            if (m == 7) break;  // the 7-vertex method returns the polygon directly (:185-195)
-                        }
+                        RingCol<kFuBlock> rg{ring, tid, rbase};
+                        n = clip_ring_in_tet_coordinates(rg, n_in, err);     // pfc_clip.h
+                        rbase = rg.rbase;
                         if (err) status |= kStNonFinite;
                         n_poly = n;
                     }
@@ -987,62 +941,11 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                     for (int k = 0; k < 3; ++k)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) { DV(tid, rbase, k, i) = z[k][i].v; DD(tid, rbase, k, i) = z[k][i].d; }
-                    for (int i = 0; i < 4 && n > 0; ++i) {
-                        unsigned nonpos = 0, nonneg = 0;
-                        for (int k = 0; k < n; ++k) {
-                            const double sv = DV(tid, rbase, k, i);
-                            nonpos |= (unsigned)(sv <= 0.0) << k;
-                            nonneg |= (unsigned)(0.0 <= sv) << k;
-                        }
-                        const unsigned full = (1u << n) - 1u;
-                        if (nonpos == full) { n = 0; break; }
-                        if (nonneg == full) continue;
-                        const unsigned nxt = ((nonpos >> 1) | ((nonpos & 1u) << (n - 1))) & full;
-                        const unsigned cand_start = nonpos & ~nxt & full;
-                        if (cand_start == 0) { n = 0; break; }   // the value pass has reported it
-                        const int st = __builtin_ctz(cand_start);
-                        int m = n;
-                        while (m > 3) {
-                            int k2 = st + m - 2; if (k2 >= n) k2 -= n;
-                            if ((nonpos >> k2) & 1u) --m; else break;
-                        }
-                        int k1 = st + 1; if (k1 >= n) k1 -= n;
-                        int kl = st + m - 1; if (kl >= n) kl -= n;
-                        int kp = st + m - 2; if (kp >= n) kp -= n;
-                        const bool inside = (m <= 5) ? (((nonpos >> kl) & 1u) == 0) : (((nonneg >> kl) & 1u) != 0);
-                        Du zs[4], ze[4];
-                        {
-                            const Du w1 = du(DV(tid, rbase, st, i), DD(tid, rbase, st, i)), w2 = du(DV(tid, rbase, k1, i), DD(tid, rbase, k1, i));
-                            const Du sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                zs[c] = c1 * du(DV(tid, rbase, k1, c), DD(tid, rbase, k1, c)) - c2 * du(DV(tid, rbase, st, c), DD(tid, rbase, st, c));
-                        }
-                        {
-                            const int kn = inside ? st : kl, kq = inside ? kl : kp;
-                            const Du w1 = du(DV(tid, rbase, kn, i), DD(tid, rbase, kn, i)), w2 = du(DV(tid, rbase, kq, i), DD(tid, rbase, kq, i));
-                            const Du sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                ze[c] = c1 * du(DV(tid, rbase, kq, c), DD(tid, rbase, kq, c)) - c2 * du(DV(tid, rbase, kn, c), DD(tid, rbase, kn, c));
-                        }
-                        const int ncopy = inside ? (m - 1) : (m - 2);
-                        for (int qq = n - st - 1; qq < ncopy; ++qq) {
-                            const int src = st + 1 + qq - n, dst = st + 1 + qq;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                const double tv = DV(tid, rbase, src, c), td = DD(tid, rbase, src, c);
-                                DV(tid, rbase, dst, c) = tv; DD(tid, rbase, dst, c) = td;
-                            }
-                        }
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            DV(tid, rbase, st, c) = zs[c].v; DD(tid, rbase, st, c) = zs[c].d;
-                            DV(tid, rbase, st + ncopy + 1, c) = ze[c].v; DD(tid, rbase, st + ncopy + 1, c) = ze[c].d;
-                        }
-                        rbase = (rbase + st) & 7;
-                        n = ncopy + 2;
-                        if (m == 7) break;
+                    {
+                        bool err = false;      // "Non-finite vertex likely": the value pass has reported it
+                        RingDu<kFuDualLanes> rg{dv, dd, kFuDualLanes, tid, kFuDualLanes, tid, rbase};
+                        n = clip_ring_in_tet_coordinates(rg, 3, err);     // pfc_clip.h
+                        rbase = rg.rbase;
                     }
                     n_poly = n >= 3 ? n : 0;
                     if (n_poly) {

@@ -130,6 +130,7 @@ __global__ void k_setup_items(EvalArgs g) {
 }
 
 #include "pfc_bp.h"
+#include "pfc_clip.h"
 #include "pfc_np.h"
 #include "pfc_dual.h"
 #include "pfc_br.h"
@@ -291,6 +292,7 @@ struct pfc_context {
     int *fout_dev = nullptr;           // set by pfc_eval: the kernel writes its per-item block straight into pinned host memory
     const int *fout_host = nullptr;    //   ... and this is where the host reads it
     int opt_fused = 1;                 // option "fused"
+    int opt_clip_queue = 1;            // option "clip_queue": clip-only narrowphase of big tri-tet batches in k_clip_queue (survivors queued in the ring); 0: k_narrow<.., 2 / 3>
     int fused_skip = 0;                // evaluations left for which the fused kernel stays off after an item did not fit
     int fused_seq = 0;                 // sequence number of the last fused launch (completion word of the polled path)
     DevBuf<int> emit_ctr;              // pair counter of the fused kernel's hand-over to the batched Dual passes
@@ -561,7 +563,12 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         // a half of a two-half evaluation clips on the compacted ring (MODE 3, 12 KiB of LDS per wave: shares the CUs with the
         // other half's kernels), a launch that has the chip to itself on a column per lane (MODE 2)
         // (and a launch that does not quite fill the chip: 768 poses 0.72 vs 0.74 ms; 512 poses the other way, 0.63 vs 0.62)
-        if (h->in_split || (n_items >= 640 && n_items < 1024)) {
+        if (h->opt_clip_queue && !h->any_tet_tet && (h->in_split || n_items >= 1024 || h->opt_clip_queue > 1)) {
+            // big tri-tet launches: survivors of the trivial reject queued in the ring, clipped 64 at a time (8 192-pose step
+            // 4.17 -> 4.13 ms as two halves, 4.87 -> 4.70 ms unsplit, 2 048 poses 1.288 -> 1.278; 768 poses lose, 0.712 -> 0.721:
+            // paired A/B, profiles/r03_ab_clip_queue.txt; option value 2 forces it for every clip-only launch: tests)
+            hipLaunchKernelGGL(k_clip_queue, dim3(np_grid), dim3(kNpBlock), 0, st, np);
+        } else if (h->in_split || (n_items >= 640 && n_items < 1024)) {
             if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, 3>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
             else hipLaunchKernelGGL((k_narrow<false, 3>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
         } else {
@@ -1222,6 +1229,7 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
     t->opt_profile = h->opt_profile; t->opt_max_levels = h->opt_max_levels; t->opt_bfs_levels = h->opt_bfs_levels;
     t->opt_poison = h->opt_poison;
     if (t->opt_clip_min != h->opt_clip_min) { t->opt_clip_min = h->opt_clip_min; t->ghave[0] = t->ghave[1] = false; }
+    if (t->opt_clip_queue != h->opt_clip_queue) { t->opt_clip_queue = h->opt_clip_queue; t->ghave[0] = t->ghave[1] = false; }
     t->opt_graph = h->opt_graph;
     if (t->opt_no_filter != h->opt_no_filter) { t->opt_no_filter = h->opt_no_filter; t->ghave[0] = t->ghave[1] = false; }
     const int n0 = n_items / 2, n1 = n_items - n0;
@@ -2041,6 +2049,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "split_min")) h->opt_split_min = (int)value;
     else if (!std::strcmp(name, "dual_reuse")) h->opt_dual_reuse = (int)value;
     else if (!std::strcmp(name, "clip_min")) { h->opt_clip_min = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
+    else if (!std::strcmp(name, "clip_queue")) { h->opt_clip_queue = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else if (!std::strcmp(name, "poison")) h->opt_poison = value != 0;
     else if (!std::strcmp(name, "fused")) { h->opt_fused = value != 0; h->fused_skip = 0; }
     else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }

@@ -175,6 +175,196 @@ __device__ __forceinline__ double lds_row_sums(double *buf, const double *v, boo
     return (dst_row >= 0 && dst_row < N) ? out : 0.0;
 }
 
+// The front of one op (tri-tet: non_friction.jl:196-215 up to the clip; tet-tet: :166-190): gather the two mesh records,
+// express the input polygon (3 or 4 vertices) in the coordinates of tet 2 -> z, its normal -> nh_in, and apply the bit-exact
+// trivial reject.  Returns true if the candidate has to be clipped.  One statement for k_narrow (every mode) and
+// k_clip_queue; `report`: raise kStNonFinite for a non-finite vertex ("Non-finite vertex likely", static_clip.jl:52).
+template <bool TT>
+__device__ __forceinline__ bool np_front(const ItemRec *it, const WorkRec &cw, const GTetRec *tp, double (&z)[4][4], int &n_in,
+                                         V3 &nh_in, unsigned *status, bool report) {
+    double R21[9], t21[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R21[k] = it->R21[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t21[k] = it->t21[k];
+    double Z[16];        // x_ζ2_r2
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
+    if (!TT || it->tet1 == nullptr) {
+        // ---- tri-tet op (non_friction.jl:196-215) -----------------------------------------------------------
+        const GTriRec *tr = (const GTriRec *)(it->tri + cw.a);
+        // x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (:204); last row of x_r2_r1.mat is (0 0 0 1)
+        double X[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
+            X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + Z[i + 12];
+        }
+        // v_k = x_ζ2_r1 * onePad(vert_k) (:205-207)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                z[k][i] = ((X[i] * tr->v[3 * k] + X[i + 4] * tr->v[3 * k + 1]) + X[i + 8] * tr->v[3 * k + 2]) + X[i + 12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[3][i] = 0.0;
+        n_in = 3;
+        // n̂2 = R(x_r2_r1) * n̂_r1 (:211-212)
+        nh_in = mk3((R21[0] * tr->n[0] + R21[3] * tr->n[1]) + R21[6] * tr->n[2],
+                    (R21[1] * tr->n[0] + R21[4] * tr->n[1]) + R21[7] * tr->n[2],
+                    (R21[2] * tr->n[0] + R21[5] * tr->n[1]) + R21[8] * tr->n[2]);
+    } else {
+        // ---- tet-tet op (non_friction.jl:166-194) -----------------------------------------------------------
+        const GTetRec *t1 = (const GTetRec *)(it->tet1 + cw.a);
+        double plane[4];
+        {
+            // ϵ_plane_r2 = (Ē2 ϵ2) x_ζ2_r2 - (Ē1 ϵ1) (x_ζ1_r1 x_r1_r2)   (find_plane_tet :164, :174-177)
+            double R12[9], t12[3], Z1[16], X1[16];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R12[k] = it->R12[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t12[k] = it->t12[k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Z1[k] = t1->xzr[k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    X1[i + 4 * j] = (Z1[i] * R12[3 * j] + Z1[i + 4] * R12[3 * j + 1]) + Z1[i + 8] * R12[3 * j + 2];
+                X1[i + 12] = ((Z1[i] * t12[0] + Z1[i + 4] * t12[1]) + Z1[i + 8] * t12[2]) + Z1[i + 12];
+            }
+            double Ee1[4], Ee2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Ee1[j] = it->Ebar1 * ((const gdouble *)it->eps1)[4 * (size_t)cw.a + j];
+                Ee2[j] = it->Ebar * ((const gdouble *)it->eps2)[4 * (size_t)cw.b + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double p1 = ((Ee1[0] * X1[4 * j] + Ee1[1] * X1[4 * j + 1]) + Ee1[2] * X1[4 * j + 2]) + Ee1[3] * X1[4 * j + 3];
+                const double p2 = ((Ee2[0] * Z[4 * j] + Ee2[1] * Z[4 * j + 1]) + Ee2[2] * Z[4 * j + 2]) + Ee2[3] * Z[4 * j + 3];
+                plane[j] = p2 - p1;
+            }
+        }
+        // x_r2_ζ1 = x_r2_r1.mat * x_r1_ζ1: the vertices of tet 1 in frame r2 (:180); proj = plane * tet (:19)
+        V3 P[4];
+        double proj[4];
+        int n_neg = 0, n_pos = 0;
+        unsigned posm = 0, negm = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double vx = t1->xrz[3 * j], vy = t1->xrz[3 * j + 1], vz = t1->xrz[3 * j + 2];
+            P[j] = mk3(((R21[0] * vx + R21[3] * vy) + R21[6] * vz) + t21[0],
+                       ((R21[1] * vx + R21[4] * vy) + R21[7] * vz) + t21[1],
+                       ((R21[2] * vx + R21[5] * vy) + R21[8] * vz) + t21[2]);
+            proj[j] = ((plane[0] * P[j].x + plane[1] * P[j].y) + plane[2] * P[j].z) + plane[3];
+            if (proj[j] < 0.0) { ++n_neg; negm |= 1u << j; }
+            if (0.0 < proj[j]) { ++n_pos; posm |= 1u << j; }
+        }
+        // clip_plane_tet (plane_tet_intersection.jl:9-106).  weightPoly(v[i1], v[i2], proj[i1], proj[i2]) does
+        // not depend on the order of (i1, i2) bit for bit, so one edge function serves every case.
+        V3 q[4];
+        q[0] = q[1] = q[2] = q[3] = mk3(0.0, 0.0, 0.0);
+        int n_q = 0;
+#define PW_(i1, i2) (P[i2] * (proj[i1] / (proj[i1] - proj[i2])) - P[i1] * (proj[i2] / (proj[i1] - proj[i2])))
+        if (n_pos != 0 && n_neg != 0) {
+            int lone = -1;
+            if (n_pos == 1) lone = __builtin_ctz(posm);
+            else if (n_neg == 1) lone = __builtin_ctz(negm);
+            if (lone >= 0) {
+                V3 a, b, c;   // :52-79
+                if (lone == 0) { a = PW_(1, 0); b = PW_(3, 0); c = PW_(2, 0); }
+                else if (lone == 1) { a = PW_(0, 1); b = PW_(2, 1); c = PW_(3, 1); }
+                else if (lone == 2) { a = PW_(0, 2); b = PW_(3, 2); c = PW_(1, 2); }
+                else { a = PW_(0, 3); b = PW_(1, 3); c = PW_(2, 3); }
+                double pl = (lone == 0) ? proj[0] : (lone == 1) ? proj[1] : (lone == 2) ? proj[2] : proj[3];
+                n_q = 3;
+                if (0.0 < pl) { q[0] = a; q[1] = b; q[2] = c; } else { q[0] = c; q[1] = b; q[2] = a; }
+            } else {
+                V3 a, b, c, d;   // :81-106
+                const bool p0 = (posm & 1u) != 0, p1 = (posm & 2u) != 0, p2 = (posm & 4u) != 0;
+                if (p0 == p1) { a = PW_(1, 2); b = PW_(1, 3); c = PW_(0, 3); d = PW_(0, 2); }
+                else if (p0 == p2) { a = PW_(0, 1); b = PW_(0, 3); c = PW_(2, 3); d = PW_(2, 1); }
+                else { a = PW_(0, 2); b = PW_(0, 1); c = PW_(3, 1); d = PW_(3, 2); }
+                n_q = 4;
+                if (0.0 < proj[0]) { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+                else { q[0] = d; q[1] = c; q[2] = b; q[3] = a; }
+            }
+        }
+#undef PW_
+        // poly_ζ2 = one_pad_then_mul(x_ζ2_r2, poly_r2), then zero_small_coordinates (:184-187)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double v = ((Z[i] * q[k].x + Z[i + 4] * q[k].y) + Z[i + 8] * q[k].z) + Z[i + 12];
+                z[k][i] = v * ((1.0e-14 < __builtin_fabs(v)) ? 1.0 : 0.0);
+            }
+        n_in = n_q;
+        nh_in = normalize(mk3(plane[0], plane[1], plane[2]));   // :190
+    }
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) finite &= (k >= n_in) || (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
+    if (!finite) if (report) atomicOr(status, kStNonFinite);
+    // Trivial reject: if every vertex is non-positive on some plane the clip is empty.  Bit-exact shortcut:
+    // every clipped vertex is c1*p2 - c2*p1 with c1 >= 0 >= c2 (static_clip.jl:197-201), whose sign on that
+    // plane is exact, so Sutherland-Hodgman returns the empty polygon at that plane (:44).
+    bool reject = !finite || n_in < 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0) && (n_in < 4 || z[3][i] <= 0.0);
+#if PFC_EXP == 3
+    reject |= z[0][0] > -1e300;
+#endif
+    return !reject;
+}
+
+// Clip-only narrowphase: poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98) fused with centroid(poly_r2, n̂2)
+// (poly_eight.jl:35-52), as in the full kernel; every vertex leaves for the kept polygon (SoA slot `slot`, streaming stores)
+// as it is converted.  k_integ and k_fric read what is written here.
+template <class Ring>
+__device__ __forceinline__ void np_keep_polygon(const Ring &R, int n, const GTetRec *tp, V3 nh, const NpArgs &g, int slot, int item,
+                                                int idx) {
+    const size_t P = (size_t)g.pcap;
+    double *o = g.poly + slot;
+#define NT_(p, v) __builtin_nontemporal_store((v), (p))
+    double V[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
+    auto conv = [&](int k) {
+        const double z0 = R.get(k, 0), z1 = R.get(k, 1), z2 = R.get(k, 2), z3 = R.get(k, 3);
+        const V3 x = mk3(((V[0] * z0 + V[3] * z1) + V[6] * z2) + V[9] * z3,
+                         ((V[1] * z0 + V[4] * z1) + V[7] * z2) + V[10] * z3,
+                         ((V[2] * z0 + V[5] * z1) + V[8] * z2) + V[11] * z3);
+        NT_(o + (10 + 3 * k) * P, x.x); NT_(o + (11 + 3 * k) * P, x.y); NT_(o + (12 + 3 * k) * P, x.z);
+        return x;
+    };
+    const V3 a = conv(0);
+    V3 cc = conv(1);
+    double cum_sum = 0.0;
+    V3 cum_prod = mk3(0.0, 0.0, 0.0);
+    for (int k = 2; k < n; ++k) {
+        const V3 b = cc;
+        cc = conv(k);
+        const double ar = triangle_area(a, b, cc, nh);
+        cum_prod = cum_prod + ((a + b) + cc) * (1.0 / 3.0) * ar;
+        cum_sum += ar;
+    }
+    const V3 cen = (cum_sum == 0.0) ? a : cum_prod / cum_sum;
+    NT_(&g.poly_item[slot], (int)((unsigned)item | ((unsigned)n << 28)));
+    NT_(o, nh.x); NT_(o + P, nh.y); NT_(o + 2 * P, nh.z);
+    NT_(o + 3 * P, cen.x); NT_(o + 4 * P, cen.y); NT_(o + 5 * P, cen.z);
+    NT_(o + 6 * P, tp->epsr[0]); NT_(o + 7 * P, tp->epsr[1]); NT_(o + 8 * P, tp->epsr[2]);
+    NT_(o + 9 * P, tp->epsr[3]);
+    if (g.poly_cand) NT_(&g.poly_cand[slot], idx);
+#undef NT_
+}
+
 // Everything up to the per-item sums (regularized friction fused; bristle: normal wrench + patch moments).  For bristle
 // items the clipped polygon of every contributing pair is kept (34 doubles, SoA by compacted slot: every store
 // instruction of a wave writes consecutive doubles) so that the friction pass after k_eig (k_fric) re-integrates the
@@ -243,63 +433,9 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
                     for (int i = 0; i < 4; ++i) PR(k, i) = z[k][i];
                 }
             bool err = false;
-            for (int i = 0; i < 4 && n > 0; ++i) {
-                unsigned nonpos = 0, nonneg = 0;
-                for (int k = 0; k < n; ++k) {
-                    double sv = PR(k, i);
-                    nonpos |= (unsigned)(sv <= 0.0) << k;
-                    nonneg |= (unsigned)(0.0 <= sv) << k;
-                }
-                const unsigned full = (1u << n) - 1u;
-                if (nonpos == full) { n = 0; break; }       // :44
-                if (nonneg == full) continue;               // :45-46
-                // first k with is_non_pos[k] && !is_non_pos[k+1] (cyclic) (:48-50)
-                unsigned nxt = ((nonpos >> 1) | ((nonpos & 1u) << (n - 1))) & full;
-                unsigned cand_start = nonpos & ~nxt & full;
-                if (cand_start == 0) { err = true; n = 0; break; }  // "Non-finite vertex likely" (:52)
-                const int st = __builtin_ctz(cand_start);
-                // cut_clip (:135-195): drop trailing vertices while z_{m-1} is non-positive
-                int m = n;
-                while (m > 3) {
-                    int k2 = st + m - 2; if (k2 >= n) k2 -= n;
-                    if ((nonpos >> k2) & 1u) --m; else break;
-                }
-                int k1 = st + 1; if (k1 >= n) k1 -= n;
-                int kl = st + m - 1; if (kl >= n) kl -= n;   // z_m (last)
-                int kp = st + m - 2; if (kp >= n) kp -= n;   // z_{m-1}
-                // inside test of the last vertex: 0 < z for arity 3..5 (:140,150,162), 0 <= z for 6..7 (:176,188)
-                const bool inside = (m <= 5) ? (((nonpos >> kl) & 1u) == 0) : (((nonneg >> kl) & 1u) != 0);
-                // z_start = clip_node(z1, z2); z_end = clip_node(z1, z_m) or clip_node(z_m, z_{m-1}); both are
-                // formed in registers before the ring is touched
-                double zs[4], ze[4];
-                {
-                    double w1 = PR(st, i), w2 = PR(k1, i);
-                    double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) zs[c] = c1 * PR(k1, c) - c2 * PR(st, c);
-                }
-                {
-                    const int kn = inside ? st : kl, kq = inside ? kl : kp;
-                    double w1 = PR(kn, i), w2 = PR(kq, i);
-                    double sw = w1 - w2, c1 = w1 / sw, c2 = w2 / sw;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) ze[c] = c1 * PR(kq, c) - c2 * PR(kn, c);
-                }
-                const int ncopy = inside ? (m - 1) : (m - 2);   // z2 .. z_m  or  z2 .. z_{m-1} stay in the polygon
-                // In place: the new polygon starts at old logical st.  Kept vertices st+1 .. n-1 do not move;
-                // kept vertices that wrapped around (old logical 0 .. ) move up by n slots, in increasing order
-                // (a destination is either a free slot or the source of an earlier move).
-                for (int q = n - st - 1; q < ncopy; ++q) {
-                    const int src = st + 1 + q - n, dst = st + 1 + q;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { const double t = PR(src, c); PR(dst, c) = t; }
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { PR(st, c) = zs[c]; PR(st + ncopy + 1, c) = ze[c]; }
-                rbase = (rbase + st) & 7;
-                n = ncopy + 2;
-                if (m == 7) break;  // the 7-vertex method returns the polygon directly (:185-195)
-            }
+            RingCol<RC> ring{poly, rcol, rbase};
+            n = clip_ring_in_tet_coordinates(ring, n_in, err);     // pfc_clip.h
+            rbase = ring.rbase;
             if (err) atomicOr(g.status, kStNonFinite);
             n_poly = n;
 #if PFC_EXP == 4
@@ -309,146 +445,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         };
         // ==== phase 1 (divergent): gather, transform to tet coordinates, clip ========================================
         if (work) {
-            double R21[9], t21[3];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) R21[k] = it->R21[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) t21[k] = it->t21[k];
-            double Z[16];        // x_ζ2_r2
-#pragma unroll
-            for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
-            if (!TT || it->tet1 == nullptr) {
-                // ---- tri-tet op (non_friction.jl:196-215) -----------------------------------------------------------
-                const GTriRec *tr = (const GTriRec *)(it->tri + cw.a);
-                // x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (:204); last row of x_r2_r1.mat is (0 0 0 1)
-                double X[16];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
-                    X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + Z[i + 12];
-                }
-                // v_k = x_ζ2_r1 * onePad(vert_k) (:205-207)
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        z[k][i] = ((X[i] * tr->v[3 * k] + X[i + 4] * tr->v[3 * k + 1]) + X[i + 8] * tr->v[3 * k + 2]) + X[i + 12];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) z[3][i] = 0.0;
-                n_in = 3;
-                // n̂2 = R(x_r2_r1) * n̂_r1 (:211-212)
-                nh_in = mk3((R21[0] * tr->n[0] + R21[3] * tr->n[1]) + R21[6] * tr->n[2],
-                            (R21[1] * tr->n[0] + R21[4] * tr->n[1]) + R21[7] * tr->n[2],
-                            (R21[2] * tr->n[0] + R21[5] * tr->n[1]) + R21[8] * tr->n[2]);
-            } else {
-                // ---- tet-tet op (non_friction.jl:166-194) -----------------------------------------------------------
-                const GTetRec *t1 = (const GTetRec *)(it->tet1 + cw.a);
-                double plane[4];
-                {
-                    // ϵ_plane_r2 = (Ē2 ϵ2) x_ζ2_r2 - (Ē1 ϵ1) (x_ζ1_r1 x_r1_r2)   (find_plane_tet :164, :174-177)
-                    double R12[9], t12[3], Z1[16], X1[16];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) R12[k] = it->R12[k];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) t12[k] = it->t12[k];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) Z1[k] = t1->xzr[k];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int j = 0; j < 3; ++j)
-                            X1[i + 4 * j] = (Z1[i] * R12[3 * j] + Z1[i + 4] * R12[3 * j + 1]) + Z1[i + 8] * R12[3 * j + 2];
-                        X1[i + 12] = ((Z1[i] * t12[0] + Z1[i + 4] * t12[1]) + Z1[i + 8] * t12[2]) + Z1[i + 12];
-                    }
-                    double Ee1[4], Ee2[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        Ee1[j] = it->Ebar1 * ((const gdouble *)it->eps1)[4 * (size_t)cw.a + j];
-                        Ee2[j] = it->Ebar * ((const gdouble *)it->eps2)[4 * (size_t)cw.b + j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const double p1 = ((Ee1[0] * X1[4 * j] + Ee1[1] * X1[4 * j + 1]) + Ee1[2] * X1[4 * j + 2]) + Ee1[3] * X1[4 * j + 3];
-                        const double p2 = ((Ee2[0] * Z[4 * j] + Ee2[1] * Z[4 * j + 1]) + Ee2[2] * Z[4 * j + 2]) + Ee2[3] * Z[4 * j + 3];
-                        plane[j] = p2 - p1;
-                    }
-                }
-                // x_r2_ζ1 = x_r2_r1.mat * x_r1_ζ1: the vertices of tet 1 in frame r2 (:180); proj = plane * tet (:19)
-                V3 P[4];
-                double proj[4];
-                int n_neg = 0, n_pos = 0;
-                unsigned posm = 0, negm = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double vx = t1->xrz[3 * j], vy = t1->xrz[3 * j + 1], vz = t1->xrz[3 * j + 2];
-                    P[j] = mk3(((R21[0] * vx + R21[3] * vy) + R21[6] * vz) + t21[0],
-                               ((R21[1] * vx + R21[4] * vy) + R21[7] * vz) + t21[1],
-                               ((R21[2] * vx + R21[5] * vy) + R21[8] * vz) + t21[2]);
-                    proj[j] = ((plane[0] * P[j].x + plane[1] * P[j].y) + plane[2] * P[j].z) + plane[3];
-                    if (proj[j] < 0.0) { ++n_neg; negm |= 1u << j; }
-                    if (0.0 < proj[j]) { ++n_pos; posm |= 1u << j; }
-                }
-                // clip_plane_tet (plane_tet_intersection.jl:9-106).  weightPoly(v[i1], v[i2], proj[i1], proj[i2]) does
-                // not depend on the order of (i1, i2) bit for bit, so one edge function serves every case.
-                V3 q[4];
-                q[0] = q[1] = q[2] = q[3] = mk3(0.0, 0.0, 0.0);
-                int n_q = 0;
-#define PW_(i1, i2) (P[i2] * (proj[i1] / (proj[i1] - proj[i2])) - P[i1] * (proj[i2] / (proj[i1] - proj[i2])))
-                if (n_pos != 0 && n_neg != 0) {
-                    int lone = -1;
-                    if (n_pos == 1) lone = __builtin_ctz(posm);
-                    else if (n_neg == 1) lone = __builtin_ctz(negm);
-                    if (lone >= 0) {
-                        V3 a, b, c;   // :52-79
-                        if (lone == 0) { a = PW_(1, 0); b = PW_(3, 0); c = PW_(2, 0); }
-                        else if (lone == 1) { a = PW_(0, 1); b = PW_(2, 1); c = PW_(3, 1); }
-                        else if (lone == 2) { a = PW_(0, 2); b = PW_(3, 2); c = PW_(1, 2); }
-                        else { a = PW_(0, 3); b = PW_(1, 3); c = PW_(2, 3); }
-                        double pl = (lone == 0) ? proj[0] : (lone == 1) ? proj[1] : (lone == 2) ? proj[2] : proj[3];
-                        n_q = 3;
-                        if (0.0 < pl) { q[0] = a; q[1] = b; q[2] = c; } else { q[0] = c; q[1] = b; q[2] = a; }
-                    } else {
-                        V3 a, b, c, d;   // :81-106
-                        const bool p0 = (posm & 1u) != 0, p1 = (posm & 2u) != 0, p2 = (posm & 4u) != 0;
-                        if (p0 == p1) { a = PW_(1, 2); b = PW_(1, 3); c = PW_(0, 3); d = PW_(0, 2); }
-                        else if (p0 == p2) { a = PW_(0, 1); b = PW_(0, 3); c = PW_(2, 3); d = PW_(2, 1); }
-                        else { a = PW_(0, 2); b = PW_(0, 1); c = PW_(3, 1); d = PW_(3, 2); }
-                        n_q = 4;
-                        if (0.0 < proj[0]) { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
-                        else { q[0] = d; q[1] = c; q[2] = b; q[3] = a; }
-                    }
-                }
-#undef PW_
-                // poly_ζ2 = one_pad_then_mul(x_ζ2_r2, poly_r2), then zero_small_coordinates (:184-187)
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const double v = ((Z[i] * q[k].x + Z[i + 4] * q[k].y) + Z[i + 8] * q[k].z) + Z[i + 12];
-                        z[k][i] = v * ((1.0e-14 < __builtin_fabs(v)) ? 1.0 : 0.0);
-                    }
-                n_in = n_q;
-                nh_in = normalize(mk3(plane[0], plane[1], plane[2]));   // :190
-            }
-            bool finite = true;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) finite &= (k >= n_in) || (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
-            if (!finite) atomicOr(g.status, kStNonFinite);
-            // Trivial reject: if every vertex is non-positive on some plane the clip is empty.  Bit-exact shortcut:
-            // every clipped vertex is c1*p2 - c2*p1 with c1 >= 0 >= c2 (static_clip.jl:197-201), whose sign on that
-            // plane is exact, so Sutherland-Hodgman returns the empty polygon at that plane (:44).
-            bool reject = !finite || n_in < 3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0) && (n_in < 4 || z[3][i] <= 0.0);
-#if PFC_EXP == 3
-            reject |= z[0][0] > -1e300;
-#endif
-            if (!reject) {
+            if (np_front<TT>(it, cw, tp, z, n_in, nh_in, g.status, true)) {
                 STAMP(t1);
                 survivor = true;
                 if constexpr (!COMPACT) clip_ring();      // (MODE 3 clips below, on the compacted ring)
@@ -479,42 +476,8 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             const int slot = ch * C + pc + __popcll(km & ((1ull << lane) - 1ull));
             pc += __popcll(km);
             if (has_poly) {
-                const int n = n_poly;
-                // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98) fused with centroid(poly_r2, n̂2)
-                // (poly_eight.jl:35-52), as in the full kernel below; every vertex leaves for the kept polygon as it is converted
-                const size_t P = (size_t)g.pcap;
-                double *o = g.poly + slot;
-#define NT_(p, v) __builtin_nontemporal_store((v), (p))
-                double V[12];
-#pragma unroll
-                for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
-                auto conv = [&](int k) {
-                    const double z0 = PR(k, 0), z1 = PR(k, 1), z2 = PR(k, 2), z3 = PR(k, 3);
-                    const V3 x = mk3(((V[0] * z0 + V[3] * z1) + V[6] * z2) + V[9] * z3,
-                                     ((V[1] * z0 + V[4] * z1) + V[7] * z2) + V[10] * z3,
-                                     ((V[2] * z0 + V[5] * z1) + V[8] * z2) + V[11] * z3);
-                    NT_(o + (10 + 3 * k) * P, x.x); NT_(o + (11 + 3 * k) * P, x.y); NT_(o + (12 + 3 * k) * P, x.z);
-                    return x;
-                };
-                const V3 a = conv(0);
-                V3 cc = conv(1);
-                double cum_sum = 0.0;
-                V3 cum_prod = mk3(0.0, 0.0, 0.0);
-                for (int k = 2; k < n; ++k) {
-                    const V3 b = cc;
-                    cc = conv(k);
-                    const double ar = triangle_area(a, b, cc, nh);
-                    cum_prod = cum_prod + ((a + b) + cc) * (1.0 / 3.0) * ar;
-                    cum_sum += ar;
-                }
-                const V3 cen = (cum_sum == 0.0) ? a : cum_prod / cum_sum;
-                NT_(&g.poly_item[slot], (int)((unsigned)cw.item | ((unsigned)n << 28)));
-                NT_(o, nh.x); NT_(o + P, nh.y); NT_(o + 2 * P, nh.z);
-                NT_(o + 3 * P, cen.x); NT_(o + 4 * P, cen.y); NT_(o + 5 * P, cen.z);
-                NT_(o + 6 * P, tp->epsr[0]); NT_(o + 7 * P, tp->epsr[1]); NT_(o + 8 * P, tp->epsr[2]);
-                NT_(o + 9 * P, tp->epsr[3]);
-                if (g.poly_cand) NT_(&g.poly_cand[slot], idx);
-#undef NT_
+                RingCol<RC> ring{poly, rcol, rbase};
+                np_keep_polygon(ring, n_poly, tp, nh, g, slot, cw.item, idx);
             }
             // (the LDS unit serves a wave's instructions in order: the next pass may overwrite the ring)
             }
@@ -889,6 +852,141 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
 #endif
 }
 #undef PR
+
+// =================================================================================================================
+// k_clip_queue (round 3) -- clip-only narrowphase of tri-tet batches: survivors of the trivial reject are QUEUED in the
+// polygon ring itself and clipped 64 at a time, every lane busy.  k_narrow<.., 2 / 3> clips a round of 64 candidates with
+// the ~35 lanes that pass the trivial reject (C3: 46 % of the candidates are rejected right after the gather); the other
+// lanes idle through the divergent Sutherland-Hodgman, the polygon conversion and the kept-polygon stores (31 of 64 lanes
+// active per VALU instruction, profiles/pmc_valu.json of round 2).  A first form of this kernel ran the front over the
+// whole chunk, noted the survivors and evaluated the front a SECOND time for 64 dense survivors at a time: elimination
+// builds put that second front at 0.25 ms of its 1.23 ms (profiles/r03_clip_elimination.txt), and it lost to
+// k_narrow<.., 3> under the two-half overlap (4.22 vs 4.15 ms per step); this form keeps what the front computed.
+//
+// A queued survivor needs its 3 input vertices in tet coordinates (12 doubles), n̂ (3) and (item, tet) (one 8-byte word):
+// 16 doubles -- half of a ring column (8 slots x 4 coordinates).  Entry e < 64 lives in column e, slots 0..2 (+ slot 6:
+// n̂, word); entry 64 + e in column e, slots 3..5 (+ slot 7).  A round of the front adds at most 64 entries to fewer than
+// 64 waiting ones, so 128 entries always suffice.  With 64 or more queued, lane c clips entry c in place (its vertices
+// already sit at logical 0..2 of column c), having first taken the upper entry of its column into registers; afterwards it
+// writes that entry back as entry c of the remaining queue.  16 KiB of LDS as before, no second gather, no second front.
+// Tet-tet candidates enter with 4 vertices and do not fit the half column: scenarios with tet-tet instructions keep
+// k_narrow<true, 2 / 3>.
+// =================================================================================================================
+__global__ void __launch_bounds__(kNpBlock) k_clip_queue(NpArgs g) {
+    constexpr int RC = kNpBlock;
+    __shared__ double poly[8 * 4 * RC];
+    __shared__ unsigned short qpos[2 * kNpBlock];     // position in the chunk of every queued entry
+    const int lane = threadIdx.x;
+    int n_c = *g.ccount;
+    if (n_c > g.ccap) n_c = g.ccap;
+    const int C = np_chunk(n_c, g.chunk_switch);
+    const int n_chunk = (n_c + C - 1) / C;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#define QZ(e, k, i) poly[(((((e) >> 6) * 3 + (k)) * 4 + (i)) * RC) + ((e) & 63)]
+#define QX(e, i) poly[(((6 + ((e) >> 6)) * 4 + (i)) * RC) + ((e) & 63)]
+    for (int ch = blockIdx.x; ch < n_chunk; ch += gridDim.x) {
+        const int n_here = n_c - ch * C < C ? n_c - ch * C : C;
+        const int n_round = (n_here + kNpBlock - 1) / kNpBlock;
+        int q = 0;    // queued entries
+        int pc = 0;   // polygons kept so far in this chunk's slot range
+        // clips entries 0 .. min(q, 64) - 1, one per lane; entries 64 .. q - 1 become entries 0 .. q - 65
+        auto dense_round = [&]() {
+            const int n_take = q < kNpBlock ? q : kNpBlock;
+            const bool mine = lane < n_take, left = kNpBlock + lane < q;
+            V3 nh = mk3(0.0, 0.0, 0.0);
+            unsigned long long meta = 0ull;
+            int pos = 0;
+            if (mine) {
+                nh = mk3(QX(lane, 0), QX(lane, 1), QX(lane, 2));
+                meta = (unsigned long long)__double_as_longlong(QX(lane, 3));
+                pos = (int)qpos[lane];
+            }
+            double zl[3][4], xl[4];
+            int posl = 0;
+            if (left) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) zl[k][i] = QZ(kNpBlock + lane, k, i);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xl[i] = QX(kNpBlock + lane, i);
+                posl = (int)qpos[kNpBlock + lane];
+            }
+            const int item = (int)(unsigned)(meta & 0xFFFFFFFFull), b = (int)(unsigned)(meta >> 32);
+            const ItemRec *it = g.items + item;
+            const GTetRec *tp = (const GTetRec *)(it->tet + b);
+            RingCol<RC> ring{poly, lane, 0};
+            int n_poly = 0;
+            if (mine) {
+                bool err = false;
+                n_poly = clip_ring_in_tet_coordinates(ring, 3, err);     // pfc_clip.h
+                if (err) atomicOr(g.status, kStNonFinite);
+            }
+            const bool has_poly = n_poly >= 3;
+            const unsigned long long km = __ballot(has_poly);
+            const int slot = ch * C + pc + __popcll(km & below);
+            pc += __popcll(km);
+            if (has_poly) np_keep_polygon(ring, n_poly, tp, nh, g, slot, item, ch * C + pos);
+            if (km) {
+                const int item_first = __builtin_amdgcn_readfirstlane(item);      // lane 0 always holds an entry here
+                if (__all(!mine || item == item_first)) {
+                    if (lane == 0) atomicAdd(&g.icnt[4 * (size_t)item_first + 2], __popcll(km));
+                } else {
+                    count_per_item(g.icnt, item, 2, mine, has_poly);
+                }
+            }
+            // the upper entry of this column moves down (a lane only touches its own column and its own two qpos entries)
+            if (left) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) QZ(lane, k, i) = zl[k][i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) QX(lane, i) = xl[i];
+                qpos[lane] = (unsigned short)posl;
+            }
+            q -= n_take;
+            wave_lds_sync();
+        };
+        for (int rd = 0; rd < n_round; ++rd) {
+            const int pos = rd * kNpBlock + lane, idx = ch * C + pos;
+            bool active = pos < n_here;
+            WorkRec cw;
+            cw.item = 0; cw.a = 0; cw.b = 0; cw.pad = 0;
+            if (active) cw = g.cand[idx];
+            if ((unsigned)cw.item >= (unsigned)g.n_items) {     // an unwritten slot is reported, never followed
+                atomicOr(g.status, kStHole);
+                cw.item = 0; cw.a = 0; cw.b = 0;
+                active = false;
+            }
+            const ItemRec *it = g.items + cw.item;
+            const GTetRec *tp = (const GTetRec *)(it->tet + cw.b);
+            double z[4][4];
+            int n_in = 0;
+            V3 nh_in = mk3(0.0, 0.0, 0.0);
+            bool survivor = false;
+            if (active) survivor = np_front<false>(it, cw, tp, z, n_in, nh_in, g.status, true);
+            const unsigned long long sm = __ballot(survivor);
+            if (survivor) {
+                const int e = q + __popcll(sm & below);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) QZ(e, k, i) = z[k][i];
+                QX(e, 0) = nh_in.x; QX(e, 1) = nh_in.y; QX(e, 2) = nh_in.z;
+                QX(e, 3) = __longlong_as_double((long long)(((unsigned long long)(unsigned)cw.b << 32) | (unsigned long long)(unsigned)cw.item));
+                qpos[e] = (unsigned short)pos;
+            }
+            q += __popcll(sm);
+            wave_lds_sync();
+            if (q >= kNpBlock) dense_round();
+        }
+        if (q > 0) dense_round();
+        if (lane == 0) g.pcnt[ch] = pc;
+    }
+#undef QZ
+#undef QX
+}
 
 // =================================================================================================================
 // k_integ -- integrate_over_polygon_patch! (non_friction.jl:217-265) over the polygons k_narrow<.., 2> kept: one lane per

@@ -18,7 +18,7 @@ pmc_check_names() {   # pmc_check_names "<CTR1 CTR2 ...>" -> 0 ok, 1 refused (me
   local c
   for c in $1; do
     case "$c" in
-      TA_*|*TA_*) echo "pmc: counter $c refused (TA_* groups aborted rocprofv3 on this image, scripts/README.md)" >&2; return 1;;
+      TA_*) echo "pmc: counter $c refused (TA_* groups aborted rocprofv3 on this image, scripts/README.md)" >&2; return 1;;
     esac
     if [ "${PFC_PMC_FORCE:-0}" != "1" ] && ! echo " $PMC_KNOWN " | grep -q " $c "; then
       echo "pmc: counter $c has not completed a pass on this image before; set PFC_PMC_FORCE=1 to try it (under the timeout)" >&2

@@ -22,7 +22,7 @@ for it in range(n_evals):
     s = int(rng.choice(sizes))
     opts = {"debug": int(rng.random() < 0.2), "graph": int(rng.random() < 0.7), "profile": int(rng.random() < 0.3),
             "bfs_levels": int(rng.choice([-1, 0, 1, 2])), "no_filter": int(rng.random() < 0.15),
-            "split_min": int(rng.choice([0, 256, 1024])), "fused": int(rng.random() < 0.6), "clip_min": int(rng.choice([0, 1, 256, 1024])),
+            "split_min": int(rng.choice([0, 256, 1024])), "fused": int(rng.random() < 0.6), "clip_min": int(rng.choice([0, 1, 256, 1024])), "clip_queue": int(rng.random() < 0.6),
             "max_levels": int(rng.choice([0, 0, 1, 3]))}
     for k, v in opts.items():
         m.set_option(k, v)

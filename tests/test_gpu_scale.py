@@ -417,13 +417,17 @@ def test_clip_and_integrate_split_equals_the_one_kernel_narrowphase(pfc):
     for w in worlds:
         ref = H.oracle_run(pfc, w, debug=False)
         out = []
-        for cm in (0, 1):
+        # clip_queue: tri-tet scenarios clip in k_clip_queue (survivors of the trivial reject queued in the ring, 64 dense
+        # lanes per clip round; round 3); 0 keeps k_narrow<.., 2 / 3>, which scenarios with tet-tet instructions always use
+        for cm, cq in ((0, 1), (1, 2), (1, 0)):        # 2: k_clip_queue whatever the launch size
             m = pfc.configs.build_scenario(w)
             m.set_option("fused", 0)
             m.set_option("clip_min", cm)
+            m.set_option("clip_queue", cq)
             out.append(m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids))
             m.close()
-        assert np.array_equal(out[0][2], out[1][2]), w.name
+        assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][2], out[2][2]), w.name
+        assert np.abs(out[0][0] - out[2][0]).max() <= 1e-11 * max(np.abs(out[0][0]).max(), 1e-300), w.name
         for k in range(w.n_items):
             assert np.array_equal(out[1][2][k], ref[k].counts), (w.name, k)
         scale = max(np.abs(out[0][0]).max(), 1e-300)
@@ -447,16 +451,18 @@ def test_clip_on_the_compacted_ring(pfc, n_scene):
     worlds = [pfc.configs.c2_box_on_plane(n_scene, montecarlo=True, n_div=5), _fuzz_workload(pfc, rng, n_scene, False, tet_tet=True)]
     for w in worlds:
         out = []
-        for cm in (0, -1):
+        for cm, cq in ((0, 1), (-1, 0), (-1, 2)):
             m = pfc.configs.build_scenario(w)
             m.set_option("fused", 0)
+            m.set_option("clip_queue", cq)       # 0: the compacted ring of k_narrow<false, 3> for the tri-tet world as well
             if cm >= 0:
                 m.set_option("clip_min", cm)
             out.append(m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids))
             if cm < 0 and n_scene > 1024:
                 assert m.last_parts() == 2
             m.close()
-        assert np.array_equal(out[0][2], out[1][2]), w.name
+        assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][2], out[2][2]), w.name
+        assert np.abs(out[0][0] - out[2][0]).max() <= 1e-11 * max(np.abs(out[0][0]).max(), 1e-300), w.name
         scale = max(np.abs(out[0][0]).max(), 1e-300)
         assert np.abs(out[0][0] - out[1][0]).max() <= 1e-11 * scale, w.name
         sample = [0, 1, w.n_items // 2, w.n_items - 1] + [int(k) for k in rng.integers(0, w.n_items, 12)]

@@ -93,8 +93,11 @@ def test_hip_sdot_difference_stays_inside_the_oracles_own_noise(pfc, pile):
         if _near_null(r) >= 2:
             _, sens = _ulp_sensitivity(r, c, w.s[k], n_trial=12)
             n_sliver += 1
-            # within a small multiple of what a rounding-level perturbation of K̄ does to the oracle itself
-            assert diff <= max(50.0 * sens, 1e-9), (k, diff, sens)
+            # within a small multiple of what a rounding-level perturbation of K̄ does to the oracle itself.  K is a sum over
+            # the item's n traction points, taken in another order on the device: the two sums differ by ~sqrt(n) eps, not
+            # by one eps (item 1804: three eigenvalues at the clamp, sens 2.4e-8 per eps, 270 points, difference 2.8e-6)
+            noise = sens * max(1.0, np.sqrt(float(r.counts[3])))
+            assert diff <= max(50.0 * noise, 1e-9), (k, diff, sens, noise)
             assert diff < 1e-3
         else:
             assert diff < 1e-6, (k, diff)
