@@ -138,7 +138,8 @@ def small_scene_latencies(pfc, reps: int = 200):
             blocks.append((time.perf_counter() - t0) / 25)
         dt = statistics.median(blocks)
         out[name] = {"us_per_eval": dt * 1e6, "ops": int(ct[:, 1].sum()), "ops_per_s": float(ct[:, 1].sum()) / dt,
-                     "path": {0: "fused", 1: "batched", 2: "batched, two halves"}[m.last_parts()]}
+                     "path": ({0: "fused", 1: "batched", 2: "batched, two halves"}[m.last_parts()] +
+                              (f", team of {m.last_team()} workgroups" if m.last_team() > 1 else ""))}
         m.close()
     return out
 

@@ -222,7 +222,11 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
  * out of range but report it, PFC_ERR_STATE "a work-list slot was read before it was written"), "fused" (default 1:
  * an evaluation of <= 256 items over small trees runs as ONE kernel, one workgroup per item, instead of the batched
  * launch sequence -- the scene sizes Radau evaluates, src/radau/radau_functions.jl:2-14,64-70; same results; 0 = always
- * batched; the debug / profile options imply the batched path). */
+ * batched; the debug / profile options imply the batched path), "clip_queue" (default 1: the clip-only kernel of a big
+ * tri-tet launch queues the candidates that pass the trivial reject in its polygon ring and clips 64 of them at a time;
+ * 0 = the lane-per-candidate clip rounds; same results bit for bit), "team" (default 32; 0 = never: an evaluation of a few
+ * pairs too big for one workgroup -- BASELINE's single 9 680-tet x 5 120-triangle pair -- runs as ONE kernel with a team
+ * of up to this many workgroups per item; same results up to the order of the sums; pfc_last_team()). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);
 
 /* Totals of the last checked evaluation: out[0..7] = {node tests, candidate pairs, non-empty pairs, traction
@@ -236,6 +240,8 @@ int pfc_get_stats(pfc_handle h, long long *out8);
 int pfc_get_stage_ms(pfc_handle h, float *out6);
 int pfc_last_parts(pfc_handle h);   /* 1, or 2 if the last checked evaluation ran as two concurrent halves; 0: it ran as the
                                      * single fused small-scene kernel (option "fused") */
+int pfc_last_team(pfc_handle h);    /* workgroups per item of the last checked evaluation if it ran as one fused kernel (1: a
+                                     * workgroup per item; > 1: a team per item, option "team"), else 0 */
 int pfc_last_dual_reused(pfc_handle h);   /* 1 if the last Dual evaluation ran only its Dual passes on the value pass of the
                                              previous one (pfc_eval_dual_device_more, or pfc_eval_dual with equal value inputs) */
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pfc_debug_tractions": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int]),
     "pfc_debug_stiffness": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]),
     "pfc_last_parts": (C.c_int, [C.c_void_p]),
+    "pfc_last_team": (C.c_int, [C.c_void_p]),
     "pfc_last_dual_reused": (C.c_int, [C.c_void_p]),
     "pfc_eval_dual": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "pfc_eval_dual_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 13),

@@ -27,7 +27,7 @@ constexpr int kFuWaves = kFuBlock / 64;
 constexpr int kFuCand = 4096;      // candidate pairs per item held in LDS (32 KiB)
 constexpr int kFuNodes = 256;      // node heads per tree cached in LDS (2 x 16 KiB) ...
 constexpr int kFuFull = (kFuNodes * 4) / 9;   // ... or the whole tree (144-byte NodeRec) if it has at most this many nodes
-constexpr int kFuStack = 2560;     // node pairs (20 KiB), as k_bp_dfs32
+constexpr int kFuStack = 4096;     // node pairs (32 KiB: with the two node caches exactly the 64 KiB the polygon ring needs anyway)
 constexpr unsigned kStFusedOvf = 512u;   // item does not fit the fused kernel's LDS lists: use the batched path
 constexpr unsigned kStFusedDualSkip = 1024u;   // too many (polygon, direction) pairs for the in-kernel Dual passes: batched Dual path
 constexpr int kFuDualLanes = 128;        // (polygon, direction) lanes per Dual clip round: value + partial ring = 512 B per lane
@@ -68,7 +68,19 @@ struct FuArgs {
     int *emit_surv, *emit_icnt, *emit_ctr;
     int emit_cap;
     unsigned long long *stamps;   // diagnostic builds (-DPFC_STAMPS): block 0 leaves wall-clock stamps (10 ns ticks) of its phases
+    // Teams (k_fused<.., true>, round 3): nw workgroups per item -- blockIdx.x = item * nw + rank.  team: per (workgroup,
+    // phase) kTeamSlots doubles of partial sums, written and read with agent-scope (sc1) accesses; team_ctr: per (item,
+    // phase) an arrival counter that only ever grows (nw adds per launch: no zeroing between evaluations).
+    int nw;
+    double *team;
+    int *team_ctr;
 };
+constexpr int kTeamSlots = 32;           // doubles a workgroup publishes per phase (27 patch-stiffness moments are the most)
+constexpr int kTeamMaxWg = 32;           // workgroups per item at most
+constexpr int kTeamMaxBlocks = 256;      // item * nw + rank < this (one workgroup per CU: every workgroup of a launch is resident)
+constexpr int kTeamSeeds = 16;           // the descent is shared out once a level holds this many pairs per workgroup ...
+constexpr int kTeamShareMax = 768;       // ... or this many in all: its children (four per pair at most) still fit the stack above it
+constexpr int kTeamSpinMax = 1 << 20;    // bounded wait for the team (~0.1 s): if a workgroup never arrives the item reports kStFusedOvf (batched path)
 
 #ifdef PFC_STAMPS
 #define FSTAMP(k)                                                                                   \
@@ -122,7 +134,60 @@ union FuScratch {
 // after the conversion to Cartesian coordinates the fourth coordinate of every slot is free: slots 0..5 hold n̂, centroid
 #define FX(t, s) ring[((((s) * 4) + 3) * kFuBlock) + (t)]
 
-template <bool TT>     // TT: the scenario has tet-tet instructions (as k_narrow<TT>)
+// Team sum of n <= kTeamSlots values, one per thread tid < n (`mine`); returns the team's total of slot tid to thread tid,
+// summed in rank order by every workgroup alike (all workgroups of a team continue with bit-identical totals).  Slot
+// or_slot is combined by bitwise OR of its integer value instead (status words).
+// Visibility across CUs / XCDs (MI355X guide, "Workgroup dispatch, XCD placement & inter-workgroup visibility", the
+// hand-off form with sc1 stores, one agent-scope atomic add per storing workgroup behind every storing wave's
+// s_waitcnt vmcnt(0) and a workgroup barrier, an sc1 poll of the counter by one lane, a workgroup barrier, sc1 loads): the
+// partials never sit in an L1 / L2 another workgroup could read stale.  The counter of (item, phase) only grows: a launch
+// adds exactly nw to it, so the arrival that returns `old` belongs to the launch whose adds end at (old / nw + 1) nw.
+__device__ __forceinline__ double team_sum(const FuArgs &g, int item, int nw, int phase, int n, double mine, int or_slot, int tid,
+                                           double *s_team, int *s_flag, unsigned &status) {
+    double *my = g.team + ((size_t)blockIdx.x * 3 + phase) * kTeamSlots;
+    if (tid < n) __hip_atomic_store(my + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        int *ctr = g.team_ctr + 3 * item + phase;
+        const unsigned old = (unsigned)atomicAdd(ctr, 1);
+        const unsigned target = (old / (unsigned)nw + 1u) * (unsigned)nw;
+        int spins = 0;
+        while ((int)((unsigned)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 && spins < kTeamSpinMax) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+        }
+        *s_flag = spins >= kTeamSpinMax ? 1 : 0;
+    }
+    __syncthreads();
+    if (*s_flag) status |= kStFusedOvf;    // a team-mate never arrived: the host re-issues on the batched path (uniform over the workgroup)
+    // every workgroup's n values -> LDS (independent loads: one round trip), then the sum in rank order
+    const double *base = g.team + ((size_t)(item * nw) * 3 + phase) * kTeamSlots;
+    for (int idx = tid; idx < nw * kTeamSlots; idx += kFuBlock) {
+        const int w2 = idx / kTeamSlots, t = idx % kTeamSlots;
+        if (t < n) s_team[idx] = __hip_atomic_load(base + (size_t)w2 * 3 * kTeamSlots + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    double acc = 0.0;
+    if (tid < n) {
+        for (int w2 = 0; w2 < nw; ++w2) {
+            const double x = s_team[w2 * kTeamSlots + tid];
+            if (tid == or_slot) acc = (double)((unsigned)acc | (unsigned)x); else acc += x;
+        }
+    }
+    __syncthreads();        // s_team is free again
+    return acc;
+}
+
+// TT: the scenario has tet-tet instructions (as k_narrow<TT>).  MW: a TEAM of g.nw workgroups per item (one big pair --
+// BASELINE config 3 as written is a single 9 680-tet x 5 120-triangle pair: a lone workgroup would need 110 broadphase
+// iterations and its candidates do not fit LDS).  Every workgroup of a team runs the top of the descent redundantly --
+// the traversal is deterministic, so all hold the same stack -- until it holds kTeamSeeds pairs per workgroup; rank r
+// keeps the pairs j = r (mod nw) and descends them alone (no shared queue, no communication in the broadphase); each
+// workgroup clips and integrates the candidates IT found; the three per-pass sums of the bristle model (normal wrench +
+// cop, patch stiffness, friction) meet in team_sum, every workgroup forms cop / K / its eigen-decomposition from the same
+// totals, rank 0 writes the item's outputs.
+template <bool TT, bool MW = false>
 __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     __shared__ FuScratch S;
     __shared__ int2 cand[kFuCand];
@@ -141,7 +206,12 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     __shared__ ItemRec s_it;                    // what dual_integrate reads of an item
     double *ring = S.ring;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int item = blockIdx.x;
+    const int nw = MW ? g.nw : 1;
+    const int item = MW ? (int)blockIdx.x / nw : (int)blockIdx.x;
+    const int wr = MW ? (int)blockIdx.x - item * nw : 0;      // rank in the team
+    __shared__ double s_team[MW ? kTeamMaxWg * kTeamSlots : 1];
+    __shared__ double s_tres[kTeamSlots];
+    __shared__ int s_tflag;
     unsigned status = 0;
 
     FSTAMP(0);
@@ -225,7 +295,16 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
 #ifdef PFC_STAMPS
         unsigned long long cy[4] = {0, 0, 0, 0}, it_n = 0;
 #endif
-        for (int guard = 0; sp > 0 && guard < (1 << 22); ++guard) {
+        // Teams: the top of the descent runs LEVEL BY LEVEL, identically in every workgroup of the team (the traversal is
+        // deterministic): the pairs of the current level sit in stk[0, hi), their children are pushed above them (from hi0 =
+        // the level's size on), and when the level is used up the next one moves down.  Once a level holds enough pairs for
+        // every rank (or the next might not fit the stack), rank wr keeps the pairs j = wr (mod nw) and goes on depth first,
+        // alone.  (Shared out from the depth-first stack at 128 pairs, a single C3 pose had nearly all its work under two or
+        // three of them: 270 us, slower than the batched path.)
+        bool bfs = MW;
+        int hi = MW ? 1 : 0, hi0 = hi;
+        const int t_share = nw * kTeamSeeds < kTeamShareMax ? nw * kTeamSeeds : kTeamShareMax;
+        for (int guard = 0; (bfs ? hi > 0 : sp > 0) && guard < (1 << 22); ++guard) {
             unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0; (void)u0; (void)u1; (void)u2; (void)u3; (void)u4;
             STAMP(u0);
             // Lookahead.  An iteration costs ~4 000 cycles whatever the number of busy lanes (one Float64 test per lane, a
@@ -235,12 +314,13 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             // result counts only if every ancestor pair it descends from overlaps (the reference tests a pair iff its
             // parent pair intersects, tree_types.jl:88-111), so node tests and candidates are the reference's.
             const int room = kFuStack - reserve - sp;
+            const int avail = bfs ? hi : sp;      // pairs that may be popped now
             int LA = 1, p;
-            if (sp <= 8 && room >= 64 * sp) { LA = 3; p = sp; }
-            else if (sp <= 32 && room >= 16 * sp) { LA = 2; p = sp; }
+            if (avail <= 8 && room >= 64 * avail) { LA = 3; p = avail; }
+            else if (avail <= 32 && room >= 16 * avail) { LA = 2; p = avail; }
             else {
                 int pw = room / 3;
-                p = sp < kFuBlock ? sp : kFuBlock;
+                p = avail < kFuBlock ? avail : kFuBlock;
                 if (pw < 1) pw = 1;
                 if (p > pw) p = pw;
             }
@@ -252,7 +332,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             else if (LA == 3 && r >= 5 && r <= 20) { lvl = 2; c1 = (r - 5) >> 2; c2 = (r - 5) & 3; }
             else if (r >= 5) act = false;
             int2 e = make_int2(0, 0);
-            if (act) e = B.stk[sp - 1 - grp];
+            if (act) e = B.stk[avail - 1 - grp];
             // walk down to the lane's own pair: child order (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107), or the two
             // children of the internal node when the other one is a leaf (:97-103)
 #define FU_LINKS(LDSARR, FULL, NC, GLOB, IDX) ((IDX) < (NC) ? LDSARR[((FULL) ? (IDX) * 9 : (IDX) * 4) + 3] : ((const gvec4i *)((GLOB) + (IDX)))[3])
@@ -281,7 +361,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                 }
             }
 #undef FU_LINKS
-            sp -= p;
+            if (bfs) hi -= p; else sp -= p;      // (level mode: the children go above the level, not into the popped slots)
             bool hit = false;
             int a0 = 0, a1 = 0, b0 = 0, b1 = 0, la_id = 0, lb_id = 0;
             const bool la = act && e.x < 0, lb = act && e.y < 0;
@@ -363,8 +443,34 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             }
             n_cand += c_tot;
             sp += p_tot;
-            if (n_cand > kFuCand) { ovf = true; sp = 0; }    // uniform: the item leaves for the batched path
+            if (n_cand > kFuCand) { ovf = true; sp = 0; hi = 0; bfs = false; }    // uniform: the item leaves for the batched path
             __syncthreads();
+            if (MW && bfs && hi == 0) {
+                // the level is used up: its children stk[hi0, sp) become the next level -- or, if there are enough of them
+                // (or their children might not fit above them), this rank's share of the depth-first descent
+                const int n_next = sp - hi0;
+                const bool share = n_next >= t_share;
+                int2 keep[kFuStack / kFuBlock];
+#pragma unroll
+                for (int k = 0; k < kFuStack / kFuBlock; ++k) {
+                    const int j = tid + k * kFuBlock;
+                    keep[k] = j < n_next ? B.stk[hi0 + j] : make_int2(0, 0);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < kFuStack / kFuBlock; ++k) {
+                    const int j = tid + k * kFuBlock;
+                    if (j < n_next && (!share || j % nw == wr)) B.stk[share ? j / nw : j] = keep[k];
+                }
+                if (share) {
+                    sp = (n_next - wr + nw - 1) / nw;
+                    if (wr != 0) { n_cand = 0; n_test = 0; }      // what has been counted and found so far stays with rank 0
+                    bfs = false;
+                } else {
+                    sp = n_next; hi = n_next; hi0 = n_next;
+                }
+                __syncthreads();
+            }
 #ifdef PFC_STAMPS
             STAMP(u4);
             if (u1 == 0) u1 = u0;
@@ -377,6 +483,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         }
 #endif
 #undef FU_FETCH
+        if (MW && bfs && wr != 0) { n_cand = 0; n_test = 0; }     // the descent ended before it was shared out
         if (ovf) status |= kStFusedOvf;
         else if (sp > 0) status |= kStAbort;
     }
@@ -801,6 +908,25 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             __syncthreads();
             n_nonempty = ((s_cnt[0][0] + s_cnt[1][0]) + s_cnt[2][0]) + s_cnt[3][0];
             n_trac = ((s_cnt[0][1] + s_cnt[1][1]) + s_cnt[2][1]) + s_cnt[3][1];
+            if (MW) {
+                // team totals: the ten sums, the four counters, the status word
+                double mine = 0.0;
+                if (tid < 10) mine = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
+                else if (tid == 10) mine = (double)n_test;
+                else if (tid == 11) mine = (double)n_cand;
+                else if (tid == 12) mine = (double)n_nonempty;
+                else if (tid == 13) mine = (double)n_trac;
+                else if (tid == 14) mine = (double)status;
+                const double tot = team_sum(g, item, nw, 0, 15, mine, 14, tid, s_team, &s_tflag, status);
+                if (tid < 15) s_tres[tid] = tot;
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 10; ++k) tot10[k] = s_tres[k];
+                n_test = (int)s_tres[10]; n_cand = (int)s_tres[11]; n_nonempty = (int)s_tres[12]; n_trac = (int)s_tres[13];
+                status |= (unsigned)s_tres[14];
+                __syncthreads();
+                FSTAMP(12);
+            }
             contact = n_trac > 0;
             if (!reg && contact) {
                 const double iS = tot10[6];
@@ -810,7 +936,12 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             block_partials<27>(acc, red, tid);
             // the item's accumulator block in the kAcc* layout (read by eig_item); a register array indexed by the thread
             // id would live in scratch, so the 27 totals are formed from the wave partials by the thread that stores them
-            if (tid < 27) s_acc[kAccSnn + tid] = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
+            if (MW) {
+                const double mine = tid < 27 ? ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid] : 0.0;
+                const double tot = team_sum(g, item, nw, 1, 27, mine, -1, tid, s_team, &s_tflag, status);
+                if (tid < 27) s_acc[kAccSnn + tid] = tot;
+                FSTAMP(13);
+            } else if (tid < 27) s_acc[kAccSnn + tid] = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
             if (tid == 32) {
                 s_acc[kAccIp] = tot10[6];
                 s_acc[kAccIpc] = tot10[7]; s_acc[kAccIpc + 1] = tot10[8]; s_acc[kAccIpc + 2] = tot10[9];
@@ -818,6 +949,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             __syncthreads();
             if (wave == 0) eig_item(s_acc, I.ins.k_bar, I.ins.magic, I.s, s_res, E, lane);
             __syncthreads();
+            if (MW) FSTAMP(14);
             // per-item constants of the friction pass (k_fric): T̄s = c0 + e x r
             const V3 copr = ld3(s_res + kResCop), Da = ld3(s_res + kResDelta), Dl = ld3(s_res + kResDelta + 3);
             cop = copr;
@@ -825,13 +957,18 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             ts_e = (Da + w * I.ins.tau) * (-I.ins.k_bar);
         } else {
             block_partials<6>(acc, red, tid);
-            if (tid < 6) s_acc[kAccFric + tid] = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
+            if (MW) {
+                const double mine = tid < 6 ? ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid] : 0.0;
+                const double tot = team_sum(g, item, nw, 2, 6, mine, -1, tid, s_team, &s_tflag, status);
+                if (tid < 6) s_acc[kAccFric + tid] = tot;
+                FSTAMP(15);
+            } else if (tid < 6) s_acc[kAccFric + tid] = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
             __syncthreads();
         }
     }
 
     // ==== 4a. hand-over to the batched Dual passes ======================================================================
-    if (g.emit_items) {
+    if (!MW && g.emit_items) {
         __shared__ int s_cbase;
         __syncthreads();
         const int n_pl = s_npoly;
@@ -877,7 +1014,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     // found above: lane = (polygon, direction) clips in (value, partial) arithmetic -- every branch on values, the value
     // half of every operation the instruction sequence of the value pass, as in k_narrow_dual -- then the fan triangles are
     // dealt out one per thread and the partial sums of each direction meet in LDS.
-    if (g.n_dir > 0) {
+    if (!MW && g.n_dir > 0) {
         const int n_dir = g.n_dir;
         __syncthreads();
         const int n_pd = s_npoly * n_dir;
@@ -1043,7 +1180,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         __syncthreads();
         status = (unsigned)(((s_cnt[0][0] | s_cnt[1][0]) | s_cnt[2][0]) | s_cnt[3][0]);
     }
-    if (tid == 0) {     // one lane, static indices only (a register array indexed by the thread id would live in scratch)
+    if (tid == 0 && wr == 0) {     // one lane, static indices only (a register array indexed by the thread id would live in scratch)
         double wv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sd[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (reg) {
 #pragma unroll
@@ -1073,7 +1210,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) { g.wrench[6 * (size_t)item + k] = wv[k]; g.sdot[6 * (size_t)item + k] = sd[k]; }
     }
-    if (tid == 0) {      // the same lane stored wrench and sdot above
+    if (tid == 0 && wr == 0) {      // the same lane stored wrench and sdot above
         int *fo = g.fout + 8 * (size_t)item;
         fo[0] = (int)status; fo[1] = n_test; fo[2] = n_cand; fo[3] = n_nonempty; fo[4] = n_trac;
         fo[6] = fo[7] = 0;

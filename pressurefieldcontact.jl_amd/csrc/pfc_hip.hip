@@ -295,6 +295,11 @@ struct pfc_context {
     int opt_clip_queue = 1;            // option "clip_queue": clip-only narrowphase of big tri-tet batches in k_clip_queue (survivors queued in the ring); 0: k_narrow<.., 2 / 3>
     int fused_skip = 0;                // evaluations left for which the fused kernel stays off after an item did not fit
     int fused_seq = 0;                 // sequence number of the last fused launch (completion word of the polled path)
+    int fu_nw = 1;                     // workgroups per item of the next fused launch (teams: k_fused<.., true>)
+    int last_fu_nw = 0, last_team = 0; // of the last fused launch / of the last checked evaluation (pfc_last_team)
+    int opt_team = kTeamMaxWg;         // option "team": big pairs (more leaves than one workgroup takes) run as teams of up to this many workgroups (0: batched path)
+    DevBuf<double> team;               // team partial sums (kTeamMaxBlocks x 3 x kTeamSlots)
+    DevBuf<int> team_ctr;              // arrival counters (kFusedMaxItems x 3), zeroed once, only ever growing
     DevBuf<int> emit_ctr;              // pair counter of the fused kernel's hand-over to the batched Dual passes
     int *h_emit = nullptr;             // pinned mirror
     unsigned *h_more = nullptr;        // pinned: status word of the Dual passes of pfc_eval_dual_device_more (device word: status.p + 1)
@@ -738,6 +743,18 @@ bool fused_ok(const pfc_context *h, int n_items) {
     return h->opt_fused && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv &&
            !h->is_twin && h->d_insfull && n_items <= kFusedMaxItems && h->max_leaves <= kFusedMaxLeaves;
 }
+// Team size for an evaluation of a few BIG pairs (more leaves than one workgroup takes: BASELINE config 3 as written is one
+// 9 680-tet x 5 120-triangle pair): as many workgroups per item as keep every workgroup of the launch resident (one per CU),
+// at most kTeamMaxWg; 0: not a team evaluation.
+int fused_team(const pfc_context *h, int n_items) {
+    if (!(h->opt_fused && h->opt_team && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv && !h->is_twin &&
+          h->d_insfull && h->max_leaves > kFusedMaxLeaves && n_items >= 1))
+        return 0;
+    int nw = kTeamMaxBlocks / n_items;
+    if (nw > kTeamMaxWg) nw = kTeamMaxWg;
+    if (nw > h->opt_team) nw = h->opt_team;
+    return nw >= 4 ? nw : 0;
+}
 
 int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
                   const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, hipStream_t st) {
@@ -777,6 +794,18 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
     HIP_TRY(h, h->stamps.ensure(16));
     a.stamps = h->stamps.p;
 #endif
+    a.nw = h->fu_nw; a.team = nullptr; a.team_ctr = nullptr;
+    h->last_fu_nw = a.nw;
+    if (a.nw > 1) {
+        if (!h->team.p) {
+            HIP_TRY(h, h->team.ensure((size_t)kTeamMaxBlocks * 3 * kTeamSlots));
+            HIP_TRY(h, h->team_ctr.ensure((size_t)kFusedMaxItems * 3));
+            HIP_TRY(h, hipMemsetAsync(h->team_ctr.p, 0, sizeof(int) * h->team_ctr.cap, st));
+        }
+        a.team = h->team.p; a.team_ctr = h->team_ctr.p;
+        if (h->any_tet_tet) hipLaunchKernelGGL((k_fused<true, true>), dim3(n_items * a.nw), dim3(kFuBlock), 0, st, a);
+        else hipLaunchKernelGGL((k_fused<false, true>), dim3(n_items * a.nw), dim3(kFuBlock), 0, st, a);
+    } else
     // a direct launch: cheaper than a graph replay
     if (h->any_tet_tet) hipLaunchKernelGGL((k_fused<true>), dim3(n_items), dim3(kFuBlock), 0, st, a);
     else hipLaunchKernelGGL((k_fused<false>), dim3(n_items), dim3(kFuBlock), 0, st, a);
@@ -1219,6 +1248,12 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
     h->dual_reuse_ok = false; h->pending_more = false;
     if (fused_ok(h, n_items))
         return enqueue_fused(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
+    if (const int team = fused_team(h, n_items)) {
+        h->fu_nw = team;
+        const int rc_t = enqueue_fused(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
+        h->fu_nw = 1;
+        return rc_t;
+    }
     if (h->fused_skip > 0 && n_items <= kFusedMaxItems) --h->fused_skip;
     const bool split = h->opt_split_min > 0 && n_items >= h->opt_split_min && d_ins_ids && !h->opt_debug &&
                        !h->want_surv && !h->is_twin;
@@ -2052,6 +2087,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "clip_queue")) { h->opt_clip_queue = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else if (!std::strcmp(name, "poison")) h->opt_poison = value != 0;
     else if (!std::strcmp(name, "fused")) { h->opt_fused = value != 0; h->fused_skip = 0; }
+    else if (!std::strcmp(name, "team")) h->opt_team = value < 0 ? 0 : (value > kTeamMaxWg ? kTeamMaxWg : (int)value);
     else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;
@@ -2084,6 +2120,7 @@ int pfc_get_stage_ms(pfc_handle h, float *out6) {
 }
 
 int pfc_last_parts(pfc_handle h) { return h ? (h->last_fused ? 0 : h->last_parts) : 0; }
+int pfc_last_team(pfc_handle h) { return h ? (h->last_fused ? h->last_fu_nw : 0) : 0; }
 int pfc_last_dual_reused(pfc_handle h) { return h ? (h->last_dual_reused ? 1 : 0) : 0; }
 
 int pfc_debug_pairs(pfc_handle h, int item, int *pairs, int *clip_n, int cap) {

@@ -403,6 +403,10 @@ class MechanismScenario:
         single fused small-scene kernel (option fused)."""
         return int(_lib.lib().pfc_last_parts(self._h))
 
+    def last_team(self) -> int:
+        """Workgroups per item of the last checked evaluation if it ran as one fused kernel (> 1: a team per item), else 0."""
+        return int(_lib.lib().pfc_last_team(self._h))
+
     def last_dual_reused(self) -> bool:
         """True if the last Dual evaluation ran only its Dual passes on the previous one's value pass."""
         return bool(_lib.lib().pfc_last_dual_reused(self._h))

@@ -1,0 +1,17 @@
+import sys, os, time
+sys.path.insert(0, '/root/repo') if os.path.isdir('/root/repo') else None
+sys.path.insert(0, os.getcwd())
+import numpy as np, pfc_pkg
+pfc = pfc_pkg.load()
+w = pfc.configs.c3_blob_tool(1)
+for team in (32, 16, 8, 0):
+    m = pfc.configs.build_scenario(w)
+    m.set_option("team", team)
+    for _ in range(20): m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    blocks = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        for _ in range(25): out = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        blocks.append((time.perf_counter() - t0) / 25)
+    print(f"team {team}: {np.median(blocks)*1e6:.1f} us/eval path {m.last_parts()} counts {out[2][0]}")
+    m.close()

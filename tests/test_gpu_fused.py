@@ -248,3 +248,38 @@ def test_fused_fuzz_with_tet_tet(pfc, degenerate):
             assert np.linalg.norm(wrench[k]) == 0.0
     assert n_contact > 40
     m.close()
+
+
+@pytest.mark.parametrize("n_poses, model", [(1, "bristle"), (4, "bristle"), (8, "bristle"), (3, "regularized")])
+def test_team_of_workgroups_for_big_pairs(pfc, n_poses, model):
+    """BASELINE config 3 as written -- ONE 9 680-tet blob against ONE 5 120-triangle tool -- is too big for a lone
+    workgroup (110 broadphase iterations; its candidates overflow the LDS list): a TEAM of workgroups per item takes it in
+    one launch (k_fused<.., true>: top of the descent redundantly, the stack shared out by rank, candidates clipped where
+    found, three team sums for the bristle passes).  Full-size meshes, counts bit-equal to the oracle's, wrench 1e-9; the
+    batched path (option team = 0) gives the same integers."""
+    w = pfc.configs.c3_blob_tool(n_poses)
+    assert w.meta["n_tet"] == 9680 and w.meta["n_tri"] == 5120
+    if model == "regularized":
+        w.instructions[0].model = "regularized"
+    m, (wrench, sdot, counts) = _run(pfc, w)
+    assert m.last_parts() == 0 and m.last_team() == min(32, 256 // n_poses), "the team kernel did not run"
+    _against_oracle(pfc, w, wrench, sdot, counts)
+    st = m.stats()
+    assert st["candidates"] == int(counts[:, 1].sum()) and st["node_tests"] == int(counts[:, 0].sum())
+    # repeated evaluations on the same handle (the arrival counters only grow), other poses in between
+    w2 = pfc.configs.c3_blob_tool(n_poses, seed=5)
+    if model == "regularized":
+        w2.instructions[0].model = "regularized"
+    for _ in range(3):
+        a = m.force_all_elastic_intersections(w2.pose, w2.twist, w2.s, w2.ins_ids)
+        b = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        assert m.last_parts() == 0
+        assert np.array_equal(b[2], counts)
+        np.testing.assert_allclose(b[0], wrench, rtol=1e-11, atol=1e-11 * np.abs(wrench).max())
+    _against_oracle(pfc, w2, *a)
+    m.set_option("team", 0)
+    c = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert m.last_parts() == 1
+    assert np.array_equal(c[2], counts)
+    np.testing.assert_allclose(c[0], wrench, rtol=1e-10, atol=1e-10 * np.abs(wrench).max())
+    m.close()
