@@ -334,8 +334,9 @@ def main():
         parts_n = parts_prof
         # SURVEY §8(d) accounting: algorithmic bytes / kernel time against the HBM peak (well below 1: these kernels re-read
         # their 64..256-byte records from L2 / Infinity Cache and are bound by vector issue, see "valu").
-        roof_np = {"kernel": "k_narrow<false, 3> + k_integ (the narrowphase of a big batch: clip-only kernel -- <false, 2> when the step is not split --, then the integration "
-                             "over the kept polygons; ms_per_launch covers both, HIP events around the pair)", "bound": "hbm",
+        roof_np = {"kernel": "k_clip_queue + k_integ (the narrowphase of a big batch: clip-only kernel -- k_narrow<.., 2 / 3> for scenarios with tet-tet instructions --, "
+                             "then the integration over the kept polygons; ms_per_launch covers both, HIP events around the pair)", "bound": "hbm",
+                   "limited_by": "vector-instruction issue and latency, not HBM: see 'valu' (the HBM fraction is the accounting SURVEY 8d prescribes)",
                    "achieved": BYTES_PER_OP * st_prof["candidates"] / parts_n / (np_ms * 1e-3) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms_per_launch": np_ms,
                    "units_per_launch": st_prof["candidates"] / parts_n, "bytes_per_unit": BYTES_PER_OP}

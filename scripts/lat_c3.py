@@ -1,6 +1,7 @@
+"""A single full-size C3 pose (BASELINE config 3 as written: one 9 680-tet x 5 120-triangle pair) through host buffers, by
+team size (option "team": workgroups per item of the one-launch kernel; 0 = the batched launch sequence)."""
 import sys, os, time
-sys.path.insert(0, '/root/repo') if os.path.isdir('/root/repo') else None
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pfc_pkg
 pfc = pfc_pkg.load()
 w = pfc.configs.c3_blob_tool(1)

@@ -19,7 +19,8 @@ def newest_per_dir(pattern):
 def kname(full):
     """kernel name without its argument list; the instantiations of k_bp_dfs32<BLK> under one name"""
     n = re.sub(r"^void (pfc::k_bp_dfs32)<\d+>$", r"\1", re.sub(r"\(.*", "", full))
-    return n.replace("k_narrow<false, 3>", "k_narrow<false, 2>")      # the two clip-only forms (ring by lane / by survivor rank) under one name
+    # the clip-only forms (ring by lane / by survivor rank; round 3: survivors queued in the ring, k_clip_queue) under one name
+    return n.replace("k_narrow<false, 3>", "k_narrow<false, 2>").replace("pfc::k_clip_queue", "void pfc::k_narrow<false, 2>")
 
 
 tag = sys.argv[1]

@@ -18,7 +18,8 @@ def newest_per_dir(pattern):
 def kname(full):
     """kernel name without its argument list; the instantiations of k_bp_dfs32<BLK> under one name"""
     n = re.sub(r"^void (pfc::k_bp_dfs32)<\d+>$", r"\1", re.sub(r"\(.*", "", full))
-    return n.replace("k_narrow<false, 3>", "k_narrow<false, 2>")      # the two clip-only forms (ring by lane / by survivor rank) under one name
+    # the clip-only forms (ring by lane / by survivor rank; round 3: survivors queued in the ring, k_clip_queue) under one name
+    return n.replace("k_narrow<false, 3>", "k_narrow<false, 2>").replace("pfc::k_clip_queue", "void pfc::k_narrow<false, 2>")
 
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -49,7 +50,7 @@ def steady(v):
 parts = int(bench.get("concurrent_parts", 1))
 out = {"source": "rocprofv3 --pmc (scripts/pmc_probe.sh, one counter group per pass), bench.py default workload "
                  f"({int(bench['config'].get('items_per_step', bench['config'].get('poses_per_gpu', 0)))} poses as {parts} concurrent part(s)); PER STEP = {parts} x the per-launch averages",
-       "measured": "round 2",
+       "measured": "round 3",
        "node_tests": int(bench["config"]["node_tests_per_step"]), "candidates": int(bench["config"]["ops_per_step"])}
 for kern, name in (("pfc::k_bp_dfs32", "k_bp_dfs32"), ("void pfc::k_narrow<false, 2>", "k_narrow"), ("pfc::k_integ", "k_integ"),
                    ("pfc::k_fric", "k_fric")):
