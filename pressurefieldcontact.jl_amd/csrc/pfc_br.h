@@ -106,11 +106,30 @@ __global__ void __launch_bounds__(64) k_shift(ShiftArgs g) {
 // Jacobi eigen-solver for a symmetric 6x6 (stands in for LAPACK eigen!(Hermitian), friction.jl:88): rotation angle of
 // one pivot, then the wave-cooperative round-robin iteration.
 __device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq, double &cs, double &sn) {
-    // apq == 0: identity rotation
-    const double theta = (aqq - app) / (2.0 * apq);
-    double t = (theta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
-    if (apq == 0.0) t = 0.0;
-    cs = 1.0 / __builtin_sqrt(t * t + 1.0);
+    // apq == 0: identity rotation.  Reciprocals and square roots by the hardware estimates + two Newton steps each (~1e-16:
+    // a Jacobi rotation only has to be orthogonal to rounding, c^2 + s^2 = 1; the IEEE division / sqrt sequences were 2/3 of
+    // the ~250 instructions of a round).  A huge |theta| (pivot at the rounding floor) takes the limit t = 1 / (2 theta).
+    double r = __builtin_amdgcn_rcp(2.0 * apq);
+    r = r * __builtin_fma(-(2.0 * apq), r, 2.0);
+    r = r * __builtin_fma(-(2.0 * apq), r, 2.0);
+    const double theta = (aqq - app) * r;
+    const double at = __builtin_fabs(theta);
+    const double h = __builtin_fma(theta, theta, 1.0);
+    double y = __builtin_amdgcn_rsq(h);
+    y = y * __builtin_fma(-0.5 * h * y, y, 1.5);
+    y = y * __builtin_fma(-0.5 * h * y, y, 1.5);
+    const double den = at + h * y;                   // |theta| + sqrt(theta^2 + 1)
+    double q = __builtin_amdgcn_rcp(den);
+    q = q * __builtin_fma(-den, q, 2.0);
+    q = q * __builtin_fma(-den, q, 2.0);
+    double t = theta >= 0 ? q : -q;
+    if (!(at < 1.0e100)) t = 0.5 * __builtin_amdgcn_rcp(theta);      // (also NaN / inf from a vanishing pivot)
+    if (apq == 0.0 || !(__builtin_fabs(t) <= 1.0)) t = 0.0;
+    const double g = __builtin_fma(t, t, 1.0);
+    double c = __builtin_amdgcn_rsq(g);
+    c = c * __builtin_fma(-0.5 * g * c, c, 1.5);
+    c = c * __builtin_fma(-0.5 * g * c, c, 1.5);
+    cs = c;
     sn = t * cs;
 }
 // Round-robin Jacobi (5 rounds of 3 index-disjoint pivots per sweep) carried by ONE WAVE: lane e = i + 6 j (e < 36) owns

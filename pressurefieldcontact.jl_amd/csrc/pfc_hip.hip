@@ -925,6 +925,7 @@ int pfc_create(int device, pfc_handle *out) {
     if (!h) return PFC_ERR_NOMEM;
     h->device = device;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return PFC_ERR_HIP; }
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) h->n_cu = cu; }
     *out = h;
     return PFC_OK;
 }
@@ -932,7 +933,6 @@ int pfc_create(int device, pfc_handle *out) {
 void pfc_destroy(pfc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess) h->n_cu = cu; }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);   // an unchecked pfc_eval_device on the caller's stream
     if (h->twin) { pfc_destroy(h->twin); h->twin = nullptr; }
