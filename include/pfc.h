@@ -224,7 +224,7 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
  * launch sequence -- the scene sizes Radau evaluates, src/radau/radau_functions.jl:2-14,64-70; same results; 0 = always
  * batched; the debug / profile options imply the batched path), "clip_queue" (default 1: the clip-only kernel of a big
  * tri-tet launch queues the candidates that pass the trivial reject in its polygon ring and clips 64 of them at a time;
- * 0 = the lane-per-candidate clip rounds; same results bit for bit), "team" (default 32; 0 = never: an evaluation of a few
+ * 0 = the lane-per-candidate clip rounds; same results bit for bit), "team" (default 48, at most 64; 0 = never: an evaluation of a few
  * pairs too big for one workgroup -- BASELINE's single 9 680-tet x 5 120-triangle pair -- runs as ONE kernel with a team
  * of up to this many workgroups per item; same results up to the order of the sums; pfc_last_team()). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);

@@ -76,7 +76,7 @@ struct FuArgs {
     int *team_ctr;
 };
 constexpr int kTeamSlots = 32;           // doubles a workgroup publishes per phase (27 patch-stiffness moments are the most)
-constexpr int kTeamMaxWg = 32;           // workgroups per item at most
+constexpr int kTeamMaxWg = 64;           // workgroups per item at most
 constexpr int kTeamMaxBlocks = 256;      // item * nw + rank < this (one workgroup per CU: every workgroup of a launch is resident)
 constexpr int kTeamSeeds = 16;           // the descent is shared out once a level holds this many pairs per workgroup ...
 constexpr int kTeamShareMax = 768;       // ... or this many in all: its children (four per pair at most) still fit the stack above it

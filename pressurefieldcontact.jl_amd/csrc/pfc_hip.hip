@@ -298,7 +298,7 @@ struct pfc_context {
     int fu_nw = 1;                     // workgroups per item of the next fused launch (teams: k_fused<.., true>)
     int last_fu_nw = 0, last_team = 0; // of the last fused launch / of the last checked evaluation (pfc_last_team)
     int n_cu = 0;                      // compute units of the device (a team launch keeps every workgroup resident: one per CU)
-    int opt_team = kTeamMaxWg;         // option "team": big pairs (more leaves than one workgroup takes) run as teams of up to this many workgroups (0: batched path)
+    int opt_team = 48;                 // option "team": big pairs (more leaves than one workgroup takes) run as teams of up to this many workgroups (0: batched path; <= kTeamMaxWg = 64).  Eight single C3 poses, mean / worst us: 64: 113 / 122, 48: 112 / 118, 32: 113 / 122, 24: 126 / 190, 16: 178 / 249, batched 132 / 136 (scripts/lat_c3_poses.py)
     DevBuf<double> team;               // team partial sums (kTeamMaxBlocks x 3 x kTeamSlots)
     DevBuf<int> team_ctr;              // arrival counters (kFusedMaxItems x 3), zeroed once, only ever growing
     DevBuf<int> emit_ctr;              // pair counter of the fused kernel's hand-over to the batched Dual passes

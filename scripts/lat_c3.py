@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pfc_pkg
 pfc = pfc_pkg.load()
 w = pfc.configs.c3_blob_tool(1)
-for team in (32, 16, 8, 0):
+for team in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "64,48,32,16,8,0".split(","))]:
     m = pfc.configs.build_scenario(w)
     m.set_option("team", team)
     for _ in range(20): m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)

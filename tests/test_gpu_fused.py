@@ -262,7 +262,7 @@ def test_team_of_workgroups_for_big_pairs(pfc, n_poses, model):
     if model == "regularized":
         w.instructions[0].model = "regularized"
     m, (wrench, sdot, counts) = _run(pfc, w)
-    assert m.last_parts() == 0 and m.last_team() == min(32, 256 // n_poses), "the team kernel did not run"
+    assert m.last_parts() == 0 and m.last_team() == min(48, 256 // n_poses), "the team kernel did not run"
     _against_oracle(pfc, w, wrench, sdot, counts)
     st = m.stats()
     assert st["candidates"] == int(counts[:, 1].sum()) and st["node_tests"] == int(counts[:, 0].sum())
