@@ -69,11 +69,9 @@ struct FuArgs {
     int emit_cap;
     unsigned long long *stamps;   // diagnostic builds (-DPFC_STAMPS): block 0 leaves wall-clock stamps (10 ns ticks) of its phases
     // Teams (k_fused<.., true>, round 3): nw workgroups per item -- blockIdx.x = item * nw + rank.  team: per (workgroup,
-    // phase) kTeamSlots doubles of partial sums, written and read with agent-scope (sc1) accesses; team_ctr: per (item,
-    // phase) an arrival counter that only ever grows (nw adds per launch: no zeroing between evaluations).
+    // phase) 2 kTeamSlots 8-byte granules {32 data bits, 32-bit tag = seq} of partial sums (team_sum).
     int nw;
-    double *team;
-    int *team_ctr;
+    unsigned long long *team;
 };
 constexpr int kTeamSlots = 32;           // doubles a workgroup publishes per phase (27 patch-stiffness moments are the most)
 constexpr int kTeamMaxWg = 64;           // workgroups per item at most
@@ -137,37 +135,65 @@ union FuScratch {
 // Team sum of n <= kTeamSlots values, one per thread tid < n (`mine`); returns the team's total of slot tid to thread tid,
 // summed in rank order by every workgroup alike (all workgroups of a team continue with bit-identical totals).  Slot
 // or_slot is combined by bitwise OR of its integer value instead (status words).
-// Visibility across CUs / XCDs (MI355X guide, "Workgroup dispatch, XCD placement & inter-workgroup visibility", the
-// hand-off form with sc1 stores, one agent-scope atomic add per storing workgroup behind every storing wave's
-// s_waitcnt vmcnt(0) and a workgroup barrier, an sc1 poll of the counter by one lane, a workgroup barrier, sc1 loads): the
-// partials never sit in an L1 / L2 another workgroup could read stale.  The counter of (item, phase) only grows: a launch
-// adds exactly nw to it, so the arrival that returns `old` belongs to the launch whose adds end at (old / nw + 1) nw.
+// The exchange is made of self-validating 8-byte GRANULES (MI355X guide, "Persistent kernels: synchronisation and hand-off
+// price list", handoff-1to1 / R2): a double leaves as two granules {32 bits of data, 32-bit tag = the launch's sequence
+// number}, each written by ONE sc1 (agent-scope, write-through) 8-byte store and polled with sc1 8-byte loads until its tag
+// is this launch's.  No flag, no counter, no fence, nothing to zero between evaluations (the sequence number never
+// repeats within 2^32 launches; the buffer starts zeroed and sequence numbers start at 1): one store and one load round
+// trip per team sum.  A first version -- sc1 partials, a returning atomic add on an arrival counter, a poll of the counter,
+// then the loads -- cost 6-7 us per team sum; this one 3-4.
 __device__ __forceinline__ double team_sum(const FuArgs &g, int item, int nw, int phase, int n, double mine, int or_slot, int tid,
                                            double *s_team, int *s_flag, unsigned &status) {
-    double *my = g.team + ((size_t)blockIdx.x * 3 + phase) * kTeamSlots;
-    if (tid < n) __hip_atomic_store(my + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tag = (unsigned long long)(unsigned)g.seq << 32;
+    unsigned long long *my = g.team + ((size_t)blockIdx.x * 3 + phase) * (2 * kTeamSlots);
+    if (tid < n) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+        __hip_atomic_store(my + 2 * tid, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(my + 2 * tid + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) *s_flag = 0;
     __syncthreads();
-    if (tid == 0) {
-        int *ctr = g.team_ctr + 3 * item + phase;
-        const unsigned old = (unsigned)atomicAdd(ctr, 1);
-        const unsigned target = (old / (unsigned)nw + 1u) * (unsigned)nw;
-        int spins = 0;
-        while ((int)((unsigned)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 && spins < kTeamSpinMax) {
-            __builtin_amdgcn_s_sleep(1);
-            ++spins;
+    // thread -> (rank w2, slot t): every granule of a thread is requested before the first is looked at
+    const unsigned long long *base = g.team + ((size_t)(item * nw) * 3 + phase) * (2 * kTeamSlots);
+    constexpr int kPer = kTeamMaxWg * kTeamSlots / kFuBlock;
+    unsigned long long lo[kPer], hi[kPer];
+    bool need[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int idx = tid + k * kFuBlock, w2 = idx / kTeamSlots, t = idx % kTeamSlots;
+        need[k] = w2 < nw && t < n;
+        lo[k] = hi[k] = 0ull;
+    }
+    bool pending = true;
+    for (int spins = 0; pending && spins < kTeamSpinMax; ++spins) {
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int idx = tid + k * kFuBlock, w2 = idx / kTeamSlots, t = idx % kTeamSlots;
+            if (need[k]) {
+                const unsigned long long *q = base + (size_t)w2 * 3 * (2 * kTeamSlots) + 2 * t;
+                lo[k] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi[k] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        *s_flag = spins >= kTeamSpinMax ? 1 : 0;
+        pending = false;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            if (need[k]) {
+                if ((lo[k] >> 32 << 32) == tag && (hi[k] >> 32 << 32) == tag) need[k] = false;
+                else pending = true;
+            }
+        }
+        if (pending) __builtin_amdgcn_s_sleep(1);
+    }
+    if (pending) *s_flag = 1;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int idx = tid + k * kFuBlock;
+        if (idx < nw * kTeamSlots)
+            s_team[idx] = __longlong_as_double((long long)(((hi[k] & 0xFFFFFFFFull) << 32) | (lo[k] & 0xFFFFFFFFull)));
     }
     __syncthreads();
     if (*s_flag) status |= kStFusedOvf;    // a team-mate never arrived: the host re-issues on the batched path (uniform over the workgroup)
-    // every workgroup's n values -> LDS (independent loads: one round trip), then the sum in rank order
-    const double *base = g.team + ((size_t)(item * nw) * 3 + phase) * kTeamSlots;
-    for (int idx = tid; idx < nw * kTeamSlots; idx += kFuBlock) {
-        const int w2 = idx / kTeamSlots, t = idx % kTeamSlots;
-        if (t < n) s_team[idx] = __hip_atomic_load(base + (size_t)w2 * 3 * kTeamSlots + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
     double acc = 0.0;
     if (tid < n) {
         for (int w2 = 0; w2 < nw; ++w2) {

@@ -299,8 +299,7 @@ struct pfc_context {
     int last_fu_nw = 0, last_team = 0; // of the last fused launch / of the last checked evaluation (pfc_last_team)
     int n_cu = 0;                      // compute units of the device (a team launch keeps every workgroup resident: one per CU)
     int opt_team = 48;                 // option "team": big pairs (more leaves than one workgroup takes) run as teams of up to this many workgroups (0: batched path; <= kTeamMaxWg = 64).  Eight single C3 poses, mean / worst us: 64: 113 / 122, 48: 112 / 118, 32: 113 / 122, 24: 126 / 190, 16: 178 / 249, batched 132 / 136 (scripts/lat_c3_poses.py)
-    DevBuf<double> team;               // team partial sums (kTeamMaxBlocks x 3 x kTeamSlots)
-    DevBuf<int> team_ctr;              // arrival counters (kFusedMaxItems x 3), zeroed once, only ever growing
+    DevBuf<unsigned long long> team;   // team partial sums: kTeamMaxBlocks x 3 x 2 kTeamSlots granules, zeroed once (tags are launch sequence numbers >= 1)
     DevBuf<int> emit_ctr;              // pair counter of the fused kernel's hand-over to the batched Dual passes
     int *h_emit = nullptr;             // pinned mirror
     unsigned *h_more = nullptr;        // pinned: status word of the Dual passes of pfc_eval_dual_device_more (device word: status.p + 1)
@@ -796,15 +795,14 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
     HIP_TRY(h, h->stamps.ensure(16));
     a.stamps = h->stamps.p;
 #endif
-    a.nw = h->fu_nw; a.team = nullptr; a.team_ctr = nullptr;
+    a.nw = h->fu_nw; a.team = nullptr;
     h->last_fu_nw = a.nw;
     if (a.nw > 1) {
         if (!h->team.p) {
-            HIP_TRY(h, h->team.ensure((size_t)kTeamMaxBlocks * 3 * kTeamSlots));
-            HIP_TRY(h, h->team_ctr.ensure((size_t)kFusedMaxItems * 3));
-            HIP_TRY(h, hipMemsetAsync(h->team_ctr.p, 0, sizeof(int) * h->team_ctr.cap, st));
+            HIP_TRY(h, h->team.ensure((size_t)kTeamMaxBlocks * 3 * 2 * kTeamSlots));
+            HIP_TRY(h, hipMemsetAsync(h->team.p, 0, sizeof(unsigned long long) * h->team.cap, st));
         }
-        a.team = h->team.p; a.team_ctr = h->team_ctr.p;
+        a.team = h->team.p;
         if (h->any_tet_tet) hipLaunchKernelGGL((k_fused<true, true>), dim3(n_items * a.nw), dim3(kFuBlock), 0, st, a);
         else hipLaunchKernelGGL((k_fused<false, true>), dim3(n_items * a.nw), dim3(kFuBlock), 0, st, a);
     } else
@@ -953,7 +951,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->h_emit) (void)hipHostFree(h->h_emit);
     if (h->h_more) (void)hipHostFree(h->h_more);
     h->emit_ctr.release();
-    h->fout.release();
+    h->fout.release(); h->team.release();
     h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
     h->clip_n.release(); h->icnt.release(); h->trac_item.release(); h->acc.release(); h->res.release();
     h->trac_d.release(); h->rec.release(); h->ctr.release(); h->status.release(); h->stamps.release();
