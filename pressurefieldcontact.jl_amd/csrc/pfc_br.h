@@ -23,6 +23,53 @@ struct BrArgs {
     int *counts;
 };
 
+// Parallel-axis shift of the 27 patch-stiffness moments (Snn 6, San 9, Saa 6, Srr 6: the kAccSnn.. layout) of a set of
+// traction points from a reference point c to c - d (d = c - target), given W = sum w and m1 = sum w (r - c):
+//   Snn' = Snn            San' = San + [d]x Snn            Srr' = Srr + m1 d' + d m1' + W d d'
+//   Saa' = Saa + San [d]x' + [d]x San' + [d]x Snn [d]x'
+// Every shift distance in this library is of the order of the patch size (reference points lie inside the patch), so
+// nothing cancels.  Used by k_shift (records of the batched narrowphase) and by the one-launch kernel (pfc_fused.h).
+__device__ __forceinline__ void shift_moments(const double *m, double W, const double *m1, const double *d, double *o) {
+    const int s6[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    double Snn[9], San[9], Saa[9], Srr[9];
+    const double dx[9] = {0.0, d[2], -d[1], -d[2], 0.0, d[0], d[1], -d[0], 0.0};   // [d]x column-major
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        Snn[k] = m[s6[k]]; San[k] = m[6 + k]; Saa[k] = m[15 + s6[k]]; Srr[k] = m[21 + s6[k]];
+    }
+    double dS[9], Sd[9], dSd[9];   // [d]x Snn,  San [d]x',  [d]x Snn [d]x'
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+            double x = 0.0, y = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { x += dx[ii + 3 * k] * Snn[k + 3 * j]; y += San[ii + 3 * k] * dx[j + 3 * k]; }
+            dS[ii + 3 * j] = x; Sd[ii + 3 * j] = y;
+        }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+            double x = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x += dS[ii + 3 * k] * dx[j + 3 * k];
+            dSd[ii + 3 * j] = x;
+        }
+    const int u6[6] = {0, 3, 6, 4, 7, 8};   // xx xy xz yy yz zz in a column-major 3x3
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = Snn[u6[k]];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[6 + k] = San[k] + dS[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int ii = u6[k] % 3, j = u6[k] / 3;
+        o[15 + k] = Saa[u6[k]] + Sd[ii + 3 * j] + Sd[j + 3 * ii] + dSd[u6[k]];
+        // sum w (x + d)(x + d)' = Srr + m1 d' + d m1' + W d d'  (m1 = sum w x about the reference point)
+        o[21 + k] = Srr[u6[k]] + (m1[ii] * d[j] + d[ii] * m1[j]) + W * d[ii] * d[j];
+    }
+}
+
 // Moves every moment record from its run centroid c_w to the item's cop and adds it to the item accumulators.
 // With d = c_w - cop and sum w (r - c_w) = 0 by construction of c_w:
 //   Snn' = Snn            San' = San + [d]x Snn            Srr' = Srr + W d d'
@@ -51,45 +98,8 @@ __global__ void __launch_bounds__(64) k_shift(ShiftArgs g) {
             const double *a = g.acc + (size_t)item * kAccStride;
             const double S = a[kAccIp];
             const double d[3] = {r[2] - a[kAccIpc] / S, r[3] - a[kAccIpc + 1] / S, r[4] - a[kAccIpc + 2] / S};
-            const int s6[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
-            double Snn[9], San[9], Saa[9], Srr[9];
-            const double dx[9] = {0.0, d[2], -d[1], -d[2], 0.0, d[0], d[1], -d[0], 0.0};   // [d]x column-major
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                Snn[k] = r[5 + s6[k]]; San[k] = r[11 + k]; Saa[k] = r[20 + s6[k]]; Srr[k] = r[26 + s6[k]];
-            }
-            double dS[9], Sd[9], dSd[9];   // [d]x Snn,  San [d]x',  [d]x Snn [d]x'
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int ii = 0; ii < 3; ++ii) {
-                    double x = 0.0, y = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { x += dx[ii + 3 * k] * Snn[k + 3 * j]; y += San[ii + 3 * k] * dx[j + 3 * k]; }
-                    dS[ii + 3 * j] = x; Sd[ii + 3 * j] = y;
-                }
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int ii = 0; ii < 3; ++ii) {
-                    double x = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) x += dS[ii + 3 * k] * dx[j + 3 * k];
-                    dSd[ii + 3 * j] = x;
-                }
-            double *o = out + lane * 28;
-            const int u6[6] = {0, 3, 6, 4, 7, 8};   // xx xy xz yy yz zz in a column-major 3x3
-#pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = Snn[u6[k]];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) o[6 + k] = San[k] + dS[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int ii = u6[k] % 3, j = u6[k] / 3;
-                o[15 + k] = Saa[u6[k]] + Sd[ii + 3 * j] + Sd[j + 3 * ii] + dSd[u6[k]];
-                // sum w (x + d)(x + d)' = Srr + m1 d' + d m1' + W d d'  (m1 = sum w x about the record's reference point)
-                o[21 + k] = Srr[u6[k]] + (r[32 + ii] * d[j] + d[ii] * r[32 + j]) + W * d[ii] * d[j];
-            }
+            const double m1[3] = {r[32], r[33], r[34]};
+            shift_moments(r + 5, W, m1, d, out + lane * 28);
             items[lane] = item;
         }
         __syncthreads();

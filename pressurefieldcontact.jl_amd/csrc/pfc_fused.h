@@ -73,8 +73,8 @@ struct FuArgs {
     int nw;
     unsigned long long *team;
 };
-constexpr int kTeamSlots = 32;           // doubles a workgroup publishes per phase (27 patch-stiffness moments are the most)
-constexpr int kTeamMaxWg = 64;           // workgroups per item at most
+constexpr int kTeamSlots = 48;           // doubles a workgroup publishes per phase (first phase: 10 sums, 4 counters, status, 27 moments, their reference point)
+constexpr int kTeamMaxWg = 48;           // workgroups per item at most
 constexpr int kTeamMaxBlocks = 256;      // item * nw + rank < this (one workgroup per CU: every workgroup of a launch is resident)
 constexpr int kTeamSeeds = 16;           // the descent is shared out once a level holds this many pairs per workgroup ...
 constexpr int kTeamShareMax = 768;       // ... or this many in all: its children (four per pair at most) still fit the stack above it
@@ -142,8 +142,8 @@ union FuScratch {
 // repeats within 2^32 launches; the buffer starts zeroed and sequence numbers start at 1): one store and one load round
 // trip per team sum.  A first version -- sc1 partials, a returning atomic add on an arrival counter, a poll of the counter,
 // then the loads -- cost 6-7 us per team sum; this one 3-4.
-__device__ __forceinline__ double team_sum(const FuArgs &g, int item, int nw, int phase, int n, double mine, int or_slot, int tid,
-                                           double *s_team, int *s_flag, unsigned &status) {
+__device__ __forceinline__ void team_gather(const FuArgs &g, int item, int nw, int phase, int n, double mine, int tid,
+                                            double *s_team, int *s_flag, unsigned &status) {
     const unsigned long long tag = (unsigned long long)(unsigned)g.seq << 32;
     unsigned long long *my = g.team + ((size_t)blockIdx.x * 3 + phase) * (2 * kTeamSlots);
     if (tid < n) {
@@ -194,6 +194,9 @@ __device__ __forceinline__ double team_sum(const FuArgs &g, int item, int nw, in
     }
     __syncthreads();
     if (*s_flag) status |= kStFusedOvf;    // a team-mate never arrived: the host re-issues on the batched path (uniform over the workgroup)
+}
+// the rank-order total of slot tid (tid < n) over the nw rows of s_team; slot or_slot by bitwise OR of its integer value
+__device__ __forceinline__ double team_total(const double *s_team, int nw, int n, int or_slot, int tid) {
     double acc = 0.0;
     if (tid < n) {
         for (int w2 = 0; w2 < nw; ++w2) {
@@ -201,6 +204,12 @@ __device__ __forceinline__ double team_sum(const FuArgs &g, int item, int nw, in
             if (tid == or_slot) acc = (double)((unsigned)acc | (unsigned)x); else acc += x;
         }
     }
+    return acc;
+}
+__device__ __forceinline__ double team_sum(const FuArgs &g, int item, int nw, int phase, int n, double mine, int or_slot, int tid,
+                                           double *s_team, int *s_flag, unsigned &status) {
+    team_gather(g, item, nw, phase, n, mine, tid, s_team, s_flag, status);
+    const double acc = team_total(s_team, nw, n, or_slot, tid);
     __syncthreads();        // s_team is free again
     return acc;
 }
@@ -235,7 +244,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     const int nw = MW ? g.nw : 1;
     const int item = MW ? (int)blockIdx.x / nw : (int)blockIdx.x;
     const int wr = MW ? (int)blockIdx.x - item * nw : 0;      // rank in the team
-    __shared__ double s_team[MW ? kTeamMaxWg * kTeamSlots : 1];
+    __shared__ double s_team[MW ? kTeamMaxWg * kTeamSlots : kTeamSlots];
     __shared__ double s_tres[kTeamSlots];
     __shared__ int s_tflag;
     unsigned status = 0;
@@ -328,9 +337,9 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         // alone.  (Shared out from the depth-first stack at 128 pairs, a single C3 pose had nearly all its work under two or
         // three of them: 270 us, slower than the batched path.)
         bool bfs = MW;
-        int hi = MW ? 1 : 0, hi0 = hi;
+        int lo = 0, hi = MW ? 1 : 0, hi0 = hi;      // the level: stk[lo, hi); its children from hi0 on
         const int t_share = nw * kTeamSeeds < kTeamShareMax ? nw * kTeamSeeds : kTeamShareMax;
-        for (int guard = 0; (bfs ? hi > 0 : sp > 0) && guard < (1 << 22); ++guard) {
+        for (int guard = 0; (bfs ? hi > lo : sp > 0) && guard < (1 << 22); ++guard) {
             unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0; (void)u0; (void)u1; (void)u2; (void)u3; (void)u4;
             STAMP(u0);
             // Lookahead.  An iteration costs ~4 000 cycles whatever the number of busy lanes (one Float64 test per lane, a
@@ -340,7 +349,8 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             // result counts only if every ancestor pair it descends from overlaps (the reference tests a pair iff its
             // parent pair intersects, tree_types.jl:88-111), so node tests and candidates are the reference's.
             const int room = kFuStack - reserve - sp;
-            const int avail = bfs ? hi : sp;      // pairs that may be popped now
+            const int avail = bfs ? hi - lo : sp;      // pairs that may be popped now
+            const int top = bfs ? hi : sp;            // ... from here downwards
             int LA = 1, p;
             if (avail <= 8 && room >= 64 * avail) { LA = 3; p = avail; }
             else if (avail <= 32 && room >= 16 * avail) { LA = 2; p = avail; }
@@ -358,7 +368,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             else if (LA == 3 && r >= 5 && r <= 20) { lvl = 2; c1 = (r - 5) >> 2; c2 = (r - 5) & 3; }
             else if (r >= 5) act = false;
             int2 e = make_int2(0, 0);
-            if (act) e = B.stk[avail - 1 - grp];
+            if (act) e = B.stk[top - 1 - grp];
             // walk down to the lane's own pair: child order (1.1,2.1) (1.2,2.1) (1.1,2.2) (1.2,2.2) (:104-107), or the two
             // children of the internal node when the other one is a leaf (:97-103)
 #define FU_LINKS(LDSARR, FULL, NC, GLOB, IDX) ((IDX) < (NC) ? LDSARR[((FULL) ? (IDX) * 9 : (IDX) * 4) + 3] : ((const gvec4i *)((GLOB) + (IDX)))[3])
@@ -469,11 +479,14 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             }
             n_cand += c_tot;
             sp += p_tot;
-            if (n_cand > kFuCand) { ovf = true; sp = 0; hi = 0; bfs = false; }    // uniform: the item leaves for the batched path
+            if (n_cand > kFuCand) { ovf = true; sp = 0; hi = 0; lo = 0; bfs = false; }    // uniform: the item leaves for the batched path
             __syncthreads();
-            if (MW && bfs && hi == 0) {
-                // the level is used up: its children stk[hi0, sp) become the next level -- or, if there are enough of them
-                // (or their children might not fit above them), this rank's share of the depth-first descent
+            if (MW && bfs && hi == lo && sp - hi0 < t_share && sp <= kFuStack / 2) {
+                // the level is used up and the next one, stk[hi0, sp), is small: it stays where it is (no copy, no barrier)
+                lo = hi0; hi = sp; hi0 = sp;
+            } else if (MW && bfs && hi == lo) {
+                // the level is used up: its children stk[hi0, sp) move down and become the next level -- or, if there are
+                // enough of them, this rank's share of the depth-first descent
                 const int n_next = sp - hi0;
                 const bool share = n_next >= t_share;
                 int2 keep[kFuStack / kFuBlock];
@@ -493,7 +506,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                     if (wr != 0) { n_cand = 0; n_test = 0; }      // what has been counted and found so far stays with rank 0
                     bfs = false;
                 } else {
-                    sp = n_next; hi = n_next; hi0 = n_next;
+                    sp = n_next; lo = 0; hi = n_next; hi0 = n_next;
                 }
                 __syncthreads();
             }
@@ -590,13 +603,19 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     V3 cop = mk3(0.0, 0.0, 0.0), ts_c0 = cop, ts_e = cop;
     const V3 w = mk3(I.twist[0], I.twist[1], I.twist[2]), vl = mk3(I.twist[3], I.twist[4], I.twist[5]);
     const double chi = I.ins.chi, Ebar = I.ins.Ebar, v_c = I.ins.v_c, mu_s = I.ins.mu_s, mu_d = I.ins.mu_d;
-    const int n_pass = reg ? 1 : 3;
-    bool contact = false;
-    for (int pass = 0; pass < n_pass; ++pass) {
-        if (pass > 0 && !contact) break;          // uniform
-        double acc[27];
+    // Bristle items take TWO integration passes (round 3; three before): pass 0 sums, next to the normal wrench and the cop
+    // sums, the 27 patch-stiffness moments (calc_patch_spatial_stiffness!, friction.jl:147-169) about a reference point c0
+    // inside the patch -- the centroid of the first polygon this workgroup integrates -- and the parallel-axis terms
+    // (shift_moments, pfc_br.h: what k_shift does for the batched path) move them to the cop once it is known; pass 2 is the
+    // friction pass.  (The reference's own second pass over the TractionCache, x = r - cop, cost an integration pass, a
+    // block reduction and, for a team, a team sum.)
+    bool contact = false, have_c0 = false;
+    V3 c0 = mk3(0.0, 0.0, 0.0);
+    for (int pass = 0; pass < 3; pass += 2) {
+        if (pass > 0 && (reg || !contact)) break;          // uniform
+        double acc[37];
 #pragma unroll
-        for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+        for (int k = 0; k < 37; ++k) acc[k] = 0.0;
         int my_ne = 0, my_nt = 0;
         for (int rd = 0; rd < n_round; ++rd) {
             // ---- clip (only once if a single round holds every candidate) -------------------------------------------
@@ -818,6 +837,11 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             }
             if (pass == 0 && rd == 0) FSTAMP(4);
             const int n_fan = ((s_scan[0] + s_scan[1]) + s_scan[2]) + s_scan[3];
+            if (!have_c0 && n_fan > 0) {       // uniform: the reference point of this workgroup's moments
+                const int pt0 = (int)(fan[0] & 0xFFFFu);
+                c0 = mk3(FX(pt0, 3), FX(pt0, 4), FX(pt0, 5));
+                have_c0 = true;
+            }
             // ---- integrate_over_polygon_patch! (non_friction.jl:217-265): one fan triangle per thread ------------------
             for (int wi = tid; wi < n_fan; wi += kFuBlock) {
                 const unsigned fe = fan[wi];
@@ -857,20 +881,17 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                             acc[0] += ta.x; acc[1] += ta.y; acc[2] += ta.z;
                             acc[3] += tk.x; acc[4] += tk.y; acc[5] += tk.z;
                         } else {
-                            // normal_wrench_cop (normal.jl:17-34): n̂ is constant over the polygon
+                            // normal_wrench_cop (normal.jl:17-34) and the moments of calc_patch_spatial_stiffness!
+                            // (friction.jl:147-169) about the polygon's own centroid: W, sum w x, sum w x x' with x = r - cen;
+                            // n̂ is constant over the polygon
                             const V3 rc = r - cen;
+                            const double wx = p_dA * rc.x, wy = p_dA * rc.y, wz = p_dA * rc.z;
                             tW += p_dA;
-                            tm[0] += p_dA * rc.x; tm[1] += p_dA * rc.y; tm[2] += p_dA * rc.z;
+                            tm[0] += wx; tm[1] += wy; tm[2] += wz;
+                            tq[0] = __builtin_fma(wx, rc.x, tq[0]); tq[1] = __builtin_fma(wx, rc.y, tq[1]);
+                            tq[2] = __builtin_fma(wx, rc.z, tq[2]); tq[3] = __builtin_fma(wy, rc.y, tq[3]);
+                            tq[4] = __builtin_fma(wy, rc.z, tq[4]); tq[5] = __builtin_fma(wz, rc.z, tq[5]);
                         }
-                    } else if (pass == 1) {
-                        // calc_patch_spatial_stiffness! (friction.jl:147-169): W, sum w x, sum w x x' with x = r - cop
-                        const V3 x = r - cop;
-                        const double wx = p_dA * x.x, wy = p_dA * x.y, wz = p_dA * x.z;
-                        tW += p_dA;
-                        tm[0] += wx; tm[1] += wy; tm[2] += wz;
-                        tq[0] = __builtin_fma(wx, x.x, tq[0]); tq[1] = __builtin_fma(wx, x.y, tq[1]);
-                        tq[2] = __builtin_fma(wx, x.z, tq[2]); tq[3] = __builtin_fma(wy, x.y, tq[3]);
-                        tq[4] = __builtin_fma(wy, x.z, tq[4]); tq[5] = __builtin_fma(wz, x.z, tq[5]);
                     } else {
                         // calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48), as in k_fric
                         const V3 x = r - cop;
@@ -904,22 +925,32 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                     acc[0] += ta.x; acc[1] += ta.y; acc[2] += ta.z;
                     acc[3] += nh.x * tW; acc[4] += nh.y * tW; acc[5] += nh.z * tW;
                     acc[6] += tW; acc[7] += Sr.x; acc[8] += Sr.y; acc[9] += Sr.z;
-                } else if (pass == 1) {
+                    // the triangle's moments about the workgroup's reference point c0: x' = x + d, d = cen - c0 (within the patch)
+                    const V3 d = cen - c0;
+                    const V3 m1 = mk3(tm[0] + tW * d.x, tm[1] + tW * d.y, tm[2] + tW * d.z);
+                    double q[6];
+                    q[0] = tq[0] + 2.0 * tm[0] * d.x + tW * d.x * d.x;
+                    q[1] = tq[1] + tm[0] * d.y + tm[1] * d.x + tW * d.x * d.y;
+                    q[2] = tq[2] + tm[0] * d.z + tm[2] * d.x + tW * d.x * d.z;
+                    q[3] = tq[3] + 2.0 * tm[1] * d.y + tW * d.y * d.y;
+                    q[4] = tq[4] + tm[1] * d.z + tm[2] * d.y + tW * d.y * d.z;
+                    q[5] = tq[5] + 2.0 * tm[2] * d.z + tW * d.z * d.z;
                     // n̂ is constant over the polygon: sum w n n' = W n n', sum w (x x n) n' = (m1 x n) n',
-                    // sum w (x x n)(x x n)' = [n]x Q [n]x'   (acc: Snn 6, San 9, Saa 6, Srr 6 -- the kAccSnn.. layout)
-                    acc[0] += tW * nh.x * nh.x; acc[1] += tW * nh.x * nh.y; acc[2] += tW * nh.x * nh.z;
-                    acc[3] += tW * nh.y * nh.y; acc[4] += tW * nh.y * nh.z; acc[5] += tW * nh.z * nh.z;
-                    const V3 an = cross(mk3(tm[0], tm[1], tm[2]), nh);
-                    acc[6] += an.x * nh.x; acc[7] += an.y * nh.x; acc[8] += an.z * nh.x;
-                    acc[9] += an.x * nh.y; acc[10] += an.y * nh.y; acc[11] += an.z * nh.y;
-                    acc[12] += an.x * nh.z; acc[13] += an.y * nh.z; acc[14] += an.z * nh.z;
-                    const V3 c0 = mk3(tq[0], tq[1], tq[2]), c1 = mk3(tq[1], tq[3], tq[4]), c2 = mk3(tq[2], tq[4], tq[5]);
-                    const V3 m0 = cross(nh, c0), m1c = cross(nh, c1), m2c = cross(nh, c2);       // M = [n]x Q
+                    // sum w (x x n)(x x n)' = [n]x Q [n]x'   (acc[10 ..]: Snn 6, San 9, Saa 6, Srr 6 -- the kAccSnn.. layout)
+                    double *am = acc + 10;
+                    am[0] += tW * nh.x * nh.x; am[1] += tW * nh.x * nh.y; am[2] += tW * nh.x * nh.z;
+                    am[3] += tW * nh.y * nh.y; am[4] += tW * nh.y * nh.z; am[5] += tW * nh.z * nh.z;
+                    const V3 an = cross(m1, nh);
+                    am[6] += an.x * nh.x; am[7] += an.y * nh.x; am[8] += an.z * nh.x;
+                    am[9] += an.x * nh.y; am[10] += an.y * nh.y; am[11] += an.z * nh.y;
+                    am[12] += an.x * nh.z; am[13] += an.y * nh.z; am[14] += an.z * nh.z;
+                    const V3 q0 = mk3(q[0], q[1], q[2]), q1 = mk3(q[1], q[3], q[4]), q2 = mk3(q[2], q[4], q[5]);
+                    const V3 m0 = cross(nh, q0), m1c = cross(nh, q1), m2c = cross(nh, q2);       // M = [n]x Q
                     const V3 r0 = cross(nh, mk3(m0.x, m1c.x, m2c.x)), r1 = cross(nh, mk3(m0.y, m1c.y, m2c.y));
                     const V3 r2 = cross(nh, mk3(m0.z, m1c.z, m2c.z));
-                    acc[15] += r0.x; acc[16] += r0.y; acc[17] += r0.z; acc[18] += r1.y; acc[19] += r1.z; acc[20] += r2.z;
+                    am[15] += r0.x; am[16] += r0.y; am[17] += r0.z; am[18] += r1.y; am[19] += r1.z; am[20] += r2.z;
 #pragma unroll
-                    for (int kk = 0; kk < 6; ++kk) acc[21 + kk] += tq[kk];
+                    for (int kk = 0; kk < 6; ++kk) am[21 + kk] += q[kk];
                 }
             }
         }
@@ -934,53 +965,84 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             __syncthreads();
             n_nonempty = ((s_cnt[0][0] + s_cnt[1][0]) + s_cnt[2][0]) + s_cnt[3][0];
             n_trac = ((s_cnt[0][1] + s_cnt[1][1]) + s_cnt[2][1]) + s_cnt[3][1];
-            if (MW) {
-                // team totals: the ten sums, the four counters, the status word
-                double mine = 0.0;
-                if (tid < 10) mine = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
-                else if (tid == 10) mine = (double)n_test;
-                else if (tid == 11) mine = (double)n_cand;
-                else if (tid == 12) mine = (double)n_nonempty;
-                else if (tid == 13) mine = (double)n_trac;
-                else if (tid == 14) mine = (double)status;
-                const double tot = team_sum(g, item, nw, 0, 15, mine, 14, tid, s_team, &s_tflag, status);
-                if (tid < 15) s_tres[tid] = tot;
-                __syncthreads();
-#pragma unroll
-                for (int k = 0; k < 10; ++k) tot10[k] = s_tres[k];
-                n_test = (int)s_tres[10]; n_cand = (int)s_tres[11]; n_nonempty = (int)s_tres[12]; n_trac = (int)s_tres[13];
-                status |= (unsigned)s_tres[14];
-                __syncthreads();
-                FSTAMP(12);
+            // what this workgroup found, one value per thread: the ten sums [0, 10), the four counters, the status word, and for
+            // a bristle item the 27 moments about c0 [15, 42) and c0 itself [42, 45)
+            double mine = 0.0;
+            if (tid < 10) mine = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
+            else if (tid == 10) mine = (double)n_test;
+            else if (tid == 11) mine = (double)n_cand;
+            else if (tid == 12) mine = (double)n_nonempty;
+            else if (tid == 13) mine = (double)n_trac;
+            else if (tid == 14) mine = (double)status;
+            else if (tid == 42) mine = c0.x;
+            else if (tid == 43) mine = c0.y;
+            else if (tid == 44) mine = c0.z;
+            if (!reg) {
+                block_partials<27>(acc + 10, red, tid);
+                if (tid >= 15 && tid < 42) mine = ((red[tid - 15] + red[32 + tid - 15]) + red[64 + tid - 15]) + red[96 + tid - 15];
             }
+            const int n_pub = reg ? 15 : 45;
+            if (MW) {
+                team_gather(g, item, nw, 0, n_pub, mine, tid, s_team, &s_tflag, status);      // every rank's values -> s_team
+            } else {
+                __syncthreads();
+                if (tid < n_pub) s_team[tid] = mine;
+                __syncthreads();
+            }
+            {
+                const double tot = team_total(s_team, nw, 15, 14, tid);
+                if (tid < 15) s_tres[tid] = tot;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 10; ++k) tot10[k] = s_tres[k];
+            n_test = (int)s_tres[10]; n_cand = (int)s_tres[11]; n_nonempty = (int)s_tres[12]; n_trac = (int)s_tres[13];
+            status |= (unsigned)s_tres[14];
+            if (MW) FSTAMP(12);
             contact = n_trac > 0;
             if (!reg && contact) {
                 const double iS = tot10[6];
                 cop = mk3(tot10[7] / iS, tot10[8] / iS, tot10[9] / iS);      // normal.jl:33
+                // every rank's moments move from its reference point to the cop (one thread per rank, in place), then add up
+                // in rank order: the item's accumulator block in the kAcc* layout (read by eig_item)
+                if (tid < nw) {
+                    double *row = s_team + tid * kTeamSlots;
+                    const double Wr = row[6];
+                    double o27[27];
+                    if (Wr > 0.0) {
+                        const double cr[3] = {row[42], row[43], row[44]};
+                        const double m1[3] = {row[7] - Wr * cr[0], row[8] - Wr * cr[1], row[9] - Wr * cr[2]};     // sum w (r - c0)
+                        const double dd[3] = {cr[0] - cop.x, cr[1] - cop.y, cr[2] - cop.z};
+                        shift_moments(row + 15, Wr, m1, dd, o27);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 27; ++k) o27[k] = 0.0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) row[15 + k] = o27[k];
+                }
+                __syncthreads();
+                if (tid < 27) {
+                    double a27 = 0.0;
+                    for (int w2 = 0; w2 < nw; ++w2) a27 += s_team[w2 * kTeamSlots + 15 + tid];
+                    s_acc[kAccSnn + tid] = a27;
+                }
+                if (tid == 32) {
+                    s_acc[kAccIp] = tot10[6];
+                    s_acc[kAccIpc] = tot10[7]; s_acc[kAccIpc + 1] = tot10[8]; s_acc[kAccIpc + 2] = tot10[9];
+                }
+                __syncthreads();
+                if (MW) FSTAMP(13);
+                if (wave == 0) eig_item(s_acc, I.ins.k_bar, I.ins.magic, I.s, s_res, E, lane);
+                __syncthreads();
+                if (MW) FSTAMP(14);
+                // per-item constants of the friction pass (k_fric): T̄s = c0 + e x r
+                const V3 copr = ld3(s_res + kResCop), Da = ld3(s_res + kResDelta), Dl = ld3(s_res + kResDelta + 3);
+                cop = copr;
+                ts_c0 = ((Dl - cross(Da, copr)) + vl * I.ins.tau) * (-I.ins.k_bar);
+                ts_e = (Da + w * I.ins.tau) * (-I.ins.k_bar);
             }
-        } else if (pass == 1) {
-            block_partials<27>(acc, red, tid);
-            // the item's accumulator block in the kAcc* layout (read by eig_item); a register array indexed by the thread
-            // id would live in scratch, so the 27 totals are formed from the wave partials by the thread that stores them
-            if (MW) {
-                const double mine = tid < 27 ? ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid] : 0.0;
-                const double tot = team_sum(g, item, nw, 1, 27, mine, -1, tid, s_team, &s_tflag, status);
-                if (tid < 27) s_acc[kAccSnn + tid] = tot;
-                FSTAMP(13);
-            } else if (tid < 27) s_acc[kAccSnn + tid] = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
-            if (tid == 32) {
-                s_acc[kAccIp] = tot10[6];
-                s_acc[kAccIpc] = tot10[7]; s_acc[kAccIpc + 1] = tot10[8]; s_acc[kAccIpc + 2] = tot10[9];
-            }
-            __syncthreads();
-            if (wave == 0) eig_item(s_acc, I.ins.k_bar, I.ins.magic, I.s, s_res, E, lane);
-            __syncthreads();
-            if (MW) FSTAMP(14);
-            // per-item constants of the friction pass (k_fric): T̄s = c0 + e x r
-            const V3 copr = ld3(s_res + kResCop), Da = ld3(s_res + kResDelta), Dl = ld3(s_res + kResDelta + 3);
-            cop = copr;
-            ts_c0 = ((Dl - cross(Da, copr)) + vl * I.ins.tau) * (-I.ins.k_bar);
-            ts_e = (Da + w * I.ins.tau) * (-I.ins.k_bar);
+            __syncthreads();        // s_team is free again
         } else {
             block_partials<6>(acc, red, tid);
             if (MW) {
