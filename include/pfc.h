@@ -226,7 +226,10 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
  * tri-tet launch queues the candidates that pass the trivial reject in its polygon ring and clips 64 of them at a time;
  * 0 = the lane-per-candidate clip rounds; same results bit for bit), "team" (default 48, at most 64; 0 = never: an evaluation of a few
  * pairs too big for one workgroup -- BASELINE's single 9 680-tet x 5 120-triangle pair -- runs as ONE kernel with a team
- * of up to this many workgroups per item; same results up to the order of the sums; pfc_last_team()). */
+ * of up to this many workgroups per item, and a lone mid-sized item -- a 972-tet box on the ground -- with a small team (one
+ * workgroup per 256 leaves, at most 8); same results up to the order of the sums; pfc_last_team().  Team-mates wait for
+ * each other inside the launch: several handles evaluating such scenes at the same moment on one device may each get
+ * only part of a team resident; the wait is bounded (~65 ms), the evaluation is then re-issued on the batched path). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);
 
 /* Totals of the last checked evaluation: out[0..7] = {node tests, candidate pairs, non-empty pairs, traction

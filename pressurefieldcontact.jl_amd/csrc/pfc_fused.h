@@ -78,7 +78,9 @@ constexpr int kTeamMaxWg = 48;           // workgroups per item at most
 constexpr int kTeamMaxBlocks = 256;      // item * nw + rank < this (one workgroup per CU: every workgroup of a launch is resident)
 constexpr int kTeamSeeds = 16;           // the descent is shared out once a level holds this many pairs per workgroup ...
 constexpr int kTeamShareMax = 768;       // ... or this many in all: its children (four per pair at most) still fit the stack above it
-constexpr int kTeamSpinMax = 1 << 20;    // bounded wait for the team (~0.1 s): if a workgroup never arrives the item reports kStFusedOvf (batched path)
+constexpr int kTeamSpinMax = 1 << 15;    // bounded wait for the team (a poll is ~2 us: ~65 ms): if a workgroup never arrives -- teams of several handles
+                                         // launched at once can each be PARTLY resident on a full chip -- the item reports kStFusedOvf and the host re-issues
+                                         // the evaluation on the batched path (the one-launch kernel then stays off for 64 evaluations of that handle)
 
 #ifdef PFC_STAMPS
 #define FSTAMP(k)                                                                                   \
@@ -522,7 +524,10 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         }
 #endif
 #undef FU_FETCH
-        if (MW && bfs && wr != 0) { n_cand = 0; n_test = 0; }     // the descent ended before it was shared out
+        if (MW && bfs) {      // the descent ended before it was shared out: every level is used up, rank 0 has it all
+            sp = 0;
+            if (wr != 0) { n_cand = 0; n_test = 0; }
+        }
         if (ovf) status |= kStFusedOvf;
         else if (sp > 0) status |= kStAbort;
     }

@@ -746,11 +746,21 @@ bool fused_ok(const pfc_context *h, int n_items) {
 // Team size for an evaluation of a few BIG pairs (more leaves than one workgroup takes: BASELINE config 3 as written is one
 // 9 680-tet x 5 120-triangle pair): as many workgroups per item as keep every workgroup of the launch resident (one per CU),
 // at most kTeamMaxWg; 0: not a team evaluation.
+// Small scenes (fused_ok): 1 -- unless the items are few and mid-sized (a 972-tet box on the ground keeps ONE CU busy for
+// 52 us, a third of it dealing 1 100 fan triangles out to 256 threads): then a small team, one workgroup per 256 leaves of
+// the pair, at most 8 (C2 64 -> 48 us, four reduced C3 poses 106 -> 81 us; a team of 2 loses to its own team sum).
 int fused_team(const pfc_context *h, int n_items) {
-    if (!(h->opt_fused && h->opt_team && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv && !h->is_twin &&
-          h->d_insfull && h->max_leaves > kFusedMaxLeaves && n_items >= 1))
-        return 0;
     const int blocks = h->n_cu < kTeamMaxBlocks ? h->n_cu : kTeamMaxBlocks;      // (a partitioned device has fewer CUs)
+    if (fused_ok(h, n_items)) {
+        int nw = (h->max_leaves + 128) / 256;
+        if (nw > 8) nw = 8;
+        if (n_items >= 1 && nw > blocks / n_items) nw = blocks / n_items;
+        if (nw > h->opt_team) nw = h->opt_team;
+        return nw >= 4 ? nw : 1;
+    }
+    if (!(h->opt_fused && h->opt_team && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv && !h->is_twin &&
+          h->d_insfull && h->max_leaves > kFusedMaxLeaves && n_items >= 1 && n_items <= kFusedMaxItems))
+        return 0;
     int nw = blocks / n_items;
     if (nw > kTeamMaxWg) nw = kTeamMaxWg;
     if (nw > h->opt_team) nw = h->opt_team;
@@ -1247,8 +1257,6 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
     h->split_n0 = 0;
     h->pending_fused = false;
     h->dual_reuse_ok = false; h->pending_more = false;
-    if (fused_ok(h, n_items))
-        return enqueue_fused(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
     if (const int team = fused_team(h, n_items)) {
         h->fu_nw = team;
         const int rc_t = enqueue_fused(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);

@@ -35,6 +35,8 @@ def test_fused_regularized_configs(pfc, config):
          "c4": lambda: pfc.configs.c2_box_on_plane(256, montecarlo=True)}[config]()
     m, (wrench, sdot, counts) = _run(pfc, w)
     assert m.last_parts() == 0, "the fused kernel did not run"
+    # a lone mid-sized item (C2: 972 tets) takes a small team of workgroups, many items (C4) or tiny ones (C1) one each
+    assert m.last_team() == {"c1": 1, "c2": 4, "c4": 1}[config]
     _against_oracle(pfc, w, wrench, sdot, counts)
     st = m.stats()
     assert st["candidates"] == int(counts[:, 1].sum()) and st["node_tests"] == int(counts[:, 0].sum())
@@ -49,9 +51,13 @@ def test_fused_bristle(pfc, n_quad):
     w = pfc.configs.c3_blob_tool(12, n_div_blob=8, n_div_tool=6)
     w.instructions[0].n_quad_rule = n_quad
     m, (wrench, sdot, counts) = _run(pfc, w)
-    assert m.last_parts() == 0
+    assert m.last_parts() == 0 and m.last_team() == 8        # 12 items of 2 000 leaves: teams of 8
     _against_oracle(pfc, w, wrench, sdot, counts)
     assert np.count_nonzero(counts[:, 3]) >= 6
+    m.set_option("team", 0)                                   # a workgroup per item: the same integers
+    w1, s1, c1 = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert m.last_team() == 1 and np.array_equal(c1, counts)
+    np.testing.assert_allclose(w1, wrench, rtol=1e-11, atol=1e-11 * np.abs(wrench).max())
     m.close()
     # separated bodies: zero wrench, sdot = -s / tau bit for bit
     w = pfc.configs.c3_blob_tool(3, n_div_blob=6, n_div_tool=5, distance=0.25)
@@ -100,10 +106,20 @@ def test_fused_item_that_does_not_fit_falls_back(pfc):
     """More candidate pairs than the kernel's LDS list holds: the evaluation is transparently re-issued on the batched
     path (pfc_eval), the fused kernel stays off for a while and comes back."""
     w = pfc.configs.c3_blob_tool(3, n_div_blob=8, n_div_tool=6, distance=0.04)
-    m, (wrench, sdot, counts) = _run(pfc, w)
-    assert counts[:, 1].max() > 4096, counts[:, 1]
-    assert m.last_parts() == 1           # ended on the batched path
     ref = H.oracle_run(pfc, w, debug=False)
+    # with a team of workgroups per item (round 3) every workgroup holds its own share of the candidates: the scene fits
+    mt, (wrench, sdot, counts) = _run(pfc, w)
+    assert counts[:, 1].max() > 4096, counts[:, 1]
+    assert mt.last_parts() == 0 and mt.last_team() == 8
+    for k, r in enumerate(ref):
+        assert np.array_equal(counts[k], r.counts)
+        assert H.rel_err(wrench[k], r.wrench) < TOL
+    mt.close()
+    # a workgroup per item (option team = 0): the list overflows, the evaluation ends on the batched path
+    m = pfc.configs.build_scenario(w)
+    m.set_option("team", 0)
+    wrench, sdot, counts = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert m.last_parts() == 1           # ended on the batched path
     for k, r in enumerate(ref):
         assert np.array_equal(counts[k], r.counts)
         assert H.rel_err(wrench[k], r.wrench) < TOL
