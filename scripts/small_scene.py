@@ -33,9 +33,12 @@ if pfc._lib.lib().pfc_build_info() & 1:
     names = ["item load", "node cache", "broadphase", "clip round 0", "integrate", "reduce+passes", "epilogue"]
     v[7] = v[9]      # slot 7 of the stamps view carries a broadphase statistic
     print("block 0 phases (us):", ", ".join(f"{nm} {(v[k+1]-v[k])/100:.2f}" for k, nm in enumerate(names)), f"| total {(v[7]-v[0])/100:.2f} | node tests {v[8]} | shader clock {(v[11]-v[10])/max(v[7]-v[0],1)*100:.0f} MHz")
-if pfc._lib.lib().pfc_build_info() & 1 and m.last_parts() == 0 and cfg == "c3":
+if pfc._lib.lib().pfc_build_info() & 1 and m.last_parts() == 0 and m.last_team() > 1:
     # team kernel (k_fused<.., true>): slots 12..15 are rank 0's stamps behind team sum 0, team sum 1, the eigen-decomposition, team sum 2
-    print("team (rank 0, us): pass 0 end -> team sum 0 %.2f, -> pass 1 + team sum 1 %.2f, -> eigen %.2f, -> pass 2 + team sum 2 %.2f, -> end %.2f" % ((v[12]-v[5])/100, (v[13]-v[12])/100, (v[14]-v[13])/100, (v[15]-v[14])/100, (v[9]-v[15])/100))
+    if v[13] > v[12]:      # bristle: stamps behind the exchange, the shift to the cop, the eigen-decomposition, the friction pass + team sum
+        print("team of %d (rank 0, us): pass 0 end -> exchange %.2f, -> moments at the cop %.2f, -> eigen %.2f, -> friction pass + team sum %.2f, -> end %.2f" % (m.last_team(), (v[12]-v[5])/100, (v[13]-v[12])/100, (v[14]-v[13])/100, (v[15]-v[14])/100, (v[9]-v[15])/100))
+    else:
+        print("team of %d (rank 0, us): pass 0 end -> exchange %.2f" % (m.last_team(), (v[12]-v[5])/100))
 elif pfc._lib.lib().pfc_build_info() & 1:
     it = max(v[15] & 0xFFFF, 1)
     print(f"broadphase iterations {it}: cycles/iteration pop+fetch {v[12]/it:.0f}, test {v[13]/it:.0f}, ballot+barrier {v[14]/it:.0f}, push+barrier {(v[15]>>16)/it:.0f}")
