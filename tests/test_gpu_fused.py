@@ -299,3 +299,21 @@ def test_team_of_workgroups_for_big_pairs(pfc, n_poses, model):
     assert np.array_equal(c[2], counts)
     np.testing.assert_allclose(c[0], wrench, rtol=1e-10, atol=1e-10 * np.abs(wrench).max())
     m.close()
+
+
+@pytest.mark.parametrize("model", ["regularized", "bristle"])
+def test_small_teams_on_tet_tet_and_mixed_items(pfc, model):
+    """Teams of the one-launch kernel on volume-volume (tet-tet) items: compliant box on the compliant half-plane tet and two
+    compliant spheres of 1 280 tets each (k_fused<true, true>: the plane / tet polygon instead of the triangle, the
+    trivial reject behind it); items of very different size in one launch (the box items finish before they are shared
+    out: everything stays with rank 0)."""
+    w = pfc.configs.vol_vol(3, n_div=8, model=model)
+    m, (wrench, sdot, counts) = _run(pfc, w)
+    assert m.last_parts() == 0 and m.last_team() == 8
+    _against_oracle(pfc, w, wrench, sdot, counts)
+    assert np.count_nonzero(counts[:, 3]) >= 4
+    m.set_option("team", 0)
+    w1, s1, c1 = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert m.last_team() == 1 and np.array_equal(c1, counts)
+    np.testing.assert_allclose(w1, wrench, rtol=1e-10, atol=1e-10 * np.abs(wrench).max())
+    m.close()
