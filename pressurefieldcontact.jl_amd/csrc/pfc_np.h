@@ -56,6 +56,7 @@ __device__ __forceinline__ V3 axpy_fma(double a, V3 x, V3 y) {
 #ifndef PFC_EXP
 #define PFC_EXP 0
 #endif
+constexpr int kElim = PFC_EXP;  // 0 in the product: every `kElim == n` below folds away
 constexpr int kNpBlock = 64;  // one wave per block: 16 KiB of LDS polygon staging per wave
 // Candidates are dealt out in CHUNKS of consecutive list entries: one workgroup walks a chunk round by round and keeps
 // the chunk's polygons in the chunk's own slot range [ch C, ch C + C) behind a counter it holds in a register -- no
@@ -318,9 +319,7 @@ __device__ __forceinline__ bool np_front(const ItemRec *it, const WorkRec &cw, c
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0) && (n_in < 4 || z[3][i] <= 0.0);
-#if PFC_EXP == 3
-    reject |= z[0][0] > -1e300;
-#endif
+    if (kElim == 3) reject |= z[0][0] > -1e300;
     return !reject;
 }
 
@@ -438,9 +437,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             rbase = ring.rbase;
             if (err) atomicOr(g.status, kStNonFinite);
             n_poly = n;
-#if PFC_EXP == 4
-            if (nh_in.x > -1e300) n_poly = 0;
-#endif
+            if (kElim == 4 && nh_in.x > -1e300) n_poly = 0;
             if (n >= 3) nh = nh_in;
         };
         // ==== phase 1 (divergent): gather, transform to tet coordinates, clip ========================================
@@ -543,11 +540,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         wr1[0] = wr1[1] = wr1[2] = 0.0;
         V3 cen = mk3(0.0, 0.0, 0.0);
         int n_trac_lane = 0;
-#if PFC_EXP == 9
-        if (n_poly >= 3 && nh.x > 1e300) {
-#else
-        if (n_poly >= 3) {
-#endif
+        if (n_poly >= 3 && !(kElim == 9 && !(nh.x > 1e300))) {
             const int n = n_poly;
             // poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98), converted in place (x, y, z), fused with
             // centroid(poly_r2, n̂2) (poly_eight.jl:35-52): vertex k is converted when the centroid fan first needs it
@@ -589,9 +582,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
             for (int k = 0; k < n; ++k) {
                 V3 v1 = v2;
                 v2 = mk3(PR(k, 0), PR(k, 1), PR(k, 2));
-#if PFC_EXP == 7
-                if (nh.x > -1e300) continue;
-#endif
+                if (kElim == 7 && nh.x > -1e300) continue;
                 // fillTractionCacheForTriangle! / InnerLoop! (:236-265): the shared statement of r, p, dA (pfc_kernels.h)
                 n_trac_lane += fan_triangle_points(pp, v1, v2, cen, nh, [&](const V3 &r, const V3 &rdot, double p, double dA) {
                     const double p_dA = p * dA;
@@ -653,11 +644,7 @@ __global__ void __launch_bounds__(kNpBlock) k_narrow(NpArgs g) {
         }
         STAMP(t4);
         // ==== phase 4 (wave-uniform): per-item reductions =============================================================
-#if PFC_EXP == 5
-        const bool contributed = work && n_trac_lane > 0 && sum[6] > 1e300;
-#else
-        const bool contributed = work && n_trac_lane > 0;
-#endif
+        const bool contributed = work && n_trac_lane > 0 && !(kElim == 5 && !(sum[6] > 1e300));
         {
             // ---- (a) the polygons of contributing bristle pairs, kept for k_fric, and (b) when pfc_eval_dual asked for it,
             // the candidate indices of the contributing pairs, in the slots reserved before the integration (lanes that
