@@ -1,71 +1,64 @@
-// Microbenchmark: sustained issue rate of wave64 VALU instructions on gfx950 at 1, 2, 4 waves per SIMD.
-// build: hipcc -O3 --offload-arch=gfx950 scripts/micro/valu_rate.hip -o /tmp/valu_rate ; run: /tmp/valu_rate
+// valu_rate.hip -- diagnostic microbenchmark (not part of the product): sustained VALU issue rate per SIMD for plain
+// Float32, packed Float32 and Float64 FMAs and for 32-bit integer/compare forms at 1, 2, 4 and 8 waves per SIMD.
+// Build: hipcc -O3 --offload-arch=gfx950 -o gpurun_out/valu_rate scripts/micro/valu_rate.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+typedef float float2v __attribute__((ext_vector_type(2)));
+constexpr int kIter = 4096, kAcc = 8;
 
-constexpr int kIter = 4096;
-// 8 independent accumulators per lane, 8 instructions per loop body (x4 unrolled by hand through the asm block)
-#define BODY_F32 "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n" \
-                 "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
-#define BODY_MUL32 "v_mul_f32 %0, %0, %8\n v_add_f32 %1, %1, %9\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %9\n" \
-                   "v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %9\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %9\n"
-#define BODY_F64 "v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n" \
-                 "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n"
-#define BODY_MUL64 "v_mul_f64 %0, %0, %8\n v_add_f64 %1, %1, %9\n v_mul_f64 %2, %2, %8\n v_add_f64 %3, %3, %9\n" \
-                   "v_mul_f64 %4, %4, %8\n v_add_f64 %5, %5, %9\n v_mul_f64 %6, %6, %8\n v_add_f64 %7, %7, %9\n"
-#define BODY_PK32 "v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n" \
-                  "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
-#define BODY_I32 "v_add_u32 %0, %0, %8\n v_and_b32 %1, %1, %9\n v_add_u32 %2, %2, %8\n v_xor_b32 %3, %3, %9\n" \
-                 "v_add_u32 %4, %4, %8\n v_or_b32 %5, %5, %9\n v_add_u32 %6, %6, %8\n v_lshlrev_b32 %7, 1, %7\n"
-
-template <typename T, int K>
-__global__ void __launch_bounds__(256) k_rate(T *out, T a, T b, unsigned long long *cyc) {
-    T x0 = (T)threadIdx.x, x1 = x0 + (T)1, x2 = x0 + (T)2, x3 = x0 + (T)3, x4 = x0 + (T)4, x5 = x0 + (T)5, x6 = x0 + (T)6, x7 = x0 + (T)7;
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    for (int i = 0; i < kIter; ++i) {
-        if constexpr (K == 0) asm volatile(BODY_F32 BODY_F32 BODY_F32 BODY_F32 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
-        if constexpr (K == 1) asm volatile(BODY_MUL32 BODY_MUL32 BODY_MUL32 BODY_MUL32 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
-        if constexpr (K == 2) asm volatile(BODY_F64 BODY_F64 BODY_F64 BODY_F64 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
-        if constexpr (K == 3) asm volatile(BODY_MUL64 BODY_MUL64 BODY_MUL64 BODY_MUL64 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
-        if constexpr (K == 4) asm volatile(BODY_PK32 BODY_PK32 BODY_PK32 BODY_PK32 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
-        if constexpr (K == 5) asm volatile(BODY_I32 BODY_I32 BODY_I32 BODY_I32 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+template <int KIND>
+__global__ void k_rate(float *out, float seed) {
+    float a[kAcc]; double d[kAcc]; float2v p[kAcc]; int q[kAcc];
+    const float b = seed * 1.0001f, c = seed * 0.5f;
+    const double bd = b, cd = c; const float2v bp = {b, b}, cp = {c, c};
+    for (int i = 0; i < kAcc; ++i) { a[i] = threadIdx.x * seed + i; d[i] = a[i]; p[i] = (float2v){a[i], a[i]}; q[i] = (int)a[i]; }
+    for (int it = 0; it < kIter; ++it) {
+#pragma unroll
+        for (int i = 0; i < kAcc; ++i) {
+            if (KIND == 0) asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %1, %0, %2" : "+v"(p[i]) : "v"(bp), "v"(cp));
+            if (KIND == 2) asm volatile("v_fma_f64 %0, %1, %0, %2" : "+v"(d[i]) : "v"(bd), "v"(cd));
+            if (KIND == 3) asm volatile("v_add_u32 %0, %1, %0" : "+v"(q[i]) : "v"(it));
+            if (KIND == 4) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (KIND == 5) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[i]) : "v"(c));
+            if (KIND == 6) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c) : "vcc");
+            if (KIND == 7) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(c));
+            if (KIND == 8) asm volatile("v_fma_f32 %0, |%1|, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        }
     }
-    const unsigned long long t1 = __builtin_readcyclecounter();
-    out[blockIdx.x * 256 + threadIdx.x] = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
-    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+    float s = 0;
+    for (int i = 0; i < kAcc; ++i) s += a[i] + (float)d[i] + p[i].x + p[i].y + q[i];
+    if (s == 12345.678f) out[0] = s;
 }
 
-template <typename T, int K>
-void run(const char *name, int n_cu) {
-    T *out; unsigned long long *cyc;
-    hipMalloc(&out, sizeof(T) * 256 * n_cu * 8);
-    hipMalloc(&cyc, 8);
-    for (int wps : {1, 2, 4, 8}) {
+template <int KIND>
+void run(const char *name, int instr_per_step, float *out) {
+    for (int w : {1, 2, 4, 8}) {
+        const int threads = 64 * 4 * (w > 4 ? 4 : w), blocks = 256 * (w > 4 ? w / 4 : 1) * 4;  // 4 rounds of full-chip blocks
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        k_rate<T, K><<<n_cu * wps, 256>>>(out, (T)1, (T)0, cyc);   // warm-up
+        hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(threads), 0, 0, out, 1.0f);
         hipDeviceSynchronize();
-        hipEventRecord(e0);
-        k_rate<T, K><<<n_cu * wps, 256>>>(out, (T)1, (T)0, cyc);
-        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(threads), 0, 0, out, 1.0f);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-        const double insts_per_simd = (double)kIter * 32 * wps;   // wave-instructions issued on each SIMD
-        printf("%-22s waves/SIMD %d: %7.3f ms  -> %.2f ns per wave-instruction per SIMD = %.2f cycles at 2.4 GHz; s_memtime cycles of block 0 per instruction of ITS wave: %.2f\n",
-               name, wps, ms, ms * 1e6 / insts_per_simd, ms * 1e6 / insts_per_simd * 2.4, (double)c / (kIter * 32.0));
+        const double waves = (double)blocks * threads / 64.0;
+        const double instr = waves * kIter * kAcc * instr_per_step;
+        const double per_simd_ns = instr / 1024.0 / (ms * 1e6);
+        printf("%-28s waves/SIMD %d  %8.3f ms  %6.3f wave-instr/ns/SIMD  = %5.2f cycles/instr at 2.4 GHz\n", name, w, ms, per_simd_ns, 2.4 / per_simd_ns);
     }
-    hipFree(out); hipFree(cyc);
 }
-
 int main() {
-    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
-    const int n_cu = p.multiProcessorCount;
-    printf("%s, %d CUs, clock %d MHz\n", p.gcnArchName, n_cu, p.clockRate / 1000);
-    run<float, 0>("v_fma_f32", n_cu);
-    run<float, 1>("v_mul_f32/v_add_f32", n_cu);
-    run<double, 2>("v_fma_f64", n_cu);
-    run<double, 3>("v_mul_f64/v_add_f64", n_cu);
-    run<double, 4>("v_pk_fma_f32", n_cu);
-    run<int, 5>("int32 add/logic", n_cu);
+    float *out; hipMalloc(&out, 64);
+    run<0>("v_fma_f32", 1, out);
+    run<8>("v_fma_f32 |abs| modifier", 1, out);
+    run<4>("v_mul_f32", 1, out);
+    run<5>("v_add_f32", 1, out);
+    run<1>("v_pk_fma_f32", 1, out);
+    run<2>("v_fma_f64", 1, out);
+    run<3>("v_add_u32", 1, out);
+    run<7>("v_mov_b32", 1, out);
+    run<6>("v_cmp_lt_f32+v_cndmask", 2, out);
     return 0;
 }
