@@ -315,7 +315,8 @@ struct pfc_context {
     int split_n0 = 0;                  // items in the first half of the pending evaluation (0: not split)
     bool in_split = false;             // this context's launches are one half of a two-half evaluation (set while they are enqueued)
     int last_parts = 1;                // 2 if the last checked evaluation ran as two halves
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join0 = nullptr;
+    hipStream_t twin_stream = nullptr;   // created right behind `stream` (the runtime deals streams out to its hardware queues in order of creation), handed to the twin
 };
 
 namespace {
@@ -884,9 +885,12 @@ int make_twin(pfc_context *h) {
     t->ins = h->ins; t->d_meshes = h->d_meshes; t->d_ins = h->d_ins; t->max_levels = h->max_levels;
     t->max_leaves = h->max_leaves;
     t->any_bristle = h->any_bristle; t->any_tet_tet = h->any_tet_tet; t->opt_split_min = 0;
-    if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess ||
+    t->stream = h->twin_stream; h->twin_stream = nullptr;
+    if ((!t->stream && hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join0, hipEventDisableTiming) != hipSuccess) {
+        if (t->stream) (void)hipStreamDestroy(t->stream);
         delete t;
         return fail(h, PFC_ERR_HIP, "could not create the second stream");
     }
@@ -933,6 +937,7 @@ int pfc_create(int device, pfc_handle *out) {
     if (!h) return PFC_ERR_NOMEM;
     h->device = device;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return PFC_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&h->twin_stream, hipStreamNonBlocking) != hipSuccess) h->twin_stream = nullptr;   // (make_twin creates one then)
     { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) h->n_cu = cu; }
     *out = h;
     return PFC_OK;
@@ -944,8 +949,10 @@ void pfc_destroy(pfc_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);   // an unchecked pfc_eval_device on the caller's stream
     if (h->twin) { pfc_destroy(h->twin); h->twin = nullptr; }
+    if (h->twin_stream) { (void)hipStreamDestroy(h->twin_stream); h->twin_stream = nullptr; }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_join0) (void)hipEventDestroy(h->ev_join0);
     if (h->is_twin) { h->d_meshes = nullptr; h->d_ins = nullptr; h->d_insfull = nullptr; }   // owned by the parent
     for (auto &m : h->meshes) {
         if (m.d_nodes) (void)hipFree(m.d_nodes);
@@ -1277,11 +1284,16 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
     t->opt_graph = h->opt_graph;
     if (t->opt_no_filter != h->opt_no_filter) { t->opt_no_filter = h->opt_no_filter; t->ghave[0] = t->ghave[1] = false; }
     const int n0 = n_items / 2, n1 = n_items - n0;      // (55 / 45 is the same within noise, 60 / 40 and 45 / 55 are slower: round 3)
-    // the second half starts when the caller's stream has reached this point and joins it again at the end
+    // Both halves run on the library's OWN two streams, which start when the caller's stream has reached this point and
+    // join it again at the end.  (The first half used to run on the caller's stream.  The halves only overlap if their
+    // streams sit on different hardware queues, and a stream the caller created may share one with the twin's: a torch
+    // pool stream took the 8 192-pose step from 4.1 to 5.1 ms -- more than the unsplit evaluation; scripts/inflight_probe.py.)
+    hipStream_t s0 = h->stream;
     HIP_TRY(h, hipEventRecord(h->ev_fork, st));
+    if (s0 != st) HIP_TRY(h, hipStreamWaitEvent(s0, h->ev_fork, 0));
     HIP_TRY(h, hipStreamWaitEvent(t->stream, h->ev_fork, 0));
     h->in_split = true; t->in_split = true;
-    rc = enqueue_eval(h, n0, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
+    rc = enqueue_eval(h, n0, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, s0);
     h->in_split = false;
     if (rc != PFC_OK) return rc;
     rc = enqueue_eval(t, n1, d_ins_ids + n0, d_pose + 24 * (size_t)n0, d_twist + 6 * (size_t)n0,
@@ -1290,6 +1302,10 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
     if (rc != PFC_OK) { h->err = t->err; return rc; }
     HIP_TRY(h, hipEventRecord(h->ev_join, t->stream));
     HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    if (s0 != st) {
+        HIP_TRY(h, hipEventRecord(h->ev_join0, s0));
+        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join0, 0));
+    }
     h->split_n0 = n0;
     return PFC_OK;
 }

@@ -266,6 +266,46 @@ def test_split_evaluation_equals_unsplit(pfc):
     assert np.all(a[2][:, 3] > 0)
 
 
+def test_two_half_evaluation_on_a_caller_stream(pfc):
+    """pfc_eval_device on a stream the CALLER created (a torch pool stream): the two halves run on the library's own two
+    streams between a fork and a join on the caller's stream, so work the caller enqueues behind the call sees the results,
+    and the results equal those of the library's own stream.  (The first half used to run on the caller's stream, which may
+    share a hardware queue with the second half's: no overlap, 4.1 -> 5.1 ms for 8 192 poses.)"""
+    import torch
+    w = pfc.configs.c3_blob_tool(1100, seed=33, n_div_blob=8, n_div_tool=6)
+    dev = torch.device("cuda:0")
+    m = pfc.configs.build_scenario(w)
+    n = w.n_items
+    d = dict(ins=torch.from_numpy(w.ins_ids.astype(np.int32)).to(dev), pose=torch.from_numpy(w.pose).to(dev),
+             twist=torch.from_numpy(w.twist).to(dev), s=torch.from_numpy(w.s).to(dev))
+    res = {}
+    for name, st in (("own", None), ("caller", torch.cuda.Stream())):
+        wr = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+        sd = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+        ct = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        total = torch.zeros(6, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(40):
+            m.eval_device(n, d["ins"].data_ptr(), d["pose"].data_ptr(), d["twist"].data_ptr(), d["s"].data_ptr(),
+                          wr.data_ptr(), sd.data_ptr(), ct.data_ptr(), st.cuda_stream if st else 0)
+            if st is not None:
+                with torch.cuda.stream(st):      # enqueued behind the call, before any synchronisation
+                    total = wr.sum(dim=0)
+            if m.check() == 0:
+                break
+        else:
+            raise AssertionError("work lists kept overflowing")
+        assert m.last_parts() == 2
+        torch.cuda.synchronize()
+        res[name] = (wr.cpu().numpy(), sd.cpu().numpy(), ct.cpu().numpy(), total.cpu().numpy())
+    a, b = res["own"], res["caller"]
+    assert np.array_equal(a[2], b[2])
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-11, atol=1e-11 * np.abs(a[0]).max())
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-7, atol=1e-7 * np.abs(a[1]).max())
+    np.testing.assert_allclose(b[3], b[0].sum(axis=0), rtol=1e-9, atol=1e-9 * np.abs(b[0]).max())
+    m.close()
+
+
 def test_alternating_batch_shapes_on_one_handle(pfc):
     """One handle, evaluations of very different sizes back to back (1, 700, 3, 1500 split, 64 items): the append lists
     (candidates, kept polygons and moment records in their 64 regions, contributing pairs) and their counters must
