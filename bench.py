@@ -137,7 +137,21 @@ def small_scene_latencies(pfc, reps: int = 200):
                 wr, sd, ct = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
             blocks.append((time.perf_counter() - t0) / 25)
         dt = statistics.median(blocks)
-        out[name] = {"us_per_eval": dt * 1e6, "ops": int(ct[:, 1].sum()), "ops_per_s": float(ct[:, 1].sum()) / dt,
+        # the same scene on bound buffers (MechanismScenario.bind: one foreign call per evaluation, no array checks or
+        # allocations) -- what a C or Julia caller of the ABI sees, within ~2 us
+        bound = m.bind(w.pose, w.twist, w.s, w.ins_ids)
+        for _ in range(10):
+            bound()
+        blocks_b = []
+        for _ in range(max(reps // 25, 1)):
+            t0 = time.perf_counter()
+            for _ in range(25):
+                bound()
+            blocks_b.append((time.perf_counter() - t0) / 25)
+        dt_b = statistics.median(blocks_b)
+        assert np.array_equal(bound.counts, ct)
+        out[name] = {"us_per_eval": dt * 1e6, "us_per_eval_bound_buffers": dt_b * 1e6, "ops": int(ct[:, 1].sum()), "ops_per_s": float(ct[:, 1].sum()) / dt,
+                     "ops_per_s_bound_buffers": float(ct[:, 1].sum()) / dt_b,
                      "path": ({0: "fused", 1: "batched", 2: "batched, two halves"}[m.last_parts()] +
                               (f", team of {m.last_team()} workgroups" if m.last_team() > 1 else ""))}
         m.close()

@@ -31,6 +31,11 @@ for name, w in (("C1 boxes (4 instructions)", pfc.configs.c1_boxes()),
     st = m.stats()
     print(f"{name:45s} {dt*1e6:9.1f} us/eval   ops {st['candidates']:8d}  node tests {st['node_tests']:9d}  "
           f"-> {st['candidates']/dt:.3g} ops/s, {w.n_items/dt:.3g} contact pairs/s")
+    bound = m.bind(w.pose, w.twist, w.s, w.ins_ids)
+    for _ in range(5):
+        bound()
+    dtb, _ = med(bound)
+    print(f"{'':45s} {dtb*1e6:9.1f} us/eval on bound buffers (MechanismScenario.bind: one foreign call, no array checks / allocations)")
     # the Dual evaluation of the same scene (6 partials, DENSE seeds: every (item, direction) carries non-zero partials --
     # keys whose seeds are all zero are skipped by the Dual passes, see the sparse figures below), alternating with value
     # evaluations as Radau does

@@ -226,3 +226,22 @@ def test_fuzz_random_and_degenerate_poses(pfc, degenerate, tet_tet):
             assert np.linalg.norm(wrench[k]) == 0.0
     assert n_contact > 100
     m.close()
+
+
+def test_bound_evaluation_equals_the_general_entry_point(pfc):
+    """MechanismScenario.bind: persistent input / output buffers, one foreign call per evaluation; inputs changed in place
+    are what the next call evaluates."""
+    w = pfc.configs.c1_boxes()
+    m = pfc.configs.build_scenario(w)
+    wr0, sd0, ct0 = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    b = m.bind(w.pose, w.twist, w.s, w.ins_ids)
+    wr, sd, ct = b()
+    assert np.array_equal(ct, ct0) and np.array_equal(wr, wr0) and np.array_equal(sd, sd0)
+    # a second point: the same change through both entry points
+    pose2 = w.pose.copy(); pose2[:, 11] -= 1.0e-3; pose2[:, 23] += 1.0e-3      # t21 / t12 along z (a rigid shift of frame 2)
+    tw2 = w.twist * 0.5
+    wr1, sd1, ct1 = m.force_all_elastic_intersections(pose2, tw2, w.s, w.ins_ids)
+    b.pose[:] = pose2; b.twist[:] = tw2
+    wr, sd, ct = b()
+    assert np.array_equal(ct, ct1) and np.array_equal(wr, wr1) and np.array_equal(sd, sd1)
+    m.close()
