@@ -370,6 +370,15 @@ constexpr int kNpMaxBlocks = 256 * 16;
 constexpr int kNpChunkSwitch = 2048;   // a batch is cut into at least this many chunks before the chunks grow beyond a wave round (512: C5 +90 us; 8192: the 2 048-pose step +9 %)
 size_t poly_cap(size_t ccap) { return (ccap + kNpChunkBig - 1) / kNpChunkBig * kNpChunkBig; }
 
+// A blocking copy that stays off the legacy stream (hipMemcpy synchronises with it, and the runtime refuses that while ANY
+// thread captures a graph: "operation would make the legacy stream depend on a capturing blocking stream" -- a second
+// handle being finalized on one host thread while another thread's evaluation records its graph; scripts/soak_threads.py).
+hipError_t copy_sync(pfc_context *h, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, h->stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(h->stream);
+}
+
 hipError_t ensure_work(pfc_context *h, int n_items) {
     hipError_t e;
     const size_t caps0[] = {h->items.cap, h->acc.cap, h->res.cap, h->icnt.cap, h->ctr.cap, h->frontier[0].cap,
@@ -1166,21 +1175,21 @@ int pfc_finalize(pfc_handle h) {
         double *d_xyz = nullptr, *d_eps = nullptr;
         int *d_idx = nullptr;
         HIP_TRY(h, hipMalloc((void **)&m.d_nodes, sizeof(NodeRec) * m.nodes.size()));
-        HIP_TRY(h, hipMemcpy(m.d_nodes, m.nodes.data(), sizeof(NodeRec) * m.nodes.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, copy_sync(h, m.d_nodes, m.nodes.data(), sizeof(NodeRec) * m.nodes.size(), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMalloc((void **)&m.d_nodesf, sizeof(NodeF) * m.nodesf.size()));
-        HIP_TRY(h, hipMemcpy(m.d_nodesf, m.nodesf.data(), sizeof(NodeF) * m.nodesf.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, copy_sync(h, m.d_nodesf, m.nodesf.data(), sizeof(NodeF) * m.nodesf.size(), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMalloc((void **)&d_xyz, sizeof(double) * m.xyz.size()));
-        HIP_TRY(h, hipMemcpy(d_xyz, m.xyz.data(), sizeof(double) * m.xyz.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, copy_sync(h, d_xyz, m.xyz.data(), sizeof(double) * m.xyz.size(), hipMemcpyHostToDevice));
         if (m.n_tri) {
             HIP_TRY(h, hipMalloc((void **)&d_idx, sizeof(int) * m.tri.size()));
-            HIP_TRY(h, hipMemcpy(d_idx, m.tri.data(), sizeof(int) * m.tri.size(), hipMemcpyHostToDevice));
+            HIP_TRY(h, copy_sync(h, d_idx, m.tri.data(), sizeof(int) * m.tri.size(), hipMemcpyHostToDevice));
             HIP_TRY(h, hipMalloc((void **)&m.d_tri, sizeof(TriRec) * m.n_tri));
             hipLaunchKernelGGL(k_prep_tri, dim3((m.n_tri + 127) / 128), dim3(128), 0, h->stream, m.n_tri, d_xyz, d_idx, m.d_tri);
         } else {
             HIP_TRY(h, hipMalloc((void **)&d_idx, sizeof(int) * m.tet.size()));
-            HIP_TRY(h, hipMemcpy(d_idx, m.tet.data(), sizeof(int) * m.tet.size(), hipMemcpyHostToDevice));
+            HIP_TRY(h, copy_sync(h, d_idx, m.tet.data(), sizeof(int) * m.tet.size(), hipMemcpyHostToDevice));
             HIP_TRY(h, hipMalloc((void **)&d_eps, sizeof(double) * m.eps.size()));
-            HIP_TRY(h, hipMemcpy(d_eps, m.eps.data(), sizeof(double) * m.eps.size(), hipMemcpyHostToDevice));
+            HIP_TRY(h, copy_sync(h, d_eps, m.eps.data(), sizeof(double) * m.eps.size(), hipMemcpyHostToDevice));
             HIP_TRY(h, hipMalloc((void **)&m.d_tet, sizeof(TetRec) * m.n_tet));
             HIP_TRY(h, hipMalloc((void **)&m.d_tet_eps, sizeof(double) * 4 * m.n_tet));
             hipLaunchKernelGGL(k_prep_tet, dim3((m.n_tet + 127) / 128), dim3(128), 0, h->stream, m.n_tet, d_xyz, d_eps, d_idx,
@@ -1194,11 +1203,11 @@ int pfc_finalize(pfc_handle h) {
         md[k].n_tri = m.n_tri; md[k].n_tet = m.n_tet; md[k].n_node = m.n_node; md[k].depth = m.depth;
     }
     unsigned status = 0;
-    HIP_TRY(h, hipMemcpy(&status, h->status.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIP_TRY(h, copy_sync(h, &status, h->status.p, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (status & kStNonFinite) return fail(h, PFC_ERR_NONFINITE, "singular tetrahedron (non-finite zeta transform)");
     if (!md.empty()) {
         HIP_TRY(h, hipMalloc((void **)&h->d_meshes, sizeof(MeshDev) * md.size()));
-        HIP_TRY(h, hipMemcpy(h->d_meshes, md.data(), sizeof(MeshDev) * md.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, copy_sync(h, h->d_meshes, md.data(), sizeof(MeshDev) * md.size(), hipMemcpyHostToDevice));
     }
     h->max_levels = 1;
     h->max_leaves = 2;
@@ -1216,7 +1225,7 @@ int pfc_finalize(pfc_handle h) {
         return fail(h, PFC_ERR_BAD_ARG, "OBB trees too deep (depth sum %d): rebuild them balanced", h->max_levels - 1);
     if (!h->ins.empty()) {
         HIP_TRY(h, hipMalloc((void **)&h->d_ins, sizeof(InsDev) * h->ins.size()));
-        HIP_TRY(h, hipMemcpy(h->d_ins, h->ins.data(), sizeof(InsDev) * h->ins.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, copy_sync(h, h->d_ins, h->ins.data(), sizeof(InsDev) * h->ins.size(), hipMemcpyHostToDevice));
         // one self-contained record per instruction for the fused small-scene kernel
         std::vector<InsFull> full(h->ins.size());
         for (size_t k = 0; k < h->ins.size(); ++k) {
@@ -1233,7 +1242,7 @@ int pfc_finalize(pfc_handle h) {
             full[k] = f;
         }
         HIP_TRY(h, hipMalloc((void **)&h->d_insfull, sizeof(InsFull) * full.size()));
-        HIP_TRY(h, hipMemcpy(h->d_insfull, full.data(), sizeof(InsFull) * full.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, copy_sync(h, h->d_insfull, full.data(), sizeof(InsFull) * full.size(), hipMemcpyHostToDevice));
     }
     h->finalized = true;
     return PFC_OK;
@@ -2157,8 +2166,8 @@ int pfc_debug_pairs(pfc_handle h, int item, int *pairs, int *clip_n, int cap) {
     std::vector<WorkRec> c(nc);
     std::vector<int> cn(nc);
     if (nc) {
-        if (hipMemcpy(c.data(), h->cand.p, sizeof(WorkRec) * nc, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(cn.data(), h->clip_n.p, sizeof(int) * nc, hipMemcpyDeviceToHost) != hipSuccess)
+        if (copy_sync(h, c.data(), h->cand.p, sizeof(WorkRec) * nc, hipMemcpyDeviceToHost) != hipSuccess ||
+            copy_sync(h, cn.data(), h->clip_n.p, sizeof(int) * nc, hipMemcpyDeviceToHost) != hipSuccess)
             return -fail(h, PFC_ERR_HIP, "copy failed");
     }
     int n = 0;
@@ -2182,10 +2191,10 @@ int pfc_debug_tractions(pfc_handle h, int item, double *buf, int cap) {
     std::vector<int> ti(nt);
     std::vector<double> td(nt * 8);
     if (nt) {
-        if (hipMemcpy(ti.data(), h->trac_item.p, sizeof(int) * nt, hipMemcpyDeviceToHost) != hipSuccess)
+        if (copy_sync(h, ti.data(), h->trac_item.p, sizeof(int) * nt, hipMemcpyDeviceToHost) != hipSuccess)
             return -fail(h, PFC_ERR_HIP, "copy failed");
         for (int a = 0; a < 8; ++a)
-            if (hipMemcpy(td.data() + a * nt, h->trac_d.p + a * h->tcap, sizeof(double) * nt, hipMemcpyDeviceToHost) != hipSuccess)
+            if (copy_sync(h, td.data() + a * nt, h->trac_d.p + a * h->tcap, sizeof(double) * nt, hipMemcpyDeviceToHost) != hipSuccess)
                 return -fail(h, PFC_ERR_HIP, "copy failed");
     }
     int n = 0;
@@ -2206,8 +2215,8 @@ int pfc_debug_stiffness(pfc_handle h, int item, double *K36, double *Kis36, doub
     if (item < 0 || item >= h->last_n_items) return -fail(h, PFC_ERR_BAD_ARG, "bad item");
     std::vector<double> r(kResStride);
     int ic[4];
-    if (hipMemcpy(r.data(), h->res.p + (size_t)item * kResStride, sizeof(double) * kResStride, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(ic, h->icnt.p + 4 * (size_t)item, sizeof ic, hipMemcpyDeviceToHost) != hipSuccess)
+    if (copy_sync(h, r.data(), h->res.p + (size_t)item * kResStride, sizeof(double) * kResStride, hipMemcpyDeviceToHost) != hipSuccess ||
+        copy_sync(h, ic, h->icnt.p + 4 * (size_t)item, sizeof ic, hipMemcpyDeviceToHost) != hipSuccess)
         return -fail(h, PFC_ERR_HIP, "copy failed");
     if (ic[3] == 0) return 0;
     if (K36) std::memcpy(K36, r.data() + kResK, sizeof(double) * 36);
@@ -2281,7 +2290,7 @@ int pfc_debug_stamps(pfc_handle h, long long *out16) {
     if (!h || !out16) return PFC_ERR_BAD_ARG;
     if (h->pending) { int rc = check_eval(h); if (rc) return rc; }
     unsigned long long v[16] = {0};
-    if (h->stamps.p) HIP_TRY(h, hipMemcpy(v, h->stamps.p, sizeof v, hipMemcpyDeviceToHost));
+    if (h->stamps.p) HIP_TRY(h, copy_sync(h, v, h->stamps.p, sizeof v, hipMemcpyDeviceToHost));
     for (int k = 0; k < 16; ++k) out16[k] = (long long)v[k];
     out16[7] = h->last_undecided;
     return PFC_OK;
@@ -2294,11 +2303,11 @@ int pfc_selftest_math(pfc_handle h, int n, const double *x, const double *y, dou
     HIP_TRY(h, hipMalloc((void **)&dx, sizeof(double) * n));
     HIP_TRY(h, hipMalloc((void **)&dy, sizeof(double) * n));
     HIP_TRY(h, hipMalloc((void **)&dout, sizeof(double) * 3 * (size_t)n));
-    HIP_TRY(h, hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(dy, y, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, copy_sync(h, dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, copy_sync(h, dy, y, sizeof(double) * n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, dx, dy, dout);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(out3n, dout, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, copy_sync(h, out3n, dout, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
     return PFC_OK;
 }

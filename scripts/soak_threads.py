@@ -31,9 +31,20 @@ f.close()
 bad = [0] * n_thr
 
 
+errors = []
+
+
 def worker(t):
+    try:
+        work(t)
+    except Exception as e:      # a thread's exception must fail the run, not only print
+        errors.append((t, repr(e)))
+        raise
+
+
+def work(t):
     r = np.random.default_rng(100 + t)
-    m = pfc.configs.build_scenario(w)
+    m = pfc.configs.build_scenario(w)      # (finalized here, while other threads may be recording graphs)
     for _ in range(n_ev):
         c = cases[int(r.integers(0, len(cases)))]
         s, lo, dual = c
@@ -59,4 +70,6 @@ for th in threads:
 for th in threads:
     th.join()
 print(f"{n_thr} threads x {n_ev} evaluations, mismatches per thread: {bad}")
-sys.exit(1 if any(bad) else 0)
+if errors:
+    print("thread errors:", errors)
+sys.exit(1 if (any(bad) or errors) else 0)

@@ -306,6 +306,41 @@ def test_two_half_evaluation_on_a_caller_stream(pfc):
     m.close()
 
 
+def test_handles_are_built_and_used_from_concurrent_host_threads(pfc):
+    """include/pfc.h: different handles may be used from different host threads.  Every thread builds its own scenario
+    (uploads in pfc_finalize) and evaluates new batch shapes (each records a graph) while the others do the same.  The
+    uploads used to go through hipMemcpy, i.e. the legacy stream, which the runtime refuses while any thread is capturing
+    ("operation would make the legacy stream depend on a capturing blocking stream")."""
+    import threading
+    w = pfc.configs.c3_blob_tool(96, seed=21, n_div_blob=5, n_div_tool=4)
+    ref_m = pfc.configs.build_scenario(w)
+    ref_m.set_option("fused", 0)
+    sizes = (96, 7, 33, 64, 1)
+    ref = {s: ref_m.force_all_elastic_intersections(w.pose[:s], w.twist[:s], w.s[:s], w.ins_ids[:s]) for s in sizes}
+    ref_m.close()
+    errors = []
+
+    def work(t):
+        try:
+            for rnd in range(3):
+                m = pfc.configs.build_scenario(w)
+                m.set_option("fused", 0)       # the batched path: every new shape records a graph
+                for s in sizes[t % len(sizes):] + sizes[:t % len(sizes)]:
+                    wr, sd, ct = m.force_all_elastic_intersections(w.pose[:s], w.twist[:s], w.s[:s], w.ins_ids[:s])
+                    assert np.array_equal(ct, ref[s][2])
+                    np.testing.assert_allclose(wr, ref[s][0], rtol=1e-10, atol=1e-10 * np.abs(ref[s][0]).max())
+                m.close()
+        except Exception as e:
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
 def test_alternating_batch_shapes_on_one_handle(pfc):
     """One handle, evaluations of very different sizes back to back (1, 700, 3, 1500 split, 64 items): the append lists
     (candidates, kept polygons and moment records in their 64 regions, contributing pairs) and their counters must
