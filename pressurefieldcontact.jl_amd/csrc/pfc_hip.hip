@@ -713,6 +713,10 @@ int check_one(pfc_context *h) {
         if (status & kStCandOvf) { size_t c = h->ccap * 2; while (c < (size_t)ctr[0]) c *= 2; h->ccap = c; }
         if (status & kStTracOvf) { size_t t = h->tcap * 2; while (t < (size_t)ctr[1]) t *= 2; h->tcap = t; }
         if (status & kStRecOvf) { size_t r = h->rcap * 2; while (r < (size_t)ctr[3]) r *= 2; h->rcap = r; }
+        // the lists are indexed by 32-bit integers (counters, slots): an evaluation that needs more is split by the caller
+        if (h->fcap > ((size_t)1 << 30) || h->ccap > ((size_t)1 << 30) || h->tcap > ((size_t)1 << 30) || h->rcap > ((size_t)1 << 30))
+            return fail(h, PFC_ERR_NOMEM, "work lists beyond 2^30 entries (frontier %zu, candidates %zu, tractions %zu, records %zu): evaluate the batch in parts",
+                        h->fcap, h->ccap, h->tcap, h->rcap);
         return fail(h, PFC_ERR_OVERFLOW, "work list overflow (status %u): capacities grown to frontier %zu, candidates %zu, tractions %zu, records %zu",
                     status, h->fcap, h->ccap, h->tcap, h->rcap);
     }
