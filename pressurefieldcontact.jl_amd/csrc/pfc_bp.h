@@ -174,16 +174,17 @@ __device__ __forceinline__ int next_ticket(int *ctr) {
 
 // =================================================================================================================
 // broadphase main kernel: the same wave-cooperative depth-first descent as k_bp_dfs, in single precision on one
-// 64-byte NodeF line per node.  Measured (in-kernel stamps): the Float64 kernel is latency-bound at 2 waves per SIMD
+// 48-byte NodeF record per node.  Measured (in-kernel stamps): the Float64 kernel is latency-bound at 2 waves per SIMD
 // (246 VGPRs, two 144-byte scattered records per lane and iteration), not ALU-bound; the Float32 kernel needs a
 // third of the registers and a third of the cache-line requests, and is exact in the following sense.
 //
-// For a node pair it forms v = R_a_b c_b + (t_a_b - c_a) in Float64 (the centre offset, of the order of the box
-// sizes), everything else in Float32 on unit quaternions: q = conj(q_a) (x) q_a_b (x) q_b (q_a, q_b from the node
+// For a node pair it forms the centre offset v = R_a_b c_b + (t_a_b - c_a) (of the order of the box sizes) and everything
+// else in Float32, rotations on unit quaternions: q = conj(q_a) (x) q_a_b (x) q_b (q_a, q_b from the node
 // records, q_a_b formed once per item from its pose (k_setup_items); each is checked in Float64 to reproduce its matrix to 4 u per
 // entry, u = 2^-24), R = matrix of q, t = R_a' v by the rotation formula, then the 15 axes d = |T.L| - (r_a + r_b).
-// The error of R is below 142 u, so |d_float - d_reference| < 320 u S with S = |v|_1 + sum e_a + sum e_b
-// (internal-internal pairs carry identity quaternions and only the pose's error: 24 u S).  d > E proves
+// The error of R is below 142 u, so |d_float - d_reference| < 320 u S + eabs with S = |v|_1 + sum e_a + sum e_b
+// (internal-internal pairs carry identity quaternions and only the pose's error: 24 u S) and eabs = 24 u x the size of
+// the scene, the price of forming v from Float32 centres.  d > E proves
 // separation, d < -E on all 15 axes proves overlap; an undecided pair (~1e-5 of its margin scale) is NOT decided by
 // this test: it is parked in LDS and settled at the top of the next iteration by the exact Float64 test.  The
 // candidate set and the node-test counts therefore equal the reference's bit for bit (tests/test_gpu_*.py).
@@ -206,10 +207,10 @@ struct Dfs32Args {
 };
 
 __device__ __forceinline__ NodeF load_nodef(const NodeF *n) {
-    // four 16-byte loads of one 64-byte line
+    // three 16-byte loads of one 48-byte record
     const gvec4i *p = (const gvec4i *)n;
-    union { vec4i v[4]; NodeF f; } u;
-    u.v[0] = p[0]; u.v[1] = p[1]; u.v[2] = p[2]; u.v[3] = p[3];
+    union { vec4i v[3]; NodeF f; } u;
+    u.v[0] = p[0]; u.v[1] = p[1]; u.v[2] = p[2];
     return u.f;
 }
 
@@ -220,7 +221,17 @@ __device__ __forceinline__ NodeF load_nodef(const NodeF *n) {
 // far below one u S and are covered by the slack left below.
 //   Notation.  R(q) is the polynomial map of quat_to_R (1 - 2(y^2 + z^2), 2(xy - wz), ...); it satisfies
 //   R(p (x) q) = R(p) R(q) for UNIT quaternions and R(s q) = I + s^2 (R(q) - I) for a scaled one.
-//   Inputs.  v_i = fl32(Float64 centre offset): |dv_i| <= u |v_i|.  e = fl32(extent): relative u.  Every quaternion used
+//   (0) Centre offset (round 3; before, v_i = fl32 of the Float64 offset, |dv_i| <= u |v_i|, which (3) still budgets).  v_i is
+//       formed from fl32(R_a_b), fl32(c_b), fl32(t_a_b), fl32(c_a) as a difference and three fused multiply-adds.  Rounded
+//       inputs: u (|t_i| + |c_a,i|) + 2 u sum_j |R_ij| |c_b,j|; the four operations round partial sums bounded by
+//       B_i = |t_i| + |c_a,i| + sum_j |R_ij| |c_b,j|: together |dv_i| <= 5.1 u B_i, and B_i <= Babs = cmax_a + cmax_b + max_i
+//       |t_a_b,i| (cmax = max over the mesh's nodes of |c|_1 >= |c|_2 >= a row of R_a_b against c_b).  This error is ABSOLUTE:
+//       it does not shrink with the boxes.  t = R_a' v is a rotation of v: a perturbation dv changes every axis value |T.L| by
+//       at most |dv|_2 |L|_2 <= sqrt 3 x 5.1 u Babs x (1 + 1e-5) < 8.9 u Babs (face axes: unit L; edge axes: (R_uj, R_vj) is
+//       part of a unit column), and S (formed from the computed v) by at most 3 x 5.1 u Babs, i.e. k S by < 1e-4 u Babs.
+//       The radius is E = k S + eabs with eabs = 24 u Babs (k_setup_items: ItemRec.bp_eabs, rounded up): 2.7 x the need.  A
+//       scene whose meshes sit far from their frame origins relative to the box sizes only sends more pairs to the exact test.
+//   Inputs.  e = fl32(extent): relative u.  Every quaternion used
 //   here (q_a, q_b: pfc_add_mesh; q_a_b: pose_quat) has passed, IN FLOAT64, the check |R(q_f) - R_ref|_max <= 4 u and
 //   | |q_f|^2 - 1 | <= 2.25 u; a node / pose that fails is exact_only and never decided here.
 //   (1) Representation.  With q^ = q_f / |q_f|: |R(q^) - R(q_f)| = |1/|q_f|^2 - 1| |R(q_f) - I| <= 2.26 u x 2, so
@@ -249,20 +260,20 @@ __device__ __forceinline__ NodeF load_nodef(const NodeF *n) {
 //       Face axis of A: u |t_i| + u e_a,i + (9 + 1 + 3) u sum e_b + 2 u S <= 15 u S; face axis of B: (9 + 1 + 3) u |v|_1 +
 //       13 u sum e_a + u e_b,j + 2 u S <= 15 u S; edge-edge: (9 + 1) u on each product + 2 u of fused rounding, + 2 u S:
 //       <= 14 u S.  E = 24 u S.
-// Hence |d_float - d_ref| < E on every axis: d_float > E proves the reference separates on that axis, d_float < -E on all
+// Hence |d_float - d_ref| < E = k S + eabs on every axis: d_float > E proves the reference separates on that axis, d_float < -E on all
 // 15 axes proves it does not separate on any; everything else is settled by the exact Float64 test.  The constants in the
 // code are 1.44e-6 (>= 24 u = 1.4305e-6) and 1.92e-5 (>= 320 u = 1.9073e-5).  tests/test_gpu_broadphase.py probes touching
 // configurations at 1 -/+ {1e-3, 1e-6, 1e-9, 1e-12} against the oracle for both box kinds; tests/test_bp_error_bound.py
 // samples a NumPy Float32 emulation of this function against these bounds (worst observed: |dR| 13 u, |d_float - d_ref| 8 u S).
 // one node pair of k_bp_dfs32: returns 0 = separated, 1 = overlapping, 2 = undecided
-__device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, bool any_leaf, const double *R12,
-                                             const float *q12, const double *t12) {
-    // centre offset in Float64, then everything in Float32
+__device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, bool any_leaf, const float *R12,
+                                             const float *q12, const float *t12, float eabs) {
+    // centre offset v = R_a_b c_b + (t_a_b - c_a) in Float32 on Float32 inputs: |dv_i| <= 5.1 u (|c_a|_1 + |c_b|_2 + |t_a_b,i|),
+    // an ABSOLUTE error that the radius carries as eabs (Error radius E, (0))
     float v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-        // fused: the rounding of this Float64 offset is far inside the error radius E of the Float32 test
-        v[i] = (float)__builtin_fma(R12[i + 6], b.c[2], __builtin_fma(R12[i + 3], b.c[1], __builtin_fma(R12[i], b.c[0], t12[i] - a.c[i])));
+        v[i] = __builtin_fmaf(R12[i + 6], b.c[2], __builtin_fmaf(R12[i + 3], b.c[1], __builtin_fmaf(R12[i], b.c[0], t12[i] - a.c[i])));
     // R = R_a' R_a_b R_b as ONE rotation: q = conj(q_a) (x) q_a_b (x) q_b, then its matrix; t = R_a' v by the quaternion
     // rotation formula: 32 + 24 + 18 instructions instead of 2 x 24 (two matrices) + 27 + 9 + 27 (two 3x3 products)
     float p[4], q[4], R[9], t[3];
@@ -272,10 +283,11 @@ __device__ __forceinline__ int test_pair_f32(const NodeF &a, const NodeF &b, boo
     quat_rot_inv(a.q, v, t);
     const float S = ((__builtin_fabsf(v[0]) + __builtin_fabsf(v[1])) + __builtin_fabsf(v[2])) +
                     ((a.e[0] + a.e[1]) + a.e[2]) + ((b.e[0] + b.e[1]) + b.e[2]);
-    const float E = (any_leaf ? 1.92e-5f : 1.44e-6f) * S;   // 320 u, 24 u
+    const float E = __builtin_fmaf(any_leaf ? 1.92e-5f : 1.44e-6f, S, eabs);   // 320 u S, 24 u S; + 24 u x the scene's size
     int verdict = sat15_f32_core(a.e, b.e, t, R, E);
-    // huge or non-finite inputs are not for this filter (sat15_f32_core): !(S < 1e18) also catches NaN
-    if ((a.exact_only | b.exact_only) || !(S < 1.0e18f)) verdict = 2;
+    // huge or non-finite inputs are not for this filter (sat15_f32_core): !(S < 1e18) also catches NaN -- which is also how
+    // a node whose quaternion failed its check announces itself (e[0] = NaN, pfc_add_mesh)
+    if (!(S < 1.0e18f)) verdict = 2;
     return verdict;
 }
 
@@ -405,6 +417,7 @@ __global__ void __launch_bounds__(BLK, 4) k_bp_dfs32(Dfs32Args g) {
     __shared__ int s_seed, s_base, s_def[2];   // s_def: parked-pair counters, alternating by iteration parity
     __shared__ double s_pose[12];         // R_a_b (9, column-major), t_a_b (3) of the current seed's item
     __shared__ float s_q12[4];            // unit quaternion of R_a_b (Float32), from the item record
+    __shared__ float s_posef[13];         // fl32 of R_a_b, t_a_b (the centre offset of the single-precision test) and bp_eabs
     __shared__ int s_pose_exact;          // the pose failed pose_quat's check: every test of the seed is settled exactly
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n_seed = *g.n_seed;
@@ -422,10 +435,11 @@ __global__ void __launch_bounds__(BLK, 4) k_bp_dfs32(Dfs32Args g) {
         const ItemRec *it = g.items + item;
         // the item's pose lives in LDS (broadcast reads inside the iteration) rather than in 33 registers that would
         // stay live across the call of the exact test
-        if (tid < 9) s_pose[tid] = it->R12[tid];
-        else if (tid < 12) s_pose[tid] = it->t12[tid - 9];
+        if (tid < 9) { const double x = it->R12[tid]; s_pose[tid] = x; s_posef[tid] = (float)x; }
+        else if (tid < 12) { const double x = it->t12[tid - 9]; s_pose[tid] = x; s_posef[tid] = (float)x; }
         else if (tid < 16) s_q12[tid - 12] = it->q12[tid - 12];     // formed and checked once per item (k_setup_items, pose_quat)
         else if (tid == 16) s_pose_exact = it->pose_exact;
+        else if (tid == 17) s_posef[12] = it->bp_eabs;
         const NodeF *n1 = it->nf1, *n2 = it->nf2;
         int sp = 1, n_out = 0, n_test = 0, n_cand = 0, n_def = 0, n_und = 0;
         if (tid == 0) {
@@ -474,12 +488,11 @@ __global__ void __launch_bounds__(BLK, 4) k_bp_dfs32(Dfs32Args g) {
                 STAMP(u1);
 #endif
                 if (!settle) {
-                    double R12[9], t12[3];
-                    float q12[4];
+                    float R12[9], t12[3], q12[4];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) R12[k] = s_pose[k];
+                    for (int k = 0; k < 9; ++k) R12[k] = s_posef[k];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
+                    for (int k = 0; k < 3; ++k) t12[k] = s_posef[9 + k];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) q12[k] = s_q12[k];
                     // Issue priority: the ~250 instructions of the test run at the default level, everything else of an
@@ -490,7 +503,7 @@ __global__ void __launch_bounds__(BLK, 4) k_bp_dfs32(Dfs32Args g) {
                     // first (exclusive 2.06 -> 1.95 ms for the 8 192-pose batch, step 4.40 -> 4.27 ms; levels 1, 2, 3
                     // alike).  The same in the clip kernel and k_integ changed nothing.
                     __builtin_amdgcn_s_setprio(0);
-                    verdict = test_pair_f32(a, b, la || lb, R12, q12, t12);
+                    verdict = test_pair_f32(a, b, la || lb, R12, q12, t12, s_posef[12]);
                     __builtin_amdgcn_s_setprio(1);
                     if (s_pose_exact) verdict = 2;
                 }

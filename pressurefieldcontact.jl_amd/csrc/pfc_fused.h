@@ -1077,8 +1077,8 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             r.k_bar = I.ins.k_bar; r.magic = I.ins.magic; r.nodes1 = I.ins.nodes1; r.nodes2 = I.ins.nodes2; r.nf1 = I.ins.nf1;
             r.nf2 = I.ins.nf2; r.tri = I.ins.tri; r.tet = I.ins.tet; r.tet1 = I.ins.tet1; r.eps1 = I.ins.eps1; r.eps2 = I.ins.eps2;
             r.Ebar1 = I.ins.Ebar1; r.model = I.ins.model; r.nq = nq; r.ins = id; r.pad = 0;
-            r.q12[0] = 1.0f; r.q12[1] = r.q12[2] = r.q12[3] = 0.0f; r.pose_exact = 1;      // (the broadphase does not read handed-over records)
-            r.pad2[0] = r.pad2[1] = r.pad2[2] = 0;
+            r.q12[0] = 1.0f; r.q12[1] = r.q12[2] = r.q12[3] = 0.0f; r.pose_exact = 1; r.bp_eabs = 0.0f;      // (the broadphase does not read handed-over records)
+            r.pad2[0] = r.pad2[1] = 0;
             s_cbase = n_pl ? atomicAdd(g.emit_ctr, n_pl) : 0;
         }
         __syncthreads();

@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <limits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -112,7 +113,12 @@ __global__ void k_setup_items(EvalArgs g) {
     r.model = in.model; r.nq = (in.nq == 1) ? 1 : 3;  // quadrature POINTS of rule 1 / rule 2 (quadrature.jl:22,31)
     r.ins = id; r.pad = 0;
     r.pose_exact = pose_quat(r.R12, r.q12) ? 0 : 1;
-    r.pad2[0] = r.pad2[1] = r.pad2[2] = 0;
+    {   // absolute part of the single-precision test's error radius (pfc_bp.h, "Error radius E", (0)); a NaN / huge pose gives
+        // NaN / inf here and every test of the item is settled exactly
+        const double tm = fmax(fmax(__builtin_fabs(r.t12[0]), __builtin_fabs(r.t12[1])), __builtin_fabs(r.t12[2]));
+        r.bp_eabs = (float)(1.4306e-6 * ((m1.cmax + m2.cmax) + tm)) * 1.000001f;
+    }
+    r.pad2[0] = r.pad2[1] = 0;
     bool finite = true;
 #pragma unroll
     for (int k = 0; k < 24; ++k) finite &= (__builtin_fabs(p[k]) <= 1.79769313486231570815e308);
@@ -170,6 +176,7 @@ struct HostMesh {
     std::vector<int> tri, tet;
     std::vector<NodeRec> nodes;
     std::vector<NodeF> nodesf;
+    double cmax = 0.0;                   // max |c|_1 over the nodes (MeshDev.cmax)
     NodeRec *d_nodes = nullptr;
     NodeF *d_nodesf = nullptr;
     TriRec *d_tri = nullptr;
@@ -1100,7 +1107,8 @@ int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int
         const NodeRec &r = m.nodes[k];
         NodeF f;
         std::memset(&f, 0, sizeof f);
-        for (int j = 0; j < 3; ++j) { f.c[j] = r.c[j]; f.e[j] = (float)r.e[j]; }
+        for (int j = 0; j < 3; ++j) { f.c[j] = (float)r.c[j]; f.e[j] = (float)r.e[j]; }
+        m.cmax = std::fmax(m.cmax, (std::fabs(r.c[0]) + std::fabs(r.c[1])) + std::fabs(r.c[2]));
         const double *R = r.R;   // column-major: R(i,j) = R[i + 3 j]
         double q[4];
         const double tr = R[0] + R[4] + R[8];
@@ -1129,7 +1137,8 @@ int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int
             double worst = 0.0;
             for (int j = 0; j < 9; ++j) worst = std::fmax(worst, std::fabs(Rq[j] - R[j]));
             const double n2 = w * w + x * x + y * y + z * z, u = 5.9604644775390625e-8;
-            f.exact_only = (std::isfinite(qn) && worst <= 4.0 * u && std::fabs(n2 - 1.0) <= 2.25 * u) ? 0 : 1;
+            // a node that fails is never decided in single precision: NaN extent -> S = NaN -> exact test (test_pair_f32)
+            if (!(std::isfinite(qn) && worst <= 4.0 * u && std::fabs(n2 - 1.0) <= 2.25 * u)) f.e[0] = std::numeric_limits<float>::quiet_NaN();
         }
         if (r.leaf == kInternal) { f.link0 = r.child0; f.link1 = r.child1; }
         else { f.link0 = r.leaf; f.link1 = -1; }
@@ -1203,7 +1212,7 @@ int pfc_finalize(pfc_handle h) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         (void)hipFree(d_xyz); (void)hipFree(d_idx);
         if (d_eps) (void)hipFree(d_eps);
-        md[k].nodes = m.d_nodes; md[k].nodesf = m.d_nodesf; md[k].tri = m.d_tri; md[k].tet = m.d_tet; md[k].tet_eps = m.d_tet_eps; md[k].Ebar = m.Ebar;
+        md[k].nodes = m.d_nodes; md[k].nodesf = m.d_nodesf; md[k].tri = m.d_tri; md[k].tet = m.d_tet; md[k].tet_eps = m.d_tet_eps; md[k].Ebar = m.Ebar; md[k].cmax = m.cmax;
         md[k].n_tri = m.n_tri; md[k].n_tet = m.n_tet; md[k].n_node = m.n_node; md[k].depth = m.depth;
     }
     unsigned status = 0;

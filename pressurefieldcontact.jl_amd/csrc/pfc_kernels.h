@@ -44,17 +44,21 @@ static_assert(sizeof(NodeRec) == 144, "NodeRec layout");
 // child links on the device: ~index (negative) marks a LEAF child (encoded at pfc_add_mesh)
 __host__ __device__ inline int node_index(int link) { return link < 0 ? ~link : link; }
 
-// One cache line per node for the single-precision broadphase: Float64 centre (the centre offset of two boxes is
-// formed in Float64), Float32 extents, the box rotation as a unit quaternion (identity for every merged box) and
-// the links.  For a leaf link0 is the element index.
+// 48 bytes per node for the single-precision broadphase (three 16-byte loads): Float32 centre and extents, the box
+// rotation as a unit quaternion (identity for every merged box) and the links.  For a leaf link0 is the element index.
+// A node whose quaternion does not reproduce R to 4 u (improper / non-orthonormal R) carries e[0] = NaN: the sum S of
+// the magnitudes of a test with such a node is NaN, which sends the pair to the exact Float64 test (test_pair_f32).
+// (Round 3: the centre used to be Float64, 64 bytes per node, and the centre offset of two boxes was formed in Float64:
+// 12 Float64 operations + 3 conversions of the test's ~230 instructions at twice the issue cost each, and a fourth load
+// per node.  The Float32 offset has an ABSOLUTE error -- of the order of u x the size of the scene, not of the boxes --
+// which the error radius carries as a per-item constant, ItemRec.bp_eabs.)
 struct alignas(16) NodeF {
-    double c[3];
+    float c[3];
     float e[3];
     float q[4];        // w, x, y, z
     int link0, link1;  // children (index, or ~index for a leaf child); leaf: link0 = element index
-    int exact_only;    // 1: the quaternion does not reproduce R to 8 u (improper / non-orthonormal R): always Float64
 };
-static_assert(sizeof(NodeF) == 64, "NodeF layout");
+static_assert(sizeof(NodeF) == 48, "NodeF layout");
 
 // Records are sized and aligned to the 128-byte L2 line: a lane's gather touches exactly one line per triangle and one
 // per tet (x_ζ²_r², all the clip needs); the second line of a tet is read only by pairs that survive the clip.  With
@@ -90,6 +94,7 @@ struct MeshDev {
     const TetRec *tet;
     const double *tet_eps;   // 4 per tet: raw ϵ of the tet's vertices (needed by the tet-tet equal-pressure plane)
     double Ebar;
+    double cmax;             // max over the nodes of |c|_1 (box centres, mesh frame): enters ItemRec.bp_eabs
     int n_tri, n_tet, n_node, depth;
 };
 
@@ -116,7 +121,11 @@ struct alignas(16) ItemRec {  // per (instruction, pose) item: outputs of refres
     // checked in Float64 once per item (pose_quat); pose_exact: the pose is not a proper rotation, every node test of the
     // item is settled by the exact Float64 test
     float q12[4];
-    int pose_exact, pad2[3];
+    int pose_exact;
+    // absolute part of the error radius of the single-precision test: 24 u (cmax_1 + cmax_2 + max |t12_i|), rounded up
+    // (pfc_bp.h, "Error radius E", (0))
+    float bp_eabs;
+    int pad2[2];
 };
 
 struct alignas(16) WorkRec {  // frontier entry (item, node_a, node_b) or candidate (item, i_1, i_2)
