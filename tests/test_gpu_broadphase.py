@@ -230,3 +230,49 @@ def test_poses_that_are_not_rotations_are_settled_exactly(pfc, n_pose):
     assert pfc._lib.lib().pfc_debug_stamps(m._h, out) == 0
     assert out[7] >= 3 * (n // 4), out[7]          # the three non-rotation kinds went to the exact test
     m.close()
+
+
+def test_meshes_far_from_their_frame_origins(pfc):
+    """The single-precision test forms the centre offset of two boxes from Float32 centres: its error is absolute -- u x the
+    distance of the boxes from their frame origins, not u x their size -- and enters the error radius as the per-item term
+    ItemRec.bp_eabs (pfc_bp.h, "Error radius E", (0)).  A reduced C3 scene whose meshes sit 60 .. 90 m from their frame
+    origins (boxes of centimetres: eabs is a few per cent of a box) must give the oracle's candidate sets and counters
+    bit for bit, with visibly more node pairs settled by the exact test than the same scene centred at the origins."""
+    import helpers as H
+    Cfg, S = pfc.configs, pfc.scenario
+    n_pose = 6
+    w0 = Cfg.c3_blob_tool(n_pose, seed=21, n_div_blob=8, n_div_tool=6)
+    o1, o2 = np.array([61.5, -83.25, 17.0]), np.array([-72.0, 40.5, 66.75])
+    tool0, blob0 = w0.meshes[0].mesh, w0.meshes[1].mesh
+    G = pfc.geometry
+    tool = G.EMesh(tool0.point + o1, tri=tool0.tri)
+    blob = G.EMesh(blob0.point + o2, tet=blob0.tet, eps=blob0.eps)
+    w1 = Cfg.Workload("C3 reduced, meshes far from their frame origins", [Cfg._mesh("tool", tool), Cfg._mesh("blob", blob, 1.0e6)],
+                      w0.instructions, w0.ins_ids.copy(), w0.pose.copy(), w0.twist.copy(), w0.s.copy())
+    for k in range(n_pose):
+        # the same relative placement of the two surfaces: frame r1 (tool) and frame r2 (blob) move against their meshes
+        R21 = w0.pose[k, 0:9].reshape(3, 3, order="F"); t21 = w0.pose[k, 9:12]        # x_r2_r1: p2 = R21 p1 + t21
+        t21n = t21 + o2 - R21 @ o1
+        R12 = R21.T
+        w1.pose[k, 9:12] = t21n
+        w1.pose[k, 21:24] = -(R12 @ t21n)
+        # ... and the same velocity field: twist of 2 w.r.t. 1 in frame r2, v(p) = v_lin + w x p, about the moved origin
+        w1.twist[k, 3:6] = w0.twist[k, 3:6] - np.cross(w0.twist[k, 0:3], o2)
+    und = []
+    for w in (w0, w1):
+        ref = H.oracle_run(pfc, w)
+        m = Cfg.build_scenario(w, debug=True)
+        m.set_option("fused", 0)          # the batched path: k_bp_dfs32
+        wrench, sdot, counts = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        out = (C.c_longlong * 16)()
+        assert pfc._lib.lib().pfc_debug_stamps(m._h, out) == 0
+        und.append(int(out[7]))
+        for k in range(w.n_items):
+            assert np.array_equal(counts[k], ref[k].counts), (w.name, k, counts[k], ref[k].counts)
+            pairs, clip_n = H.sorted_pairs(*m.debug_pairs(k))
+            rp, rc = H.sorted_pairs(ref[k].pairs, ref[k].clip_n)
+            assert np.array_equal(pairs, rp) and np.array_equal(clip_n, rc), (w.name, k)
+            assert H.rel_err(wrench[k], ref[k].wrench) < 1e-7, (w.name, k)        # 1e-16 x 100 m / 1 cm of cancellation in both
+        assert counts[:, 1].sum() > 0 and counts[:, 3].sum() > 0
+        m.close()
+    assert und[1] > 10 * max(und[0], 1), und      # the absolute term widened the band; verdicts stayed exact
