@@ -326,7 +326,7 @@ __device__ __forceinline__ void final_item(const BrArgs &g, int i) {
 // wait for the other blocks; it also leaves the counters and the status word zeroed for the next evaluation.  (What a
 // small scene pays is launches, not kernels: this used to be a kernel of its own plus two memset nodes.)
 __global__ void __launch_bounds__(128) k_final(BrArgs g) {
-    __shared__ unsigned long long tot[3];
+    __shared__ unsigned long long tot[4];
     __shared__ int rtot[2];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * blockDim.x + tid;
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(128) k_final(BrArgs g) {
     // packing loaded after the epilogue and between barriers).
     unsigned stw = 0;
     int c0 = 0, c1 = 0, r0 = 0, r1 = 0;
-    unsigned long long a = 0, b = 0, c = 0;
+    unsigned long long a = 0, b = 0, c = 0, d = 0;
     if (b0) {
         if (tid < 4) stw = g.status[tid];
         if (tid < g.n_ctr) c0 = g.ctr[tid];
@@ -344,8 +344,9 @@ __global__ void __launch_bounds__(128) k_final(BrArgs g) {
         if (tid < kRgn) { r0 = g.rgn[tid * kRgnStride]; r1 = g.rgn[tid * kRgnStride + 1]; }
         for (int k = tid; k < g.n_items; k += blockDim.x) {
             a += (unsigned)g.icnt[4 * (size_t)k]; b += (unsigned)g.icnt[4 * (size_t)k + 2]; c += (unsigned)g.icnt[4 * (size_t)k + 3];
+            d += (unsigned)g.icnt[4 * (size_t)k] > 1u ? 1ull : 0ull;      // items whose root pair overlapped (pile_mode's hint)
         }
-        if (tid < 3) tot[tid] = 0ull;
+        if (tid < 4) tot[tid] = 0ull;
         if (tid < 2) rtot[tid] = 0;
     }
     if (i < g.n_items) final_item(g, i);
@@ -354,6 +355,7 @@ __global__ void __launch_bounds__(128) k_final(BrArgs g) {
     if (a) atomicAdd(&tot[0], a);
     if (b) atomicAdd(&tot[1], b);
     if (c) atomicAdd(&tot[2], c);
+    if (d) atomicAdd(&tot[3], d);
     if (r0) atomicAdd(&rtot[0], r0);
     if (r1) atomicAdd(&rtot[1], r1);
     int *tail = g.tail;
@@ -365,8 +367,7 @@ __global__ void __launch_bounds__(128) k_final(BrArgs g) {
     for (int k = tid + 256; k < g.n_ctr; k += blockDim.x) { tail[12 + k] = g.ctr[k]; g.ctr[k] = 0; }   // very deep trees
     if (tid < kRgn) { g.rgn[tid * kRgnStride] = 0; g.rgn[tid * kRgnStride + 1] = 0; }
     __syncthreads();
-    if (tid < 3) reinterpret_cast<unsigned long long *>(tail + 4)[tid] = tot[tid];
-    if (tid == 3) reinterpret_cast<unsigned long long *>(tail + 4)[3] = 0ull;
+    if (tid < 4) reinterpret_cast<unsigned long long *>(tail + 4)[tid] = tot[tid];
     // region counters -> totals (the host sizes the record list by them)
     if (tid == 0) { tail[12 + g.i_pcount] = rtot[0]; tail[12 + 3] = rtot[1]; }
 }

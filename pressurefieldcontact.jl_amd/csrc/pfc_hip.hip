@@ -196,6 +196,10 @@ struct pfc_context {
     std::vector<HostMesh> meshes;
     std::vector<InsDev> ins;
     MeshDev *d_meshes = nullptr;
+    // every mesh's device records (NodeF, NodeRec, TriRec / TetRec, raw eps) are carved out of ONE allocation, the
+    // single-precision nodes of all meshes first (a pile of 128 meshes used to make ~600 small hipMallocs; measured neutral
+    // for C5's evaluation time, kept for the contiguous hot set and the one free)
+    char *mesh_arena = nullptr;
     InsDev *d_ins = nullptr;
     int max_levels = 1;
     int max_leaves = 2;                // largest n_leaf(mesh_1) + n_leaf(mesh_2) over the instructions
@@ -283,6 +287,12 @@ struct pfc_context {
     DevBuf<int> poly_item, pcnt, poly_cand;                 // kept polygons (k_narrow -> k_integ, k_fric): keys, count per chunk, candidate index (Dual list)
     DevBuf<double> poly;
     long long last_undecided = 0;      // node pairs the Float32 broadphase settled with the exact Float64 test
+    long long last_active = 0;         // items of the last checked evaluation whose root pair overlapped (more than one node test)
+    // what the last checked evaluation looked like: a SPARSE pile (at most a quarter of the items in contact: all pairs of a
+    // pile of bodies, most of them apart) of mid-sized trees is latency-bound by the descents of its few big pairs, a dense
+    // batch by throughput -- the next evaluation of the same shape is laid out accordingly (pile_mode)
+    int hint_n = 0;
+    bool hint_sparse = false;
     long long last_tslots = 0;         // traction slots used by the last evaluation (>= traction points)
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
@@ -490,13 +500,37 @@ int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
         const bool big = h->max_leaves >= 8192, mid = h->max_leaves >= 1024;
         // (end of round 2, final kernels: from ~600 items a seed level only costs -- 640 poses 0.71 vs 0.74 ms without /
         // with one level, 768 0.73 vs 0.80, 1 023 0.80 vs 0.92; 512 and below are indifferent or gain)
+        // (End of round 3, scripts/sweep_bp_blk_levels.py / sweep_bp_split.py: mid-sized trees want ~256 seeds, not 1 024 --
+        // 512 poses of a 1 280-leaf pair 185 vs 213 us with 0 / 1 level -- and a batch of >= 1 024 items over small or mid-sized
+        // trees no level at all: the level that used to be forced there, tuned on the sparse pile C5 (340 vs 370 us), cost dense
+        // batches 20-30 %: 2 000 poses 381 vs 500 us, 2 500 box-on-plane scenes 343 vs 493.  The pile gets its parallelism from
+        // 512-thread workgroups instead, pile_mode.)
         const double target = big ? (n_items >= 600 ? 1.0 : (n_items >= 256 ? 1024.0 : (n_items >= 128 ? 2048.0 : (n_items >= 32 ? 16384.0 : 49152.0))))
-                                  : (mid ? 1024.0 : 64.0);
+                                  : (mid ? 256.0 : 64.0);
         double seeds = (double)n_items;
         while (seeds < target && L < 9) { seeds *= 4.0; ++L; }
-        if (L == 0 && !big && n_items >= 1024) L = 1;
     }
     return L > levels ? levels : L;
+}
+
+// A sparse pile (see hint_sparse): >= 1 024 items over small or mid-sized trees of which at most a quarter were in contact the
+// last time this shape was evaluated.  Evaluated in ONE launch sequence with 512-thread broadphase workgroups (C5: 318 us
+// against 340 as two halves with 256-thread workgroups and a seed level; without the level 370).
+bool pile_mode(const pfc_context *h, int n_items) {
+    return h->max_leaves < 8192 && n_items >= 1024 && n_items < kBpSmallBlockMin && h->hint_n == n_items && h->hint_sparse && !h->is_twin;
+}
+
+// Threads per workgroup of the depth-first broadphase kernel.  128: the halves of a big batch (throughput: the finer grain
+// shares the CUs with the other half's kernels).  512: launches whose time is the descent of a few big pairs -- 8 ... 1 023 items
+// over big trees (16 full-size C3 poses 198 -> 183 us, 128: 386 -> 314, 256: 459 -> 399, 600: 681 -> 662; from 1 024 items
+// on 256 threads win again) and sparse piles: an iteration costs ~1.7 us whatever its width, 512 pairs per iteration halve
+// the chain.  (1 024 threads: no further gain, C5 105 vs 97 us of broadphase.)  256 otherwise.
+int bp_block_for(const pfc_context *h, int n_items) {
+    if (n_items >= kBpSmallBlockMin) return 128;
+    if (h->in_split) return 256;
+    if (h->max_leaves >= 8192 && n_items >= 8 && n_items < 1024) return 512;
+    if (pile_mode(h, n_items)) return 512;
+    return 256;
 }
 
 // The launch sequence of one evaluation on stream st (eagerly, or while st is being captured into a graph).
@@ -556,8 +590,11 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
             // kernel alone runs as fast either way (2.08 ms), but next to the other half's narrowphase the finer grain
             // shares the CUs better (8 192-pose step 4.53 -> 4.39 ms; 4 096: 2.33 vs 2.38, 2 048: 1.30 vs 1.45 -- a smaller
             // launch needs the 256 pairs per iteration; profiles/r02_sweep_bp_block.txt).  Grid = resident workgroups.
-            if (n_items >= kBpSmallBlockMin && f.reserve <= 128 * 10 - 512)
+            const int blk = bp_block_for(h, n_items);
+            if (blk == 128 && f.reserve <= 128 * 10 - 512)
                 hipLaunchKernelGGL((k_bp_dfs32<128>), dim3(grid_for(bound, 1, 256 * 8)), dim3(128), 0, st, f);
+            else if (blk == 512)
+                hipLaunchKernelGGL((k_bp_dfs32<512>), dim3(grid_for(bound, 1, 256 * 2)), dim3(512), 0, st, f);
             else
                 hipLaunchKernelGGL((k_bp_dfs32<kDfsBlock>), dim3(grid_for(bound, 1, 256 * 6)), dim3(kDfsBlock), 0, st, f);
         }
@@ -654,7 +691,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
 #endif
     if (use_graph) {
         pfc_context::GraphKey key = {};
-        key.n_items = n_items; key.levels = levels; key.L = L; key.debug = (h->opt_debug ? 1 : 0) | (h->in_split ? 2 : 0);
+        key.n_items = n_items; key.levels = levels; key.L = L; key.debug = (h->opt_debug ? 1 : 0) | (h->in_split ? 2 : 0) | (bp_block_for(h, n_items) << 4);
         key.bristle = (h->any_bristle ? 1 : 0) | (h->any_tet_tet ? 2 : 0);
         key.surv = h->want_surv ? 1 : 0;
         key.p[0] = d_ins_ids; key.p[1] = d_pose; key.p[2] = d_twist; key.p[3] = d_s; key.p[4] = d_wrench;
@@ -732,6 +769,7 @@ int check_one(pfc_context *h) {
 
     if (status & kStNonFinite) return fail(h, PFC_ERR_NONFINITE, "Non-finite vertex likely");
     h->stats[0] = (long long)tot[0]; h->stats[2] = (long long)tot[1]; h->stats[3] = (long long)tot[2];
+    h->last_active = (long long)tot[3];
     return PFC_OK;
 }
 
@@ -740,7 +778,12 @@ int check_fused(pfc_context *h);
 int check_eval(pfc_context *h) {
     if (h->pending_fused) return check_fused(h);
     h->last_fused = false;
-    if (!h->split_n0) { h->last_parts = 1; return check_one(h); }
+    if (!h->split_n0) {
+        h->last_parts = 1;
+        const int rc0 = check_one(h);
+        if (rc0 == PFC_OK) { h->hint_n = h->last_n_items; h->hint_sparse = h->last_active * 4 <= (long long)h->last_n_items; }
+        return rc0;
+    }
     h->last_parts = 2;
     pfc_context *t = h->twin;
     const int rc1 = check_one(h), rc2 = check_one(t);   // both always run: each grows its own work lists on overflow
@@ -753,6 +796,8 @@ int check_eval(pfc_context *h) {
     h->stats[6] |= t->stats[6];
     h->stats[7] += t->stats[7];
     h->last_undecided += t->last_undecided;
+    h->hint_n = (int)h->stats[7];
+    h->hint_sparse = (h->last_active + t->last_active) * 4 <= h->stats[7];
     return PFC_OK;
 }
 
@@ -974,13 +1019,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_join0) (void)hipEventDestroy(h->ev_join0);
     if (h->is_twin) { h->d_meshes = nullptr; h->d_ins = nullptr; h->d_insfull = nullptr; }   // owned by the parent
-    for (auto &m : h->meshes) {
-        if (m.d_nodes) (void)hipFree(m.d_nodes);
-        if (m.d_nodesf) (void)hipFree(m.d_nodesf);
-        if (m.d_tri) (void)hipFree(m.d_tri);
-        if (m.d_tet) (void)hipFree(m.d_tet);
-        if (m.d_tet_eps) (void)hipFree(m.d_tet_eps);
-    }
+    if (h->mesh_arena) (void)hipFree(h->mesh_arena);      // the meshes' d_* pointers point into it
     if (h->d_meshes) (void)hipFree(h->d_meshes);
     if (h->d_ins) (void)hipFree(h->d_ins);
     if (h->d_insfull) (void)hipFree(h->d_insfull);
@@ -1183,28 +1222,42 @@ int pfc_finalize(pfc_handle h) {
     HIP_TRY(h, hipMemsetAsync(h->status.p, 0, sizeof(unsigned) * 4, h->stream));   // same stream as k_prep_tet below
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::vector<MeshDev> md(h->meshes.size());
+    {   // one arena for the records of all meshes, the broadphase's single-precision nodes first (its hot set, contiguous)
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        size_t total = 0;
+        for (HostMesh &m : h->meshes) total += up(sizeof(NodeF) * m.nodesf.size());
+        for (HostMesh &m : h->meshes)
+            total += up(sizeof(NodeRec) * m.nodes.size()) + (m.n_tri ? up(sizeof(TriRec) * m.n_tri)
+                                                                      : up(sizeof(TetRec) * m.n_tet) + up(sizeof(double) * 4 * m.n_tet));
+        if (total) HIP_TRY(h, hipMalloc((void **)&h->mesh_arena, total));
+        size_t off = 0;
+        for (HostMesh &m : h->meshes) { m.d_nodesf = (NodeF *)(h->mesh_arena + off); off += up(sizeof(NodeF) * m.nodesf.size()); }
+        for (HostMesh &m : h->meshes) {
+            m.d_nodes = (NodeRec *)(h->mesh_arena + off); off += up(sizeof(NodeRec) * m.nodes.size());
+            if (m.n_tri) { m.d_tri = (TriRec *)(h->mesh_arena + off); off += up(sizeof(TriRec) * m.n_tri); }
+            else {
+                m.d_tet = (TetRec *)(h->mesh_arena + off); off += up(sizeof(TetRec) * m.n_tet);
+                m.d_tet_eps = (double *)(h->mesh_arena + off); off += up(sizeof(double) * 4 * m.n_tet);
+            }
+        }
+    }
     for (size_t k = 0; k < h->meshes.size(); ++k) {
         HostMesh &m = h->meshes[k];
         double *d_xyz = nullptr, *d_eps = nullptr;
         int *d_idx = nullptr;
-        HIP_TRY(h, hipMalloc((void **)&m.d_nodes, sizeof(NodeRec) * m.nodes.size()));
         HIP_TRY(h, copy_sync(h, m.d_nodes, m.nodes.data(), sizeof(NodeRec) * m.nodes.size(), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMalloc((void **)&m.d_nodesf, sizeof(NodeF) * m.nodesf.size()));
         HIP_TRY(h, copy_sync(h, m.d_nodesf, m.nodesf.data(), sizeof(NodeF) * m.nodesf.size(), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMalloc((void **)&d_xyz, sizeof(double) * m.xyz.size()));
         HIP_TRY(h, copy_sync(h, d_xyz, m.xyz.data(), sizeof(double) * m.xyz.size(), hipMemcpyHostToDevice));
         if (m.n_tri) {
             HIP_TRY(h, hipMalloc((void **)&d_idx, sizeof(int) * m.tri.size()));
             HIP_TRY(h, copy_sync(h, d_idx, m.tri.data(), sizeof(int) * m.tri.size(), hipMemcpyHostToDevice));
-            HIP_TRY(h, hipMalloc((void **)&m.d_tri, sizeof(TriRec) * m.n_tri));
             hipLaunchKernelGGL(k_prep_tri, dim3((m.n_tri + 127) / 128), dim3(128), 0, h->stream, m.n_tri, d_xyz, d_idx, m.d_tri);
         } else {
             HIP_TRY(h, hipMalloc((void **)&d_idx, sizeof(int) * m.tet.size()));
             HIP_TRY(h, copy_sync(h, d_idx, m.tet.data(), sizeof(int) * m.tet.size(), hipMemcpyHostToDevice));
             HIP_TRY(h, hipMalloc((void **)&d_eps, sizeof(double) * m.eps.size()));
             HIP_TRY(h, copy_sync(h, d_eps, m.eps.data(), sizeof(double) * m.eps.size(), hipMemcpyHostToDevice));
-            HIP_TRY(h, hipMalloc((void **)&m.d_tet, sizeof(TetRec) * m.n_tet));
-            HIP_TRY(h, hipMalloc((void **)&m.d_tet_eps, sizeof(double) * 4 * m.n_tet));
             hipLaunchKernelGGL(k_prep_tet, dim3((m.n_tet + 127) / 128), dim3(128), 0, h->stream, m.n_tet, d_xyz, d_eps, d_idx,
                                m.d_tet, m.d_tet_eps, h->status.p);
         }
@@ -1294,7 +1347,7 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
     }
     if (h->fused_skip > 0 && n_items <= kFusedMaxItems) --h->fused_skip;
     const bool split = h->opt_split_min > 0 && n_items >= h->opt_split_min && d_ins_ids && !h->opt_debug &&
-                       !h->want_surv && !h->is_twin;
+                       !h->want_surv && !h->is_twin && !pile_mode(h, n_items);
     if (!split) return enqueue_eval(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
     int rc = make_twin(h);
     if (rc != PFC_OK) return rc;

@@ -4,8 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pfc_pkg
 pfc = pfc_pkg.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-w = pfc.configs.c3_blob_tool(n)
+cfg = sys.argv[2] if len(sys.argv) > 2 else "c3"          # c3 (n poses) | c5 (the pile) ; argv[3]: bfs_levels
+w = pfc.configs.c5_pile() if cfg == "c5" else pfc.configs.c3_blob_tool(n)
 m = pfc.configs.build_scenario(w)
+if len(sys.argv) > 3:
+    m.set_option("bfs_levels", int(sys.argv[3]))
+if os.environ.get("PFC_SPLIT_MIN"):
+    m.set_option("split_min", int(os.environ["PFC_SPLIT_MIN"]))
 for _ in range(3):
     m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
 out = (C.c_longlong * 16)()

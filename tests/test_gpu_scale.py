@@ -9,8 +9,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-9
 
 
-def _check_vs_oracle(pfc, w, m, wrench, sdot, counts, pair_items=(), tol=TOL):
-    ref = H.oracle_run(pfc, w, debug=bool(pair_items))
+def _check_vs_oracle(pfc, w, m, wrench, sdot, counts, pair_items=(), tol=TOL, oracle_debug=False):
+    ref = H.oracle_run(pfc, w, debug=bool(pair_items) or oracle_debug)      # debug: the oracle also returns K (the ṡ tolerance rule below)
     for k, r in enumerate(ref):
         assert np.array_equal(counts[k], r.counts), (k, counts[k], r.counts)
         for name, a, b in (("wrench", wrench[k], r.wrench), ("sdot", sdot[k], r.sdot)):
@@ -58,6 +58,39 @@ def test_c5_pile_all_pairs(pfc):
     # reference as much as here: ṡ is only reproducible to ~1e-8 relative.  The north_star tolerance (1e-6) is asserted.
     _check_vs_oracle(pfc, w, m, wrench, sdot, counts, pair_items=tuple(touching[:3]) + (0,), tol=1e-6)
     m.close()
+
+
+def test_c5_pile_mode_and_wide_broadphase_workgroups(pfc):
+    """Default options (no debug lists): the first C5 evaluation of a handle runs as two halves; it finds at most a quarter of
+    the 2 016 items in contact, so the next evaluations of that shape run as ONE launch sequence with 512-thread broadphase
+    workgroups (pile_mode, pfc_hip.hip).  All of them against the oracle, and equal among themselves in every integer.  A batch
+    of 24 full-size C3 poses takes the 512-thread workgroups from its first evaluation (big trees, fewer than 1 024 items)."""
+    w = pfc.configs.c5_pile()
+    m = pfc.configs.build_scenario(w)
+    first = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert m.last_parts() == 2
+    _check_vs_oracle(pfc, w, m, *first, tol=1e-6, oracle_debug=True)
+    for _ in range(2):
+        again = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        assert m.last_parts() == 1          # pile mode
+        assert np.array_equal(again[2], first[2])
+        np.testing.assert_allclose(again[0], first[0], rtol=1e-9, atol=1e-9 * np.abs(first[0]).max())
+    # a dense evaluation of the same size ends the pile mode: every item in contact (the touching pairs repeated)
+    touching = np.nonzero(first[2][:, 3] > 0)[0]
+    idx = np.resize(touching, w.n_items)
+    dense = m.force_all_elastic_intersections(w.pose[idx], w.twist[idx], w.s[idx], w.ins_ids[idx])
+    assert m.last_parts() == 1              # laid out from the previous evaluation's picture
+    dense2 = m.force_all_elastic_intersections(w.pose[idx], w.twist[idx], w.s[idx], w.ins_ids[idx])
+    assert m.last_parts() == 2              # ... and from its own
+    assert np.array_equal(dense[2], dense2[2]) and np.array_equal(dense[2], first[2][idx])
+    m.close()
+    w3 = pfc.configs.c3_blob_tool(24, seed=77)
+    m3 = pfc.configs.build_scenario(w3)
+    m3.set_option("fused", 0)
+    out = m3.force_all_elastic_intersections(w3.pose, w3.twist, w3.s, w3.ins_ids)
+    assert m3.last_parts() == 1
+    _check_vs_oracle(pfc, w3, m3, *out, oracle_debug=True)
+    m3.close()
 
 
 def test_c3_batch_properties(pfc):
