@@ -505,7 +505,10 @@ int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
         // trees no level at all: the level that used to be forced there, tuned on the sparse pile C5 (340 vs 370 us), cost dense
         // batches 20-30 %: 2 000 poses 381 vs 500 us, 2 500 box-on-plane scenes 343 vs 493.  The pile gets its parallelism from
         // 512-thread workgroups instead, pile_mode.)
-        const double target = big ? (n_items >= 600 ? 1.0 : (n_items >= 256 ? 1024.0 : (n_items >= 128 ? 2048.0 : (n_items >= 32 ? 16384.0 : 49152.0))))
+        // (a half of a two-half evaluation shares the chip with its twin's seeds: 1 100 poses as 2 x 550, 891 vs 930 us
+        // without / with the level its own 550 items would ask for)
+        const int n_eff = h->in_split ? 2 * n_items : n_items;
+        const double target = big ? (n_eff >= 600 ? 1.0 : (n_eff >= 256 ? 1024.0 : (n_eff >= 128 ? 2048.0 : (n_eff >= 32 ? 16384.0 : 49152.0))))
                                   : (mid ? 256.0 : 64.0);
         double seeds = (double)n_items;
         while (seeds < target && L < 9) { seeds *= 4.0; ++L; }
