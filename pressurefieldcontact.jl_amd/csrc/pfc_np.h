@@ -326,15 +326,14 @@ __device__ __forceinline__ bool np_front(const ItemRec *it, const WorkRec &cw, c
 // Clip-only narrowphase: poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98) fused with centroid(poly_r2, n̂2)
 // (poly_eight.jl:35-52), as in the full kernel; every vertex leaves for the kept polygon (SoA slot `slot`, streaming stores)
 // as it is converted.  k_integ and k_fric read what is written here.
+// (V = x_r2_ζ2 and E = ϵ_r2 of the tet, the second line of its record, as the caller loaded them: k_clip_queue issues that gather
+// before it clips)
 template <class Ring>
-__device__ __forceinline__ void np_keep_polygon(const Ring &R, int n, const GTetRec *tp, V3 nh, const NpArgs &g, int slot, int item,
-                                                int idx) {
+__device__ __forceinline__ void np_keep_polygon(const Ring &R, int n, const double (&V)[12], const double (&E)[4], V3 nh, const NpArgs &g,
+                                                int slot, int item, int idx) {
     const size_t P = (size_t)g.pcap;
     double *o = g.poly + slot;
 #define NT_(p, v) __builtin_nontemporal_store((v), (p))
-    double V[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
     auto conv = [&](int k) {
         const double z0 = R.get(k, 0), z1 = R.get(k, 1), z2 = R.get(k, 2), z3 = R.get(k, 3);
         const V3 x = mk3(((V[0] * z0 + V[3] * z1) + V[6] * z2) + V[9] * z3,
@@ -358,10 +357,20 @@ __device__ __forceinline__ void np_keep_polygon(const Ring &R, int n, const GTet
     NT_(&g.poly_item[slot], (int)((unsigned)item | ((unsigned)n << 28)));
     NT_(o, nh.x); NT_(o + P, nh.y); NT_(o + 2 * P, nh.z);
     NT_(o + 3 * P, cen.x); NT_(o + 4 * P, cen.y); NT_(o + 5 * P, cen.z);
-    NT_(o + 6 * P, tp->epsr[0]); NT_(o + 7 * P, tp->epsr[1]); NT_(o + 8 * P, tp->epsr[2]);
-    NT_(o + 9 * P, tp->epsr[3]);
+    NT_(o + 6 * P, E[0]); NT_(o + 7 * P, E[1]); NT_(o + 8 * P, E[2]);
+    NT_(o + 9 * P, E[3]);
     if (g.poly_cand) NT_(&g.poly_cand[slot], idx);
 #undef NT_
+}
+template <class Ring>
+__device__ __forceinline__ void np_keep_polygon(const Ring &R, int n, const GTetRec *tp, V3 nh, const NpArgs &g, int slot, int item,
+                                                int idx) {
+    double V[12], E[4];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) E[k] = tp->epsr[k];
+    np_keep_polygon(R, n, V, E, nh, g, slot, item, idx);
 }
 
 // Everything up to the per-item sums (regularized friction fused; bristle: normal wrench + patch moments).  For bristle
@@ -904,6 +913,15 @@ __global__ void __launch_bounds__(kNpBlock) k_clip_queue(NpArgs g) {
             const GTetRec *tp = (const GTetRec *)(it->tet + b);
             RingCol<RC> ring{poly, lane, 0};
             int n_poly = 0;
+            // the second line of the tet's record (vertices, ϵ_r2: what a kept polygon needs) is asked for NOW, a dependent gather
+            // behind the queue entry that would otherwise start after the clip and be waited for in full
+            double V[12] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, E[4] = {0.0, 0.0, 0.0, 0.0};
+            if (mine) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) V[k] = tp->xrz[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) E[k] = tp->epsr[k];
+            }
             if (mine) {
                 bool err = false;
                 n_poly = clip_ring_in_tet_coordinates(ring, 3, err);     // pfc_clip.h
@@ -913,7 +931,7 @@ __global__ void __launch_bounds__(kNpBlock) k_clip_queue(NpArgs g) {
             const unsigned long long km = __ballot(has_poly);
             const int slot = ch * C + pc + __popcll(km & below);
             pc += __popcll(km);
-            if (has_poly) np_keep_polygon(ring, n_poly, tp, nh, g, slot, item, ch * C + pos);
+            if (has_poly) np_keep_polygon(ring, n_poly, V, E, nh, g, slot, item, ch * C + pos);
             if (km) {
                 const int item_first = __builtin_amdgcn_readfirstlane(item);      // lane 0 always holds an entry here
                 if (__all(!mine || item == item_first)) {
