@@ -180,6 +180,48 @@ __device__ __forceinline__ double lds_row_sums(double *buf, const double *v, boo
 // express the input polygon (3 or 4 vertices) in the coordinates of tet 2 -> z, its normal -> nh_in, and apply the bit-exact
 // trivial reject.  Returns true if the candidate has to be clipped.  One statement for k_narrow (every mode) and
 // k_clip_queue; `report`: raise kStNonFinite for a non-finite vertex ("Non-finite vertex likely", static_clip.jl:52).
+// the arithmetic of the tri-tet front on loaded values (R21, t21: x_r2_r1; Z: x_ζ2_r2; TV, TN: the triangle's vertices and normal
+// in frame r1): one statement for np_front and for k_clip_queue, which loads a round's records one round ahead
+__device__ __forceinline__ void np_front_tri_values(const double (&R21)[9], const double (&t21)[3], const double (&Z)[16],
+                                                    const double (&TV)[9], const double (&TN)[3], double (&z)[4][4], V3 &nh_in) {
+    // x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (:204); last row of x_r2_r1.mat is (0 0 0 1)
+    double X[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
+        X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + Z[i + 12];
+    }
+    // v_k = x_ζ2_r1 * onePad(vert_k) (:205-207)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            z[k][i] = ((X[i] * TV[3 * k] + X[i + 4] * TV[3 * k + 1]) + X[i + 8] * TV[3 * k + 2]) + X[i + 12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[3][i] = 0.0;
+    // n̂2 = R(x_r2_r1) * n̂_r1 (:211-212)
+    nh_in = mk3((R21[0] * TN[0] + R21[3] * TN[1]) + R21[6] * TN[2],
+                (R21[1] * TN[0] + R21[4] * TN[1]) + R21[7] * TN[2],
+                (R21[2] * TN[0] + R21[5] * TN[1]) + R21[8] * TN[2]);
+}
+// finite check + the bit-exact trivial reject of a front's tet coordinates (see np_front)
+__device__ __forceinline__ bool np_front_accept(const double (&z)[4][4], int n_in, unsigned *status, bool report) {
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) finite &= (k >= n_in) || (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
+    if (!finite) if (report) atomicOr(status, kStNonFinite);
+    bool reject = !finite || n_in < 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0) && (n_in < 4 || z[3][i] <= 0.0);
+    if (kElim == 3) reject |= z[0][0] > -1e300;
+    return !reject;
+}
+
 template <bool TT>
 __device__ __forceinline__ bool np_front(const ItemRec *it, const WorkRec &cw, const GTetRec *tp, double (&z)[4][4], int &n_in,
                                          V3 &nh_in, unsigned *status, bool report) {
@@ -194,28 +236,13 @@ __device__ __forceinline__ bool np_front(const ItemRec *it, const WorkRec &cw, c
     if (!TT || it->tet1 == nullptr) {
         // ---- tri-tet op (non_friction.jl:196-215) -----------------------------------------------------------
         const GTriRec *tr = (const GTriRec *)(it->tri + cw.a);
-        // x_ζ2_r1 = x_ζ2_r2 * x_r2_r1.mat (:204); last row of x_r2_r1.mat is (0 0 0 1)
-        double X[16];
+        double TV[9], TN[3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int k = 0; k < 9; ++k) TV[k] = tr->v[k];
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                X[i + 4 * j] = (Z[i] * R21[3 * j] + Z[i + 4] * R21[3 * j + 1]) + Z[i + 8] * R21[3 * j + 2];
-            X[i + 12] = ((Z[i] * t21[0] + Z[i + 4] * t21[1]) + Z[i + 8] * t21[2]) + Z[i + 12];
-        }
-        // v_k = x_ζ2_r1 * onePad(vert_k) (:205-207)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                z[k][i] = ((X[i] * tr->v[3 * k] + X[i + 4] * tr->v[3 * k + 1]) + X[i + 8] * tr->v[3 * k + 2]) + X[i + 12];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[3][i] = 0.0;
+        for (int k = 0; k < 3; ++k) TN[k] = tr->n[k];
+        np_front_tri_values(R21, t21, Z, TV, TN, z, nh_in);
         n_in = 3;
-        // n̂2 = R(x_r2_r1) * n̂_r1 (:211-212)
-        nh_in = mk3((R21[0] * tr->n[0] + R21[3] * tr->n[1]) + R21[6] * tr->n[2],
-                    (R21[1] * tr->n[0] + R21[4] * tr->n[1]) + R21[7] * tr->n[2],
-                    (R21[2] * tr->n[0] + R21[5] * tr->n[1]) + R21[8] * tr->n[2]);
     } else {
         // ---- tet-tet op (non_friction.jl:166-194) -----------------------------------------------------------
         const GTetRec *t1 = (const GTetRec *)(it->tet1 + cw.a);
@@ -306,21 +333,10 @@ __device__ __forceinline__ bool np_front(const ItemRec *it, const WorkRec &cw, c
         n_in = n_q;
         nh_in = normalize(mk3(plane[0], plane[1], plane[2]));   // :190
     }
-    bool finite = true;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) finite &= (k >= n_in) || (__builtin_fabs(z[k][i]) <= 1.79769313486231570815e308);
-    if (!finite) if (report) atomicOr(status, kStNonFinite);
     // Trivial reject: if every vertex is non-positive on some plane the clip is empty.  Bit-exact shortcut:
     // every clipped vertex is c1*p2 - c2*p1 with c1 >= 0 >= c2 (static_clip.jl:197-201), whose sign on that
     // plane is exact, so Sutherland-Hodgman returns the empty polygon at that plane (:44).
-    bool reject = !finite || n_in < 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        reject |= (z[0][i] <= 0.0) && (z[1][i] <= 0.0) && (z[2][i] <= 0.0) && (n_in < 4 || z[3][i] <= 0.0);
-    if (kElim == 3) reject |= z[0][0] > -1e300;
-    return !reject;
+    return np_front_accept(z, n_in, status, report);
 }
 
 // Clip-only narrowphase: poly_r2 = mul_then_un_pad(x_r2_ζ2, poly_ζ2) (poly_eight.jl:83-98) fused with centroid(poly_r2, n̂2)
