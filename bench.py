@@ -86,13 +86,14 @@ def cpu_baseline(pfc, w, budget_s: float, n_threads: int = 1):
 
 
 def validate(pfc, w, local_ids, wrench, sdot, counts, k: int, seed: int = 7):
-    """Oracle check of k random items of what was just timed: counts bit-equal, wrench 1e-9, sdot 1e-6 (1e-3 where
-    K̄ has >= 2 near-null eigenvalues: DESIGN.md §5.7)."""
+    """Oracle check of k random items of what was just timed: counts bit-equal, wrench 1e-9, sdot 1e-6 (items whose K̄ has
+    a near-null eigenvalue: wrench 1e-6; two or more: sdot 1e-3)."""
     import numpy as np
     O, om, oi, m1, m2 = oracle_setup(pfc, w)
     rng = np.random.default_rng(seed)
     pick = rng.choice(len(local_ids), size=min(k, len(local_ids)), replace=False)
     worst_w = worst_s = 0.0
+    n_flat = 0
     for j in pick:
         g = int(local_ids[j])
         ins = int(w.ins_ids[g])
@@ -106,11 +107,20 @@ def validate(pfc, w, local_ids, wrench, sdot, counts, k: int, seed: int = 7):
                     raise AssertionError(f"validation: {name} of item {g} should be zero")
                 continue
             err = float(np.linalg.norm(np.asarray(a) - b) / nb)
-            if name == "sdot" and r.has_K:
+            if r.has_K:
+                # decompose_K! clamps eigenvalues of K̄ at 1e-16 sigma_max (friction.jl:92): along a (near-)null direction
+                # K̄^{-1/2} amplifies the last bits of K by up to 1e8, in the reference as much as here.  A flat patch has one such
+                # direction: the friction part of its wrench and its ṡ are reproducible to ~1e-8 (north_star's 1e-6 is asserted);
+                # two or more (sliver / edge contacts): ṡ to 1e-3 (tests/test_sdot_sensitivity.py).
                 Kb = np.diag(r.Sinv) @ r.K @ np.diag(r.Sinv)
                 ev = np.linalg.eigvalsh((Kb + Kb.T) / 2)
-                if np.sum(ev < 1e-12 * ev[-1]) >= 2:
+                n_null = int(np.sum(ev < 1e-12 * ev[-1]))
+                if n_null >= 1:
+                    tol = 1e-6
+                if n_null >= 2 and name == "sdot":
                     tol = 1e-3
+                if n_null >= 1 and name == "wrench":
+                    n_flat += 1
             if err >= tol:
                 raise AssertionError(f"validation: {name} of item {g} off by {err:.3e} (tolerance {tol})")
             if name == "wrench":
@@ -118,7 +128,8 @@ def validate(pfc, w, local_ids, wrench, sdot, counts, k: int, seed: int = 7):
             else:
                 worst_s = max(worst_s, err)
     return {"validated_items": int(len(pick)), "validation": "counts bit-equal; worst relative error wrench "
-            f"{worst_w:.1e}, sdot {worst_s:.1e} (CPU oracle, same inputs)"}
+            f"{worst_w:.1e}, sdot {worst_s:.1e} (CPU oracle, same inputs"
+            + (f"; {n_flat} items with a (near-)null direction of the patch stiffness held to 1e-6" if n_flat else "") + ")"}
 
 
 def small_scene_latencies(pfc, reps: int = 200):
