@@ -210,8 +210,12 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PFC_BENCH_FORCE_EXCHANGE=1: a one-rank rehearsal of the RCCL exchange on a one-GPU box (process group of size 1, the
+    # collective really issued): what a multi-GPU run does per step, minus the wire
+    force_x = os.environ.get("PFC_BENCH_FORCE_EXCHANGE") == "1"
+    if world > 1 or force_x:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -262,13 +266,13 @@ def main():
     d_sdot = torch.zeros((max(n, 1), 6), dtype=torch.float64, device=dev)
     d_counts = torch.zeros((max(n, 1), 4), dtype=torch.int32, device=dev)
     d_out = torch.zeros((max(n, 1), 12), dtype=torch.float64, device=dev)      # C3 exchange: [wrench 6 | sdot 6] per item
-    gathered = torch.zeros((world * n, 12), dtype=torch.float64, device=dev) if (world > 1 and args.config == "C3") else None
+    gathered = torch.zeros((world * n, 12), dtype=torch.float64, device=dev) if ((world > 1 or force_x) and args.config == "C3") else None
     stream = torch.cuda.current_stream().cuda_stream
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     xchg_ms = [0.0]
 
     def exchange(timed: bool):
-        if world == 1:
+        if world == 1 and not force_x:
             return
         if timed:
             ev_a.record()
@@ -286,7 +290,7 @@ def main():
             rows = P.pack_rows(d_wrench[:n], d_sdot[:n], d_counts[:n])
             if backend != "nccl":
                 rows = rows.cpu()
-            P.all_gather_rows(rows, parts, n_global)
+            P.all_gather_rows(rows, parts, n_global, force_collective=force_x)
         if timed:
             ev_b.record()
             ev_b.synchronize()
@@ -443,7 +447,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "name": args.config, "items_per_step": items_step, "ops_per_step": ops_step,
                        "node_tests_per_step": nodes_step, "traction_points_per_step": trac_step,
-                       "exchange": ("none" if world == 1 else
+                       "exchange": ("none" if (world == 1 and not force_x) else
                                     ("RCCL all-gather of [wrench, sdot] per item" if args.config == "C3" else
                                      "RCCL all-gather of [wrench | sdot | counts] rows (parallel.all_gather_rows)")
                                     if backend == "nccl" else f"REHEARSAL ({backend}, ranks share GPUs): all-gather through host memory")},
@@ -454,7 +458,7 @@ def main():
             "node_tests_per_s": nodes_step * K / dt,
             "stage_ms_per_step": {k: v / K for k, v in stage.items()},
             "exchange_ms_per_step": xchg_per_step,
-            "exchange_share": (xchg_per_step / (dt / K * 1e3)) if world > 1 else 0.0,
+            "exchange_share": (xchg_per_step / (dt / K * 1e3)) if (world > 1 or force_x) else 0.0,
             "path": {0: "fused small-scene kernel", 1: "batched", 2: "batched, two concurrent halves"}[path],
             "concurrent_parts": max(path, 1),
             "roofline": roof_np if (args.config != "C3" or np_ms >= bp_ms) else roof_bp,
@@ -479,7 +483,7 @@ def main():
                 out["cpu_baseline_multicore"] = cpu_baseline(pfc, w, args.cpu_seconds / 2, nt)
         print(json.dumps(out))
     m.close()
-    if world > 1:
+    if world > 1 or force_x:
         dist.destroy_process_group()
 
 

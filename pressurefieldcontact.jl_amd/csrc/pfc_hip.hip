@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <cstdarg>
 #include <cstdio>
@@ -333,6 +334,7 @@ struct pfc_context {
     bool in_split = false;             // this context's launches are one half of a two-half evaluation (set while they are enqueued)
     int last_parts = 1;                // 2 if the last checked evaluation ran as two halves
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join0 = nullptr;
+    int twin_queue_fallback = 0;         // make_twin: 0 the two streams run side by side as created; 1 the twin's stream was re-created with another priority because they did not; 2 they still do not
     hipStream_t twin_stream = nullptr;   // created right behind `stream` (the runtime deals streams out to its hardware queues in order of creation), handed to the twin
 };
 
@@ -944,6 +946,31 @@ int check_fused(pfc_context *h) {
     return PFC_OK;
 }
 
+// Do two streams run side by side?  The halves of a big evaluation only overlap if their streams sit on different hardware
+// queues of the runtime, which deals its few queues (four by default) out to streams by its own bookkeeping: with an RCCL
+// communicator initialised before pfc_create and no collective issued yet -- bench.py under torch.distributed.run, i.e. every
+// multi-GPU run -- both streams of a handle came to sit on ONE queue and the 8 192-pose step took 4.85 instead of 3.89 ms
+// (scripts/rccl_queue_probe.py; the kernel trace shows one queue).  Creation order, first-use order: neither is a guarantee.
+// So the pair is TESTED once per handle: a one-wave kernel on each stream spins for ~60 us and stamps its start and end with
+// the constant-rate clock; on different queues the second starts while the first still spins.
+__global__ void k_queue_probe(unsigned long long ticks, unsigned long long *out) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) { out[0] = t0; out[1] = wall_clock64(); }
+}
+bool streams_overlap(pfc_context *h, hipStream_t a, hipStream_t b) {
+    if (h->stamps.ensure(16) != hipSuccess) return true;      // cannot test: assume the best
+    unsigned long long *d = h->stamps.p;
+    unsigned long long v[4] = {0, 0, 0, 0};
+    if (hipMemsetAsync(d, 0, sizeof v, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return true;
+    hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, a, 6000ull, d);          // 100 MHz clock: 60 us
+    hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, b, 6000ull, d + 2);
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
+    if (hipMemcpyAsync(v, d, sizeof v, hipMemcpyDeviceToHost, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return true;
+    (void)hipMemsetAsync(d, 0, sizeof v, a); (void)hipStreamSynchronize(a);
+    return v[2] < v[1] && v[0] < v[3];      // each started before the other ended
+}
+
 // the second set of work buffers: shares the (immutable) mesh / instruction records of h
 int make_twin(pfc_context *h) {
     if (h->twin) return PFC_OK;
@@ -961,6 +988,21 @@ int make_twin(pfc_context *h) {
         if (t->stream) (void)hipStreamDestroy(t->stream);
         delete t;
         return fail(h, PFC_ERR_HIP, "could not create the second stream");
+    }
+    // one queue for both streams: a stream of another priority cannot share a hardware queue with a normal one (its price where
+    // the plain pair does overlap: 1 % of the step, which is why it is the fallback and not the rule)
+    h->twin_queue_fallback = 0;
+    if (!std::getenv("PFC_NO_QUEUE_TEST") && !streams_overlap(h, h->stream, t->stream)) {
+        int lo = 0, hi = 0;
+        hipStream_t s2 = nullptr;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
+            hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, hi) == hipSuccess) {
+            (void)hipStreamDestroy(t->stream);
+            t->stream = s2;
+            h->twin_queue_fallback = streams_overlap(h, h->stream, t->stream) ? 1 : 2;      // 2: still serial (reported, not fatal)
+        } else {
+            h->twin_queue_fallback = 2;
+        }
     }
     h->twin = t;
     return PFC_OK;
@@ -2362,6 +2404,9 @@ int pfc_debug_stamps(pfc_handle h, long long *out16) {
     if (h->stamps.p) HIP_TRY(h, copy_sync(h, v, h->stamps.p, sizeof v, hipMemcpyDeviceToHost));
     for (int k = 0; k < 16; ++k) out16[k] = (long long)v[k];
     out16[7] = h->last_undecided;
+#ifndef PFC_STAMPS
+    out16[6] = h->twin_queue_fallback;      // make_twin's finding about the two streams (statistics view of the product build)
+#endif
     return PFC_OK;
 }
 

@@ -53,11 +53,12 @@ def unpack_rows(rows: torch.Tensor):
 
 
 def all_gather_rows(local_rows: torch.Tensor, parts: List[np.ndarray], n_items: int,
-                    group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+                    group: Optional[dist.ProcessGroup] = None, force_collective: bool = False) -> torch.Tensor:
     """All-gather the ranks' result rows into item order.  parts[r] = item indices owned by rank r (every rank
-    knows the whole assignment, it is a pure function of the inputs)."""
+    knows the whole assignment, it is a pure function of the inputs).  force_collective: issue the collective even in a
+    process group of one rank (rehearsal of the RCCL path on a one-GPU box)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         out = torch.zeros((n_items, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
         out[torch.as_tensor(parts[0], device=local_rows.device)] = local_rows
         return out

@@ -703,3 +703,57 @@ def test_bench_two_ranks_share_the_gpu_gloo_rehearsal():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["validated_items"] >= 1 and out["validation"].startswith("counts bit-equal"), out.get("validation")
+
+
+@pytest.mark.parametrize("config", ["C5", "C3"])
+def test_bench_one_rank_rccl_exchange_rehearsal(config):
+    """The RCCL leg of the multi-GPU step on a one-GPU box: bench.py in a fresh process with a process group of ONE rank over
+    the nccl backend and PFC_BENCH_FORCE_EXCHANGE=1, so that the per-step exchange is really issued through RCCL on device
+    tensors -- parallel.all_gather_rows ([wrench | sdot | counts] rows, C5) / all_gather_into_tensor ([wrench | sdot], C3) -- with
+    the Float64 rows and shapes the multi-rank run uses.  What it cannot show is the wire."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PFC_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PFC_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", config, "--steps", "2", "--warmup", "1",
+           "--reps", "1", "--cpu-seconds", "0", "--no-extras"] + (["--poses", "1200"] if config == "C3" else [])
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["exchange"].startswith("RCCL all-gather"), out["config"]
+    assert out["exchange_ms_per_step"] > 0.0 and out["validation"].startswith("counts bit-equal")
+
+
+def test_two_halves_run_side_by_side_after_an_eager_rccl_init():
+    """The two halves of a big evaluation need two hardware queues.  With an RCCL communicator initialised eagerly before
+    pfc_create and no collective issued yet (what bench.py does under torch.distributed.run), the runtime put both streams of a
+    handle on ONE queue and the step took 25 % longer; make_twin now tests the pair (k_queue_probe) and re-creates the twin's stream
+    with another priority when they do not overlap.  scripts/rccl_queue_probe.py in fresh processes: the step after such an
+    initialisation must cost what it costs without one, and the pair must not be reported serial."""
+    import os
+    import re
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("none", "before-nocoll"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.run([sys.executable, os.path.join(root, "scripts", "rccl_queue_probe.py"), mode, "4096"], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("mode")][-1]
+        res[mode] = (float(re.search(r": ([0-9.]+) ms per step", line).group(1)), line)
+        assert "parts 2" in line and "serial" not in line, line
+    assert res["before-nocoll"][0] < 1.10 * res["none"][0], res
