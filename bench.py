@@ -267,6 +267,8 @@ def main():
     d_counts = torch.zeros((max(n, 1), 4), dtype=torch.int32, device=dev)
     d_out = torch.zeros((max(n, 1), 12), dtype=torch.float64, device=dev)      # C3 exchange: [wrench 6 | sdot 6] per item
     gathered = torch.zeros((world * n, 12), dtype=torch.float64, device=dev) if ((world > 1 or force_x) and args.config == "C3") else None
+    plan = (P.RowExchange(parts, n_global, dev, force_collective=force_x)
+            if (args.config != "C3" and backend == "nccl" and (world > 1 or force_x)) else None)
     stream = torch.cuda.current_stream().cuda_stream
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     xchg_ms = [0.0]
@@ -287,10 +289,11 @@ def main():
                 gathered.copy_(torch.cat(parts_cpu).to(dev))
         else:
             # the product exchange: per-item rows [wrench | sdot | counts] of the rank's own items -> item order, every rank
-            rows = P.pack_rows(d_wrench[:n], d_sdot[:n], d_counts[:n])
-            if backend != "nccl":
-                rows = rows.cpu()
-            P.all_gather_rows(rows, parts, n_global, force_collective=force_x)
+            if backend == "nccl":
+                plan(d_wrench, d_sdot, d_counts)         # parallel.RowExchange: buffers and the item-order index built once
+            else:
+                rows = P.pack_rows(d_wrench[:n], d_sdot[:n], d_counts[:n]).cpu()
+                P.all_gather_rows(rows, parts, n_global, force_collective=force_x)
         if timed:
             ev_b.record()
             ev_b.synchronize()

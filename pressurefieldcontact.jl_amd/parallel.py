@@ -74,6 +74,50 @@ def all_gather_rows(local_rows: torch.Tensor, parts: List[np.ndarray], n_items: 
     return out
 
 
+class RowExchange:
+    """The per-evaluation exchange with everything that does not change from one evaluation to the next done once: the
+    padded send block, the receive block, and ONE index vector that brings the gathered rows into item order (a single
+    gather instead of one scatter per rank, no host-to-device copy of indices per call).  On device tensors the call is
+    pack (wrench | sdot | counts -> rows of 16 doubles) + collective + gather: about five launches.
+
+    parts[r] = item indices owned by rank r (every rank knows the whole assignment)."""
+
+    def __init__(self, parts: List[np.ndarray], n_items: int, device, group: Optional[dist.ProcessGroup] = None,
+                 force_collective: bool = False):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert len(parts) == self.world, "one index set per rank"
+        self.collective = self.world > 1 or (force_collective and dist.is_initialized())
+        self.n_items = int(n_items)
+        self.n_mine = int(parts[self.rank].size)
+        self.n_max = max(max(int(p.size) for p in parts), 1)
+        self.device = torch.device(device)
+        src = np.zeros(self.n_items, dtype=np.int64)
+        covered = np.zeros(self.n_items, dtype=bool)
+        for r, p in enumerate(parts):
+            src[p] = r * self.n_max + np.arange(p.size)
+            covered[p] = True
+        if not covered.all():
+            raise ValueError("the partition does not cover every item")
+        self.src = torch.as_tensor(src, device=self.device)
+        self.send = torch.zeros((self.n_max, ROW), dtype=torch.float64, device=self.device)
+        self.recv = torch.zeros((self.world * self.n_max, ROW), dtype=torch.float64, device=self.device)
+
+    def __call__(self, wrench: torch.Tensor, sdot: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+        """wrench, sdot (n_mine, 6) float64, counts (n_mine, 4) int32 of the rank's own items, on the plan's device ->
+        (n_items, 16) rows [wrench | sdot | counts] in item order."""
+        n = self.n_mine
+        if n:
+            self.send[:n, 0:6] = wrench[:n]
+            self.send[:n, 6:12] = sdot[:n]
+            self.send[:n, 12:16] = counts[:n]          # int32 -> float64 in the copy (counts < 2^53 are exact)
+        if self.collective:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            return self.recv.index_select(0, self.src)
+        return self.send.index_select(0, self.src)
+
+
 def evaluate_sharded(evaluator: Callable[[np.ndarray], tuple], n_items: int, parts: Optional[List[np.ndarray]] = None,
                      device: Optional[torch.device] = None):
     """Evaluate all items across the ranks of the default process group.

@@ -253,6 +253,14 @@ assert np.array_equal(wrench, np.array([r.wrench for r in ref]))
 assert np.array_equal(counts, np.array([r.counts for r in ref]))
 w2, _, _ = pfc.parallel.evaluate_sharded(evaluator, w.n_items)        # default block partition
 assert np.array_equal(w2, wrench)
+# the planned exchange (parallel.RowExchange: what bench.py --config C4 / C5 calls per step) gives the same rows
+rank = dist.get_rank()
+plan = pfc.parallel.RowExchange(parts, w.n_items, "cpu")
+mw, ms, mc = evaluator(parts[rank])
+for _ in range(2):      # the buffers are reused from call to call
+    rows = plan(torch.as_tensor(mw), torch.as_tensor(ms), torch.as_tensor(mc.astype(np.int32)))
+    pw, ps, pc = pfc.parallel.unpack_rows(rows)
+    assert np.array_equal(pw, wrench) and np.array_equal(ps, sdot) and np.array_equal(pc, counts)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", os.environ["RANK"], "ok")
