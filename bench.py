@@ -221,6 +221,13 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if (world > 1 or force_x) and backend == "nccl":
+        # One collective before the library creates its streams: the communicator's own streams exist from here on.  (With the
+        # communicator initialised but idle the runtime put both streams of the handle on one hardware queue; the library
+        # detects and repairs that -- pfc_hip.hip, make_twin -- at 1 % of the step, this order avoids it.)
+        _t = torch.zeros(8, device=dev)
+        dist.all_reduce(_t)
+        torch.cuda.synchronize()
     import pfc_pkg
     pfc = pfc_pkg.load()
     P = pfc.parallel
@@ -265,8 +272,14 @@ def main():
     d_wrench = torch.zeros((max(n, 1), 6), dtype=torch.float64, device=dev)
     d_sdot = torch.zeros((max(n, 1), 6), dtype=torch.float64, device=dev)
     d_counts = torch.zeros((max(n, 1), 4), dtype=torch.int32, device=dev)
-    d_out = torch.zeros((max(n, 1), 12), dtype=torch.float64, device=dev)      # C3 exchange: [wrench 6 | sdot 6] per item
-    gathered = torch.zeros((world * n, 12), dtype=torch.float64, device=dev) if ((world > 1 or force_x) and args.config == "C3") else None
+    # C3 exchange: [wrench 6 | sdot 6] per item.  Two send / receive blocks: the all-gather of step k is issued asynchronously
+    # (its own RCCL stream, behind the copies into the send block) and travels while step k + 1 is evaluated; a block is reused
+    # two steps later, after its collective has been waited for, and every collective is waited for before the timed region ends.
+    x_c3 = (world > 1 or force_x) and args.config == "C3"
+    d_out = [torch.zeros((max(n, 1), 12), dtype=torch.float64, device=dev) for _ in range(2)]
+    gathered = [torch.zeros((world * n, 12), dtype=torch.float64, device=dev) for _ in range(2)] if x_c3 else None
+    pending = [None, None]
+    x_k = [0]
     plan = (P.RowExchange(parts, n_global, dev, force_collective=force_x)
             if (args.config != "C3" and backend == "nccl" and (world > 1 or force_x)) else None)
     stream = torch.cuda.current_stream().cuda_stream
@@ -279,14 +292,22 @@ def main():
         if timed:
             ev_a.record()
         if args.config == "C3":
-            d_out[:, :6] = d_wrench
-            d_out[:, 6:] = d_sdot
+            k = x_k[0] & 1
+            x_k[0] += 1
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+            d_out[k][:, :6] = d_wrench
+            d_out[k][:, 6:] = d_sdot
             if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, d_out)
+                pending[k] = dist.all_gather_into_tensor(gathered[k], d_out[k], async_op=True)
+                if timed:      # the exchange's own cost is measured with nothing beside it
+                    pending[k].wait()
+                    pending[k] = None
             else:
                 parts_cpu = [torch.empty((n, 12), dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(parts_cpu, d_out.cpu())
-                gathered.copy_(torch.cat(parts_cpu).to(dev))
+                dist.all_gather(parts_cpu, d_out[k].cpu())
+                gathered[k].copy_(torch.cat(parts_cpu).to(dev))
         else:
             # the product exchange: per-item rows [wrench | sdot | counts] of the rank's own items -> item order, every rank
             if backend == "nccl":
@@ -312,6 +333,10 @@ def main():
         exchange(timed)
 
     def fence():
+        for k in range(2):      # collectives still travelling belong to the steps before the fence
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -487,6 +512,10 @@ def main():
         print(json.dumps(out))
     m.close()
     if world > 1 or force_x:
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
