@@ -292,8 +292,18 @@ struct pfc_context {
     // what the last checked evaluation looked like: a SPARSE pile (at most a quarter of the items in contact: all pairs of a
     // pile of bodies, most of them apart) of mid-sized trees is latency-bound by the descents of its few big pairs, a dense
     // batch by throughput -- the next evaluation of the same shape is laid out accordingly (pile_mode)
-    int hint_n = 0;
-    bool hint_sparse = false;
+    // (the last four shapes: a host that alternates a few batch sizes keeps a picture of each)
+    struct ShapeHint { int n = 0; bool sparse = false; } hints[4];
+    void note_shape(int n, bool sparse) {
+        int k = 0;
+        while (k < 3 && hints[k].n != n) ++k;      // the entry of this size, or the oldest
+        for (; k > 0; --k) hints[k] = hints[k - 1];
+        hints[0].n = n; hints[0].sparse = sparse;
+    }
+    bool shape_is_sparse(int n) const {
+        for (const ShapeHint &e : hints) if (e.n == n) return e.sparse;
+        return false;
+    }
     long long last_tslots = 0;         // traction slots used by the last evaluation (>= traction points)
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
@@ -518,11 +528,11 @@ int bfs_levels_for(const pfc_context *h, int n_items, int levels) {
     return L > levels ? levels : L;
 }
 
-// A sparse pile (see hint_sparse): >= 1 024 items over small or mid-sized trees of which at most a quarter were in contact the
+// A sparse pile (see hints): >= 1 024 items over small or mid-sized trees of which at most a quarter were in contact the
 // last time this shape was evaluated.  Evaluated in ONE launch sequence with 512-thread broadphase workgroups (C5: 318 us
 // against 340 as two halves with 256-thread workgroups and a seed level; without the level 370).
 bool pile_mode(const pfc_context *h, int n_items) {
-    return h->max_leaves < 8192 && n_items >= 1024 && n_items < kBpSmallBlockMin && h->hint_n == n_items && h->hint_sparse && !h->is_twin;
+    return h->max_leaves < 8192 && n_items >= 1024 && n_items < kBpSmallBlockMin && h->shape_is_sparse(n_items) && !h->is_twin;
 }
 
 // Threads per workgroup of the depth-first broadphase kernel.  128: the halves of a big batch (throughput: the finer grain
@@ -786,7 +796,7 @@ int check_eval(pfc_context *h) {
     if (!h->split_n0) {
         h->last_parts = 1;
         const int rc0 = check_one(h);
-        if (rc0 == PFC_OK) { h->hint_n = h->last_n_items; h->hint_sparse = h->last_active * 4 <= (long long)h->last_n_items; }
+        if (rc0 == PFC_OK) h->note_shape(h->last_n_items, h->last_active * 4 <= (long long)h->last_n_items);
         return rc0;
     }
     h->last_parts = 2;
@@ -801,8 +811,7 @@ int check_eval(pfc_context *h) {
     h->stats[6] |= t->stats[6];
     h->stats[7] += t->stats[7];
     h->last_undecided += t->last_undecided;
-    h->hint_n = (int)h->stats[7];
-    h->hint_sparse = (h->last_active + t->last_active) * 4 <= h->stats[7];
+    h->note_shape((int)h->stats[7], (h->last_active + t->last_active) * 4 <= h->stats[7]);
     return PFC_OK;
 }
 

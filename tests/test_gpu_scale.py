@@ -83,6 +83,13 @@ def test_c5_pile_mode_and_wide_broadphase_workgroups(pfc):
     dense2 = m.force_all_elastic_intersections(w.pose[idx], w.twist[idx], w.s[idx], w.ins_ids[idx])
     assert m.last_parts() == 2              # ... and from its own
     assert np.array_equal(dense[2], dense2[2]) and np.array_equal(dense[2], first[2][idx])
+    # a host that alternates batch sizes keeps a picture of each (the last four shapes)
+    sub = np.arange(1500)
+    for k in range(3):
+        part = m.force_all_elastic_intersections(w.pose[sub], w.twist[sub], w.s[sub], w.ins_ids[sub])
+        assert m.last_parts() == (2 if k == 0 else 1) and np.array_equal(part[2], first[2][sub])
+        full = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        assert m.last_parts() == (2 if k == 0 else 1) and np.array_equal(full[2], first[2])
     m.close()
     w3 = pfc.configs.c3_blob_tool(24, seed=77)
     m3 = pfc.configs.build_scenario(w3)
