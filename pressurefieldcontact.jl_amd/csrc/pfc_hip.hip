@@ -827,13 +827,15 @@ bool fused_ok(const pfc_context *h, int n_items) {
 // 9 680-tet x 5 120-triangle pair): as many workgroups per item as keep every workgroup of the launch resident (one per CU),
 // at most kTeamMaxWg; 0: not a team evaluation.
 // Small scenes (fused_ok): 1 -- unless the items are few and mid-sized (a 972-tet box on the ground keeps ONE CU busy for
-// 52 us, a third of it dealing 1 100 fan triangles out to 256 threads): then a small team, one workgroup per 256 leaves of
-// the pair, at most 8 (C2 64 -> 48 us, four reduced C3 poses 106 -> 81 us; a team of 2 loses to its own team sum).
+// 52 us, a third of it dealing 1 100 fan triangles out to 256 threads): then a small team, one workgroup per 128 leaves of
+// the pair, at most 32 (C2 64 -> 48 us, four reduced C3 poses 106 -> 81 us; a team of 2 loses to its own team sum).
 int fused_team(const pfc_context *h, int n_items) {
     const int blocks = h->n_cu < kTeamMaxBlocks ? h->n_cu : kTeamMaxBlocks;      // (a partitioned device has fewer CUs)
     if (fused_ok(h, n_items)) {
-        int nw = (h->max_leaves + 128) / 256;
-        if (nw > 8) nw = 8;
+        // (end of round 3, scripts/variants/team_cap_run.py: a workgroup per 128 leaves, at most 32 -- a 4 880-leaf pair alone
+        // 94 -> 82 us, four of them 132 -> 86, sixteen 148 -> 94; 2 000-leaf pairs 84 -> 79 (x 4), 88 -> 80 (x 16); C2 unchanged)
+        int nw = (h->max_leaves + 64) / 128;
+        if (nw > 32) nw = 32;
         if (n_items >= 1 && nw > blocks / n_items) nw = blocks / n_items;
         if (nw > h->opt_team) nw = h->opt_team;
         return nw >= 4 ? nw : 1;
@@ -844,7 +846,12 @@ int fused_team(const pfc_context *h, int n_items) {
     int nw = blocks / n_items;
     if (nw > kTeamMaxWg) nw = kTeamMaxWg;
     if (nw > h->opt_team) nw = h->opt_team;
-    return nw >= 4 ? nw : 0;
+    // A team pays while each of its workgroups has at most ~720 leaves of the pair to descend; beyond that the batched path with
+    // its 512-thread broadphase workgroups is faster (scripts/team_vs_batched.py, team_rule_sweep.py; full-size C3 poses, 14 800
+    // leaves: 8 in teams of 32 114 us against 172 batched, 12 in teams of 21 168 against 190, but 16 in teams of 16 225 against
+    // 204, 32 in teams of 8 378 against 231, 64 in teams of 4 488 against 289 -- the rule until the end of round 3 was "teams of
+    // at least 4"; a 7 380-leaf pair: 16 poses in teams of 16 101 against 189, a 10 400-leaf pair: 16 in teams of 16 165 against 186).
+    return (nw >= 4 && h->max_leaves <= 720 * nw) ? nw : 0;
 }
 
 int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,

@@ -36,7 +36,7 @@ def test_fused_regularized_configs(pfc, config):
     m, (wrench, sdot, counts) = _run(pfc, w)
     assert m.last_parts() == 0, "the fused kernel did not run"
     # a lone mid-sized item (C2: 972 tets) takes a small team of workgroups, many items (C4) or tiny ones (C1) one each
-    assert m.last_team() == {"c1": 1, "c2": 4, "c4": 1}[config]
+    assert m.last_team() == {"c1": 1, "c2": 8, "c4": 1}[config]      # a workgroup per 128 leaves of the pair
     _against_oracle(pfc, w, wrench, sdot, counts)
     st = m.stats()
     assert st["candidates"] == int(counts[:, 1].sum()) and st["node_tests"] == int(counts[:, 0].sum())
@@ -51,7 +51,7 @@ def test_fused_bristle(pfc, n_quad):
     w = pfc.configs.c3_blob_tool(12, n_div_blob=8, n_div_tool=6)
     w.instructions[0].n_quad_rule = n_quad
     m, (wrench, sdot, counts) = _run(pfc, w)
-    assert m.last_parts() == 0 and m.last_team() == 8        # 12 items of 2 000 leaves: teams of 8
+    assert m.last_parts() == 0 and m.last_team() == 16       # 12 items of 2 000 leaves: teams of 16
     _against_oracle(pfc, w, wrench, sdot, counts)
     assert np.count_nonzero(counts[:, 3]) >= 6
     m.set_option("team", 0)                                   # a workgroup per item: the same integers
@@ -110,7 +110,7 @@ def test_fused_item_that_does_not_fit_falls_back(pfc):
     # with a team of workgroups per item (round 3) every workgroup holds its own share of the candidates: the scene fits
     mt, (wrench, sdot, counts) = _run(pfc, w)
     assert counts[:, 1].max() > 4096, counts[:, 1]
-    assert mt.last_parts() == 0 and mt.last_team() == 8
+    assert mt.last_parts() == 0 and mt.last_team() == 16
     for k, r in enumerate(ref):
         assert np.array_equal(counts[k], r.counts)
         assert H.rel_err(wrench[k], r.wrench) < TOL
@@ -309,7 +309,7 @@ def test_small_teams_on_tet_tet_and_mixed_items(pfc, model):
     out: everything stays with rank 0)."""
     w = pfc.configs.vol_vol(3, n_div=8, model=model)
     m, (wrench, sdot, counts) = _run(pfc, w)
-    assert m.last_parts() == 0 and m.last_team() == 8
+    assert m.last_parts() == 0 and m.last_team() == 20       # 2 560 leaves: a workgroup per 128
     _against_oracle(pfc, w, wrench, sdot, counts)
     assert np.count_nonzero(counts[:, 3]) >= 4
     m.set_option("team", 0)
