@@ -300,23 +300,38 @@ __device__ __forceinline__ void final_item(const BrArgs &g, int i) {
         for (int k = 0; k < 6; ++k) { w[k] = contact ? aw[k] : 0.0; sd[k] = 0.0; }
         return;
     }
-    for (int k = 0; k < 6; ++k) { w[k] = 0.0; sd[k] = 0.0; }
     const double tau_inv = 1.0 / it->tau;
     if (!contact) {
-        for (int k = 0; k < 6; ++k) sd[k] = -tau_inv * it->s[k];
+        double s0[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s0[k] = it->s[k];
+        for (int k = 0; k < 6; ++k) { w[k] = 0.0; sd[k] = -tau_inv * s0[k]; }
         return;
     }
-    V3 fang = ld3(a + kAccFric), flin = ld3(a + kAccFric + 3), cop = ld3(r + kResCop);
-    V3 fang2 = fang + cross(cop, flin);
-    w[0] = aw[0] + fang2.x; w[1] = aw[1] + fang2.y; w[2] = aw[2] + fang2.z;
-    w[3] = aw[3] + flin.x; w[4] = aw[4] + flin.y; w[5] = aw[5] + flin.z;
-    double sw[6];
-    for (int k = 0; k < 6; ++k) sw[k] = r[kResSinv + k] * a[kAccFric + k];
+    // every operand is in registers before the first store (the outputs are plain double pointers: behind a store the compiler
+    // must re-issue what it could otherwise have fetched in one go -- the 6 x 6 product below was six dependent round trips)
+    double fr[6], sinv[6], kis[36], s0[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { fr[k] = a[kAccFric + k]; sinv[k] = r[kResSinv + k]; s0[k] = it->s[k]; }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) kis[k] = r[kResKis + k];
+    const V3 cop = ld3(r + kResCop);
+    const V3 fang = mk3(fr[0], fr[1], fr[2]), flin = mk3(fr[3], fr[4], fr[5]);
+    const V3 fang2 = fang + cross(cop, flin);
+    double sw[6], sdv[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sw[k] = sinv[k] * fr[k];
+#pragma unroll
     for (int ii = 0; ii < 6; ++ii) {
         double acc = 0.0;
-        for (int k = 0; k < 6; ++k) acc += r[kResKis + ii + 6 * k] * sw[k];
-        sd[ii] = -tau_inv * (acc + it->s[ii]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc += kis[ii + 6 * k] * sw[k];
+        sdv[ii] = -tau_inv * (acc + s0[ii]);
     }
+    w[0] = aw[0] + fang2.x; w[1] = aw[1] + fang2.y; w[2] = aw[2] + fang2.z;
+    w[3] = aw[3] + flin.x; w[4] = aw[4] + flin.y; w[5] = aw[5] + flin.z;
+#pragma unroll
+    for (int ii = 0; ii < 6; ++ii) sd[ii] = sdv[ii];
 }
 
 // k_final: the per-item epilogue, and -- in block 0, after its own items -- the packing of everything the host needs
@@ -342,10 +357,22 @@ __global__ void __launch_bounds__(128) k_final(BrArgs g) {
         if (tid < g.n_ctr) c0 = g.ctr[tid];
         if (tid + 128 < g.n_ctr) c1 = g.ctr[tid + 128];
         if (tid < kRgn) { r0 = g.rgn[tid * kRgnStride]; r1 = g.rgn[tid * kRgnStride + 1]; }
-        for (int k = tid; k < g.n_items; k += blockDim.x) {
-            a += (unsigned)g.icnt[4 * (size_t)k]; b += (unsigned)g.icnt[4 * (size_t)k + 2]; c += (unsigned)g.icnt[4 * (size_t)k + 3];
-            d += (unsigned)g.icnt[4 * (size_t)k] > 1u ? 1ull : 0ull;      // items whose root pair overlapped (pile_mode's hint)
+        // (one 16-byte load per item, eight items in flight per thread: as a plain loop of three 4-byte loads per item this
+        // was a chain of n_items / 128 dependent round trips -- 16 us of the 22 us kernel at 2 016 items)
+        const int4 *ic = reinterpret_cast<const int4 *>(g.icnt);
+        auto tally = [&](const int4 &v) {
+            a += (unsigned)v.x; b += (unsigned)v.z; c += (unsigned)v.w;
+            d += (unsigned)v.x > 1u ? 1ull : 0ull;      // items whose root pair overlapped (pile_mode's hint)
+        };
+        int k = tid;
+        for (; k + 7 * 128 < g.n_items; k += 8 * 128) {
+            int4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ic[k + u * 128];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tally(v[u]);
         }
+        for (; k < g.n_items; k += 128) tally(ic[k]);
         if (tid < 4) tot[tid] = 0ull;
         if (tid < 2) rtot[tid] = 0;
     }
