@@ -637,7 +637,9 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         // a half of a two-half evaluation clips on the compacted ring (MODE 3, 12 KiB of LDS per wave: shares the CUs with the
         // other half's kernels), a launch that has the chip to itself on a column per lane (MODE 2)
         // (and a launch that does not quite fill the chip: 768 poses 0.72 vs 0.74 ms; 512 poses the other way, 0.63 vs 0.62)
-        if (h->opt_clip_queue && !h->any_tet_tet && (h->in_split || n_items >= 1024 || h->opt_clip_queue > 1)) {
+        // (end of round 3, with the kernel's earlier gather: every clip-only tri-tet launch -- 900 poses 802 -> 767 us, 1 000:
+        // 858 -> 824, 520 ... 800 poses equal within 1 %; scripts/sweep_clip_queue_min.py.  Before: from 1 024 items or as a half.)
+        if (h->opt_clip_queue && !h->any_tet_tet) {
             // big tri-tet launches: survivors of the trivial reject queued in the ring, clipped 64 at a time (8 192-pose step
             // 4.17 -> 4.13 ms as two halves, 4.87 -> 4.70 ms unsplit, 2 048 poses 1.288 -> 1.278; 768 poses lose, 0.712 -> 0.721:
             // paired A/B, profiles/r03_ab_clip_queue.txt; option value 2 forces it for every clip-only launch: tests)
