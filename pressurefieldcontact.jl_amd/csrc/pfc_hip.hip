@@ -338,7 +338,7 @@ struct pfc_context {
     int fu_ndir = 0;
     bool pending_fused = false, last_fused = false;
     int opt_split_min = 1025;          // 0: never split.  (Paired sweeps at the end of round 2: 1 024 poses -- one seed per resident broadphase workgroup -- 0.80 ms unsplit / 0.90 split; 1 100 0.95 / 0.93, 1 280 1.09 / 1.01, 2 048 1.50 / 1.28.)
-    int opt_clip_min = 512;            // items per launch from which the narrowphase runs as clip-only kernel + k_integ; 0: never.  (First set at 1 024 from scripts/sweep_clip.sh; a paired sweep with the final kernels: 512 poses 0.61 vs 0.63 ms, 768 0.80 vs 0.83, 1 536 as 2 x 768 1.14 vs 1.19, 1 920 1.33 vs 1.40; 384 poses and below are indifferent.)
+    int opt_clip_min = 384;            // items per launch from which the narrowphase runs as clip-only kernel + k_integ; 0: never.  (End of round 3, k_clip_queue for every such launch, scripts/sweep_clip_min.py: full-size C3 poses 256: 405 vs 405 us one-kernel / split, 400: 518 vs 502, 511: 598 vs 568; 400 box-on-plane scenes 120 vs 123 -- 384, was 512.)  (First set at 1 024 from scripts/sweep_clip.sh; a paired sweep with the final kernels: 512 poses 0.61 vs 0.63 ms, 768 0.80 vs 0.83, 1 536 as 2 x 768 1.14 vs 1.19, 1 920 1.33 vs 1.40; 384 poses and below are indifferent.)
     int opt_poison = 0;                // diagnostic: fill (re)allocated work lists with 0xFF bytes (item index -1)
     int split_n0 = 0;                  // items in the first half of the pending evaluation (0: not split)
     bool in_split = false;             // this context's launches are one half of a two-half evaluation (set while they are enqueued)
