@@ -88,6 +88,13 @@ struct EvalArgs {
 
 __global__ void k_setup_items(EvalArgs g) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    {   // the accumulators of the workgroup's items, cleared with consecutive lanes on consecutive doubles (44 stores of 512
+        // contiguous bytes per wave instead of 44 stores to 64 different cache lines each)
+        const int i0 = blockIdx.x * blockDim.x;
+        const int n_here = g.n_items - i0 < (int)blockDim.x ? g.n_items - i0 : (int)blockDim.x;
+        double *a0 = g.acc + (size_t)i0 * kAccStride;
+        for (int k = threadIdx.x; k < n_here * kAccStride; k += blockDim.x) a0[k] = 0.0;
+    }
     if (i >= g.n_items) return;
     int id = g.ins_ids ? g.ins_ids[i] : i;
     ItemRec r;
@@ -130,9 +137,7 @@ __global__ void k_setup_items(EvalArgs g) {
     // depth-first kernel can start a seed without reading the two nodes first
     w.item = i; w.a = 0; w.b = 0; w.pad = (m1.n_node == 1 ? 1 : 0) | (m2.n_node == 1 ? 2 : 0);
     g.frontier0[i] = w;
-    for (int k = 0; k < kAccStride; ++k) g.acc[(size_t)i * kAccStride + k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) g.icnt[4 * (size_t)i + k] = 0;
+    *reinterpret_cast<int4 *>(g.icnt + 4 * (size_t)i) = make_int4(0, 0, 0, 0);
     if (i == 0) g.fcount[0] = g.n_items;
 }
 
@@ -568,7 +573,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     ea.ins = h->d_ins; ea.meshes = h->d_meshes; ea.n_ins = (int)h->ins.size(); ea.items = h->items.p;
     ea.frontier0 = h->frontier[0].p; ea.fcount = fcount; ea.acc = h->acc.p; ea.icnt = h->icnt.p;
     ea.status = h->status.p;
-    hipLaunchKernelGGL(k_setup_items, dim3(grid_for(n_items, 128, 1 << 20)), dim3(128), 0, st, ea);
+    hipLaunchKernelGGL(k_setup_items, dim3(grid_for(n_items, 64, 1 << 20)), dim3(64), 0, st, ea);
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_SETUP], st));
 
     // broadphase: a few level-synchronous expansions to get enough independent seed pairs, then the per-wave
