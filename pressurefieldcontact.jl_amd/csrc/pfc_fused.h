@@ -71,11 +71,13 @@ struct FuArgs {
     // Teams (k_fused<.., true>, round 3): nw workgroups per item -- blockIdx.x = item * nw + rank.  team: per (workgroup,
     // phase) 2 kTeamSlots 8-byte granules {32 data bits, 32-bit tag = seq} of partial sums (team_sum).
     int nw;
+    int team_seeds;     // the descent of a team is shared out once a level holds this many pairs per workgroup (kTeamSeeds / kTeamSeedsBig)
     unsigned long long *team;
 };
 constexpr int kTeamSlots = 48;           // doubles a workgroup publishes per phase (first phase: 10 sums, 4 counters, status, 27 moments, their reference point)
 constexpr int kTeamMaxWg = 48;           // workgroups per item at most
 constexpr int kTeamMaxBlocks = 256;      // item * nw + rank < this (one workgroup per CU: every workgroup of a launch is resident)
+constexpr int kTeamSeedsBig = 32;        // the same for pairs too big for one workgroup: 12 full-size C3 poses 170 -> 144 us, 8: 114 -> 108, 16 poses of a 7 380-leaf pair 101 -> 92 (mid-sized pairs lose with it: four 4 880-leaf pairs 82 -> 93 us)
 constexpr int kTeamSeeds = 16;           // the descent is shared out once a level holds this many pairs per workgroup ...
 constexpr int kTeamShareMax = 768;       // ... or this many in all: its children (four per pair at most) still fit the stack above it
 constexpr int kTeamSpinMax = 1 << 15;    // bounded wait for the team (a poll is ~2 us: ~65 ms): if a workgroup never arrives -- teams of several handles
@@ -340,7 +342,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         // three of them: 270 us, slower than the batched path.)
         bool bfs = MW;
         int lo = 0, hi = MW ? 1 : 0, hi0 = hi;      // the level: stk[lo, hi); its children from hi0 on
-        const int t_share = nw * kTeamSeeds < kTeamShareMax ? nw * kTeamSeeds : kTeamShareMax;
+        const int t_share = nw * g.team_seeds < kTeamShareMax ? nw * g.team_seeds : kTeamShareMax;
         for (int guard = 0; (bfs ? hi > lo : sp > 0) && guard < (1 << 22); ++guard) {
             unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0; (void)u0; (void)u1; (void)u2; (void)u3; (void)u4;
             STAMP(u0);

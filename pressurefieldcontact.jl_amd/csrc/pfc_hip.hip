@@ -853,12 +853,13 @@ int fused_team(const pfc_context *h, int n_items) {
     int nw = blocks / n_items;
     if (nw > kTeamMaxWg) nw = kTeamMaxWg;
     if (nw > h->opt_team) nw = h->opt_team;
-    // A team pays while each of its workgroups has at most ~720 leaves of the pair to descend; beyond that the batched path with
-    // its 512-thread broadphase workgroups is faster (scripts/team_vs_batched.py, team_rule_sweep.py; full-size C3 poses, 14 800
-    // leaves: 8 in teams of 32 114 us against 172 batched, 12 in teams of 21 168 against 190, but 16 in teams of 16 225 against
-    // 204, 32 in teams of 8 378 against 231, 64 in teams of 4 488 against 289 -- the rule until the end of round 3 was "teams of
-    // at least 4"; a 7 380-leaf pair: 16 poses in teams of 16 101 against 189, a 10 400-leaf pair: 16 in teams of 16 165 against 186).
-    return (nw >= 4 && h->max_leaves <= 720 * nw) ? nw : 0;
+    // A team pays while each of its workgroups has at most ~1 200 leaves of the pair to descend; beyond that the batched path with
+    // its 512-thread broadphase workgroups is faster (scripts/team_vs_batched.py, team_rule_sweep.py, profiles/r03_team_rules.txt;
+    // full-size C3 poses, 14 800 leaves: 8 in teams of 32 109 us against 172 batched, 16 in teams of 16 166 against 200, 20 in
+    // teams of 12 203 against 212, but 24 in teams of 10 283 against 230; a 10 400-leaf pair: 24 in teams of 10 136 against 210;
+    // a 7 380-leaf pair: 32 in teams of 8 137 against 188).  Until the end of round 3 the rule was "teams of at least 4", which
+    // ran 64 full-size poses in teams of 4: 488 us against 289.
+    return (nw >= 4 && h->max_leaves <= 1200 * nw) ? nw : 0;
 }
 
 int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
@@ -900,6 +901,7 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
     a.stamps = h->stamps.p;
 #endif
     a.nw = h->fu_nw; a.team = nullptr;
+    a.team_seeds = h->max_leaves > kFusedMaxLeaves ? kTeamSeedsBig : kTeamSeeds;
     h->last_fu_nw = a.nw;
     if (a.nw > 1) {
         if (!h->team.p) {

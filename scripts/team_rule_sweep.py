@@ -2,7 +2,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pfc_pkg
 pfc = pfc_pkg.load()
-for nb, nt, ns in ((15, 12, (8, 12, 16, 20, 24, 32)), (18, 14, (8, 12, 16, 20)), (22, 16, (8, 10, 11, 12))):
+for nb, nt, ns in ((15, 12, (8, 16, 24, 32, 48)), (18, 14, (8, 16, 24, 32)), (22, 16, (8, 12, 16, 20, 24, 32))):
     for n in ns:
         w = pfc.configs.c3_blob_tool(n, seed=31, n_div_blob=nb, n_div_tool=nt)
         res = []
