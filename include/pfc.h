@@ -213,21 +213,26 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
  * resolver; same candidate set, for A/B checks), "split_min" (default 1025; 0 = never: an evaluation of at least
  * this many items with ins_ids given is run as two concurrent halves on two streams with their own work lists, the
  * vector-ALU-bound broadphase of one half sharing the CUs with the latency-bound narrowphase of the other; results,
- * counters and stream ordering are those of the unsplit call), "dual_reuse" (default 1: pfc_eval_dual compares the
+ * counters and stream ordering are those of the unsplit call; a SPARSE PILE -- at least 1 024 items over small or mid-sized
+ * trees of which at most a quarter were in contact the last time the handle evaluated that many items -- runs as one launch
+ * sequence with wider broadphase workgroups instead: pfc_last_parts() tells; the two streams of a handle are tested once for
+ * running side by side -- environment PFC_NO_QUEUE_TEST=1 skips the test), "dual_reuse" (default 1: pfc_eval_dual compares the
  * value inputs of a call above the small-scene limits with those of the previous call and, if they are bitwise equal,
- * runs only the Dual passes on the previous call's value pass -- the chunks of one Jacobian), "clip_min" (default 512; 0 = never: a launch of at
+ * runs only the Dual passes on the previous call's value pass -- the chunks of one Jacobian), "clip_min" (default 384; 0 = never: a launch of at
  * least this many items runs the narrowphase as a clip-only kernel that keeps every clipped polygon, followed by the
  * integration over the compacted polygons; same results up to the order of the sums), "poison" (diagnostic, default 0: before every
  * evaluation the work lists are filled with entries whose item index is -1; the kernels never follow an item index
  * out of range but report it, PFC_ERR_STATE "a work-list slot was read before it was written"), "fused" (default 1:
  * an evaluation of <= 256 items over small trees runs as ONE kernel, one workgroup per item, instead of the batched
  * launch sequence -- the scene sizes Radau evaluates, src/radau/radau_functions.jl:2-14,64-70; same results; 0 = always
- * batched; the debug / profile options imply the batched path), "clip_queue" (default 1: the clip-only kernel of a big
+ * batched; the debug / profile options imply the batched path), "clip_queue" (default 1: the clip-only kernel of a
  * tri-tet launch queues the candidates that pass the trivial reject in its polygon ring and clips 64 of them at a time;
  * 0 = the lane-per-candidate clip rounds; same results bit for bit), "team" (default 48, at most 64; 0 = never: an evaluation of a few
  * pairs too big for one workgroup -- BASELINE's single 9 680-tet x 5 120-triangle pair -- runs as ONE kernel with a team
- * of up to this many workgroups per item, and a lone mid-sized item -- a 972-tet box on the ground -- with a small team (one
- * workgroup per 256 leaves, at most 8); same results up to the order of the sums; pfc_last_team().  Team-mates wait for
+ * of up to this many workgroups per item -- while a workgroup of the team has at most ~1 200 leaves of the pair to descend: up
+ * to 16 poses of that pair; beyond that the batched path is faster --, and a few mid-sized items -- a 972-tet box on the
+ * ground -- with a small team each (one workgroup per 128 leaves, at most 32); same results up to the order of the sums;
+ * pfc_last_team().  Team-mates wait for
  * each other inside the launch: several handles evaluating such scenes at the same moment on one device may each get
  * only part of a team resident; the wait is bounded (~65 ms), the evaluation is then re-issued on the batched path). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);
