@@ -227,6 +227,13 @@ struct pfc_context {
     size_t h_tail_cap = 0;
     void *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-buffer path
     size_t pin_in_cap = 0, pin_out_cap = 0;
+    // Inputs of a very small scene written by the host straight into DEVICE memory (fine-grained allocation, reachable through
+    // the PCIe BAR when the device has a large one): the one-launch kernel's first two dependent reads -- instruction id, then
+    // the instruction's record -- start from HBM instead of from host memory (scripts/micro/bar_probe.hip: launch + two
+    // dependent reads + completion word 7.5 -> 6.2 us).  Host stores into it are write-combined: written once per evaluation,
+    // never read back; they leave the core with the locked update of the queue's write index that every launch begins with.
+    void *bar_in = nullptr;
+    int bar_state = 0;                            // 0: not probed, 1: in use, -1: no large BAR / allocation failed / PFC_NO_BAR_INPUTS
     void *pin_din = nullptr, *pin_dout = nullptr; // pinned blocks of the small-scene Dual path (partials in / out)
     size_t pin_din_cap = 0, pin_dout_cap = 0;
     long long dual_hint = -1;                     // contributing pairs of the last Dual evaluation (-1: none yet)
@@ -1109,6 +1116,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->dgexec) (void)hipGraphExecDestroy(h->dgexec);
     if (h->h_tail) (void)hipHostFree(h->h_tail);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->bar_in) (void)hipFree(h->bar_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_din) (void)hipHostFree(h->pin_din);
     if (h->pin_dout) (void)hipHostFree(h->pin_dout);
@@ -1537,7 +1545,19 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
         HIP_TRY(h, h->tail.ensure(t0 + out_bytes / sizeof(int) + 4));   // only ever grows; ensure_work asks for less
         if (h->tail.cap != cap0) ++h->epoch;                   // captured graphs hold the old address
     }
-    double *pi = (double *)h->pin_in;
+    // (up to kBarItems items: beyond that the write-combined stores cost the host more than the kernel gains)
+    constexpr size_t kBarItems = 16;
+    if (h->bar_state == 0) {
+        int large_bar = 0;
+        h->bar_state = -1;
+#if defined(__x86_64__)      // the ordering argument above (a locked instruction drains the write-combining buffers) is x86's
+        if (!std::getenv("PFC_NO_BAR_INPUTS") && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess &&
+            large_bar && hipExtMallocWithFlags(&h->bar_in, kBarItems * (36 * sizeof(double) + sizeof(int)), hipDeviceMallocFinegrained) == hipSuccess)
+            h->bar_state = 1;
+#endif
+    }
+    const bool bar = h->bar_state == 1 && n <= kBarItems && !h->want_surv;
+    double *pi = bar ? (double *)h->bar_in : (double *)h->pin_in;
     std::memcpy(pi, pose, sizeof(double) * n * 24);
     std::memcpy(pi + n * 24, twist, sizeof(double) * n * 6);
     if (s) std::memcpy(pi + n * 30, s, sizeof(double) * n * 6); else std::memset(pi + n * 30, 0, sizeof(double) * n * 6);
@@ -1548,8 +1568,8 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     const bool zero_copy = n_items <= 512 && !h->want_surv;
     double *di = h->h_pose.p, *dout = reinterpret_cast<double *>(h->tail.p + t0);
     if (zero_copy) {
-        void *dpi = nullptr, *dpo = nullptr;
-        HIP_TRY(h, hipHostGetDevicePointer(&dpi, h->pin_in, 0));
+        void *dpi = h->bar_in, *dpo = nullptr;
+        if (!bar) HIP_TRY(h, hipHostGetDevicePointer(&dpi, h->pin_in, 0));
         HIP_TRY(h, hipHostGetDevicePointer(&dpo, h->pin_out, 0));
         di = (double *)dpi;
         dout = reinterpret_cast<double *>((int *)dpo + t0);
