@@ -1545,8 +1545,9 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
         HIP_TRY(h, h->tail.ensure(t0 + out_bytes / sizeof(int) + 4));   // only ever grows; ensure_work asks for less
         if (h->tail.cap != cap0) ++h->epoch;                   // captured graphs hold the old address
     }
-    // (up to kBarItems items: beyond that the write-combined stores cost the host more than the kernel gains)
-    constexpr size_t kBarItems = 16;
+    // (every evaluation whose kernels read the inputs in place, i.e. up to 512 items: 64 box-on-plane scenes 52.2 -> 48.7 us, C4's
+    // 256 66.5 -> 64.5, 128 full-size poses on the batched path 333 -> 328; scripts/variants/bar_items_run.py)
+    constexpr size_t kBarItems = 512;
     if (h->bar_state == 0) {
         int large_bar = 0;
         h->bar_state = -1;
