@@ -233,6 +233,7 @@ struct pfc_context {
     // dependent reads + completion word 7.5 -> 6.2 us).  Host stores into it are write-combined: written once per evaluation,
     // never read back; they leave the core with the locked update of the queue's write index that every launch begins with.
     void *bar_in = nullptr;
+    void *bar_din = nullptr;                      // the same for the seeds of a small-scene Dual evaluation (up to kBarKeys (item, direction) pairs)
     int bar_state = 0;                            // 0: not probed, 1: in use, -1: no large BAR / allocation failed / PFC_NO_BAR_INPUTS
     void *pin_din = nullptr, *pin_dout = nullptr; // pinned blocks of the small-scene Dual path (partials in / out)
     size_t pin_din_cap = 0, pin_dout_cap = 0;
@@ -1117,6 +1118,7 @@ void pfc_destroy(pfc_handle h) {
     if (h->h_tail) (void)hipHostFree(h->h_tail);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->bar_in) (void)hipFree(h->bar_in);
+    if (h->bar_din) (void)hipFree(h->bar_din);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_din) (void)hipHostFree(h->pin_din);
     if (h->pin_dout) (void)hipHostFree(h->pin_dout);
@@ -1508,6 +1510,35 @@ int pfc_check(pfc_handle h) {
     return PFC_OK;
 }
 
+// BAR-resident input blocks (pfc_context::bar_in): allocated on first use if the device has a large BAR.
+constexpr size_t kBarItems = 512;      // items whose value inputs go there: every evaluation whose kernels read them in place
+constexpr size_t kBarKeys = 64;        // (item, direction) pairs whose Dual seeds go there (18 KiB of write-combined stores)
+static bool bar_ready(pfc_context *h) {
+    if (h->bar_state == 0) {
+        h->bar_state = -1;
+#if defined(__x86_64__)      // the ordering argument (a locked instruction drains the write-combining buffers) is x86's
+        int large_bar = 0;
+        if (!std::getenv("PFC_NO_BAR_INPUTS") && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess &&
+            large_bar && hipExtMallocWithFlags(&h->bar_in, kBarItems * (36 * sizeof(double) + sizeof(int)), hipDeviceMallocFinegrained) == hipSuccess) {
+            if (hipExtMallocWithFlags(&h->bar_din, kBarKeys * 36 * sizeof(double), hipDeviceMallocFinegrained) == hipSuccess) h->bar_state = 1;
+            else { (void)hipFree(h->bar_in); h->bar_in = nullptr; }
+        }
+#endif
+    }
+    return h->bar_state == 1;
+}
+// The device-visible address of a pinned input block the host has just filled: its copy in BAR-resident device memory if it
+// fits there (slot 0: value inputs, slot 1: Dual seeds), else the pinned block itself.  The pinned block stays the host's copy
+// (the Dual paths compare the next call's inputs with it).
+static void bar_mirror(pfc_context *h, void **dev, const void *pinned, size_t bytes, int slot) {
+    if (!bar_ready(h)) return;
+    void *dst = slot == 0 ? h->bar_in : h->bar_din;
+    const size_t cap = slot == 0 ? kBarItems * (36 * sizeof(double) + sizeof(int)) : kBarKeys * 36 * sizeof(double);
+    if (bytes > cap) return;
+    std::memcpy(dst, pinned, bytes);
+    *dev = dst;
+}
+
 // pinned staging block of at least `bytes` (grown with slack, never shrunk)
 static hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes) {
     if (*cap >= bytes) return hipSuccess;
@@ -1547,17 +1578,7 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     }
     // (every evaluation whose kernels read the inputs in place, i.e. up to 512 items: 64 box-on-plane scenes 52.2 -> 48.7 us, C4's
     // 256 66.5 -> 64.5, 128 full-size poses on the batched path 333 -> 328; scripts/variants/bar_items_run.py)
-    constexpr size_t kBarItems = 512;
-    if (h->bar_state == 0) {
-        int large_bar = 0;
-        h->bar_state = -1;
-#if defined(__x86_64__)      // the ordering argument above (a locked instruction drains the write-combining buffers) is x86's
-        if (!std::getenv("PFC_NO_BAR_INPUTS") && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess &&
-            large_bar && hipExtMallocWithFlags(&h->bar_in, kBarItems * (36 * sizeof(double) + sizeof(int)), hipDeviceMallocFinegrained) == hipSuccess)
-            h->bar_state = 1;
-#endif
-    }
-    const bool bar = h->bar_state == 1 && n <= kBarItems && !h->want_surv;
+    const bool bar = n <= kBarItems && !h->want_surv && bar_ready(h);
     double *pi = bar ? (double *)h->bar_in : (double *)h->pin_in;
     std::memcpy(pi, pose, sizeof(double) * n * 24);
     std::memcpy(pi + n * 24, twist, sizeof(double) * n * 6);
@@ -1694,6 +1715,8 @@ int eval_dual_fused(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     HIP_TRY(h, hipHostGetDevicePointer(&v_out, h->pin_out, 0));
     HIP_TRY(h, hipHostGetDevicePointer(&v_din, h->pin_din, 0));
     HIP_TRY(h, hipHostGetDevicePointer(&v_dout, h->pin_dout, 0));
+    bar_mirror(h, &v_in, h->pin_in, in_bytes, 0);
+    bar_mirror(h, &v_din, h->pin_din, sizeof(double) * nk * 30, 1);
     double *di = (double *)v_in, *dout = (double *)v_out, *ddi = (double *)v_din, *ddo = (double *)v_dout;
     h->fout_dev = reinterpret_cast<int *>(dout + out_d) + n * 4;
     h->fout_host = reinterpret_cast<const int *>((const double *)h->pin_out + out_d) + n * 4;
@@ -1765,6 +1788,8 @@ int eval_dual_hybrid(pfc_context *h, int n_items, int n_dir, const int *ins_ids,
     HIP_TRY(h, hipHostGetDevicePointer(&v_out, h->pin_out, 0));
     HIP_TRY(h, hipHostGetDevicePointer(&v_din, h->pin_din, 0));
     HIP_TRY(h, hipHostGetDevicePointer(&v_dout, h->pin_dout, 0));
+    bar_mirror(h, &v_in, h->pin_in, in_bytes, 0);
+    bar_mirror(h, &v_din, h->pin_din, sizeof(double) * nk * 36, 1);
     double *di = (double *)v_in, *dout = (double *)v_out;
     hipStream_t st = h->stream;
     // seeds / results of up to 512 (item, direction) pairs are read / written in place by the kernels, larger ones staged
@@ -1883,6 +1908,8 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     HIP_TRY(h, hipHostGetDevicePointer(&v_out, h->pin_out, 0));
     HIP_TRY(h, hipHostGetDevicePointer(&v_din, h->pin_din, 0));
     HIP_TRY(h, hipHostGetDevicePointer(&v_dout, h->pin_dout, 0));
+    bar_mirror(h, &v_in, h->pin_in, in_bytes, 0);
+    bar_mirror(h, &v_din, h->pin_din, sizeof(double) * nk * 36, 1);
     double *di = (double *)v_in, *dout = reinterpret_cast<double *>((int *)v_out + t0);
     hipStream_t st = h->stream;
     // One captured graph: accumulator fill, the value pass, the Dual passes.  (Launched eagerly behind the replayed value
