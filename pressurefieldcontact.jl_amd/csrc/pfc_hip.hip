@@ -1512,7 +1512,7 @@ int pfc_check(pfc_handle h) {
 
 // BAR-resident input blocks (pfc_context::bar_in): allocated on first use if the device has a large BAR.
 constexpr size_t kBarItems = 512;      // items whose value inputs go there: every evaluation whose kernels read them in place
-constexpr size_t kBarKeys = 64;        // (item, direction) pairs whose Dual seeds go there (18 KiB of write-combined stores)
+constexpr size_t kBarKeys = 512;       // (item, direction) pairs whose Dual seeds go there: every Dual evaluation whose kernels read the seeds in place (48 box-on-plane scenes x 6 directions: a chunk 96 -> 82 us, 80 scenes 111 -> 90; scripts/variants/bar_keys_run.py)
 static bool bar_ready(pfc_context *h) {
     if (h->bar_state == 0) {
         h->bar_state = -1;
