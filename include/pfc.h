@@ -216,7 +216,7 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
  * counters and stream ordering are those of the unsplit call; a SPARSE PILE -- at least 1 024 items over small or mid-sized
  * trees of which at most a quarter were in contact the last time the handle evaluated that many items -- runs as one launch
  * sequence with wider broadphase workgroups instead: pfc_last_parts() tells; the two streams of a handle are tested once for
- * running side by side -- environment PFC_NO_QUEUE_TEST=1 skips the test; pfc_eval writes the inputs of evaluations of up to 512
+ * running side by side -- environment PFC_NO_QUEUE_TEST=1 skips the test; pfc_eval writes the inputs of evaluations of up to 4 096
  * items straight into device memory when the device has a large PCIe BAR -- PFC_NO_BAR_INPUTS=1 keeps them in pinned host memory), "dual_reuse" (default 1: pfc_eval_dual compares the
  * value inputs of a call above the small-scene limits with those of the previous call and, if they are bitwise equal,
  * runs only the Dual passes on the previous call's value pass -- the chunks of one Jacobian), "clip_min" (default 384; 0 = never: a launch of at

@@ -1511,7 +1511,7 @@ int pfc_check(pfc_handle h) {
 }
 
 // BAR-resident input blocks (pfc_context::bar_in): allocated on first use if the device has a large BAR.
-constexpr size_t kBarItems = 512;      // items whose value inputs go there: every evaluation whose kernels read them in place
+constexpr size_t kBarItems = 4096;     // items whose value inputs go there: every evaluation whose kernels read them in place (kInPlaceItems)
 constexpr size_t kBarKeys = 512;       // (item, direction) pairs whose Dual seeds go there: every Dual evaluation whose kernels read the seeds in place (48 box-on-plane scenes x 6 directions: a chunk 96 -> 82 us, 80 scenes 111 -> 90; scripts/variants/bar_keys_run.py)
 static bool bar_ready(pfc_context *h) {
     if (h->bar_state == 0) {
@@ -1587,7 +1587,10 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     hipStream_t st = h->stream;
     // A small scene (what a Radau stage evaluates) pays ~5 us per staging copy, more than the kernels spend on the data:
     // there the kernels read the inputs from, and write the results and the tail to, the pinned blocks directly.
-    const bool zero_copy = n_items <= 512 && !h->want_surv;
+    // (Up to 512 items while the inputs sat in host memory -- a kernel's reads over PCIe stop paying beyond that; with BAR-resident
+    // inputs up to 4 096: C5 through host buffers 307 -> 282 us, 1 000 box-on-plane scenes 198 -> 178, 600 full-size poses
+    // 635 -> 619, 2 048 unchanged; scripts/variants/zero_copy_limit_run.py.)
+    const bool zero_copy = n_items <= (bar ? (int)kBarItems : 512) && !h->want_surv;
     double *di = h->h_pose.p, *dout = reinterpret_cast<double *>(h->tail.p + t0);
     if (zero_copy) {
         void *dpi = h->bar_in, *dpo = nullptr;
