@@ -1512,7 +1512,9 @@ int pfc_check(pfc_handle h) {
 
 // BAR-resident input blocks (pfc_context::bar_in): allocated on first use if the device has a large BAR.
 constexpr size_t kBarItems = 4096;     // items whose value inputs go there: every evaluation whose kernels read them in place (kInPlaceItems)
-constexpr size_t kBarKeys = 512;       // (item, direction) pairs whose Dual seeds go there: every Dual evaluation whose kernels read the seeds in place (48 box-on-plane scenes x 6 directions: a chunk 96 -> 82 us, 80 scenes 111 -> 90; scripts/variants/bar_keys_run.py)
+constexpr size_t kBarKeys = 4096;      // (item, direction) pairs whose Dual seeds go there; the Dual kernels then read the seeds and write the partials in place
+                                       // (48 box-on-plane scenes x 6 directions: a chunk 96 -> 82 us; 256 scenes 278 -> 250, 100 reduced blob/tool poses 318 -> 288:
+                                       // scripts/variants/bar_keys_run.py, dual_in_place_limit_run.py); without a BAR block the in-place limit is 512 pairs
 static bool bar_ready(pfc_context *h) {
     if (h->bar_state == 0) {
         h->bar_state = -1;
@@ -1795,8 +1797,8 @@ int eval_dual_hybrid(pfc_context *h, int n_items, int n_dir, const int *ins_ids,
     bar_mirror(h, &v_din, h->pin_din, sizeof(double) * nk * 36, 1);
     double *di = (double *)v_in, *dout = (double *)v_out;
     hipStream_t st = h->stream;
-    // seeds / results of up to 512 (item, direction) pairs are read / written in place by the kernels, larger ones staged
-    const bool zc = nk <= 512;
+    // seeds / results of up to kBarKeys (512 without a BAR block) (item, direction) pairs are read / written in place by the kernels, larger ones staged
+    const bool zc = nk <= (h->bar_state == 1 ? (int)kBarKeys : 512);
     if (!zc) {
         HIP_TRY(h, ensure_dual(h, h->dual_in, nk * 36));
         HIP_TRY(h, ensure_dual(h, h->dual_out, nk * 12));
@@ -1931,7 +1933,7 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     const int L = bfs_levels_for(h, n_items, levels);
     // seeds / results of up to 512 (item, direction) pairs are read / written in place by the kernels; larger ones are
     // copied by memcpy nodes of the graph (reading 288 B per pair over PCIe from inside k_narrow_dual stops paying)
-    const bool zc_dual = nk <= 512;
+    const bool zc_dual = nk <= (h->bar_state == 1 ? (int)kBarKeys : 512);
     if (!zc_dual) {
         HIP_TRY(h, ensure_dual(h, h->dual_in, nk * 36));
         HIP_TRY(h, ensure_dual(h, h->dual_out, nk * 12));
