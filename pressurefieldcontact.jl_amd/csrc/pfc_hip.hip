@@ -1529,9 +1529,17 @@ static bool bar_ready(pfc_context *h) {
     }
     return h->bar_state == 1;
 }
+// After the host has filled a BAR-resident block: drain the core's write-combining buffers, so that the stores are posted
+// before the doorbell write of the launch that reads them (PCIe keeps posted writes in order).  The runtime's locked
+// queue-index update does the same; this makes the ordering independent of it.
+static inline void bar_publish() {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("sfence" ::: "memory");
+#endif
+}
 // The device-visible address of a pinned input block the host has just filled: its copy in BAR-resident device memory if it
 // fits there (slot 0: value inputs, slot 1: Dual seeds), else the pinned block itself.  The pinned block stays the host's copy
-// (the Dual paths compare the next call's inputs with it).
+// (the Dual paths compare the next call's inputs with it).  The caller ends its mirrors with one bar_publish().
 static void bar_mirror(pfc_context *h, void **dev, const void *pinned, size_t bytes, int slot) {
     if (!bar_ready(h)) return;
     void *dst = slot == 0 ? h->bar_in : h->bar_din;
@@ -1586,6 +1594,7 @@ int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, 
     std::memcpy(pi + n * 24, twist, sizeof(double) * n * 6);
     if (s) std::memcpy(pi + n * 30, s, sizeof(double) * n * 6); else std::memset(pi + n * 30, 0, sizeof(double) * n * 6);
     if (ins_ids) std::memcpy(pi + in_d, ins_ids, sizeof(int) * n);
+    if (bar) bar_publish();
     hipStream_t st = h->stream;
     // A small scene (what a Radau stage evaluates) pays ~5 us per staging copy, more than the kernels spend on the data:
     // there the kernels read the inputs from, and write the results and the tail to, the pinned blocks directly.
@@ -1722,6 +1731,7 @@ int eval_dual_fused(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     HIP_TRY(h, hipHostGetDevicePointer(&v_dout, h->pin_dout, 0));
     bar_mirror(h, &v_in, h->pin_in, in_bytes, 0);
     bar_mirror(h, &v_din, h->pin_din, sizeof(double) * nk * 30, 1);
+    bar_publish();
     double *di = (double *)v_in, *dout = (double *)v_out, *ddi = (double *)v_din, *ddo = (double *)v_dout;
     h->fout_dev = reinterpret_cast<int *>(dout + out_d) + n * 4;
     h->fout_host = reinterpret_cast<const int *>((const double *)h->pin_out + out_d) + n * 4;
@@ -1795,6 +1805,7 @@ int eval_dual_hybrid(pfc_context *h, int n_items, int n_dir, const int *ins_ids,
     HIP_TRY(h, hipHostGetDevicePointer(&v_dout, h->pin_dout, 0));
     bar_mirror(h, &v_in, h->pin_in, in_bytes, 0);
     bar_mirror(h, &v_din, h->pin_din, sizeof(double) * nk * 36, 1);
+    bar_publish();
     double *di = (double *)v_in, *dout = (double *)v_out;
     hipStream_t st = h->stream;
     // seeds / results of up to kBarKeys (512 without a BAR block) (item, direction) pairs are read / written in place by the kernels, larger ones staged
@@ -1915,6 +1926,7 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     HIP_TRY(h, hipHostGetDevicePointer(&v_dout, h->pin_dout, 0));
     bar_mirror(h, &v_in, h->pin_in, in_bytes, 0);
     bar_mirror(h, &v_din, h->pin_din, sizeof(double) * nk * 36, 1);
+    bar_publish();
     double *di = (double *)v_in, *dout = reinterpret_cast<double *>((int *)v_out + t0);
     hipStream_t st = h->stream;
     // One captured graph: accumulator fill, the value pass, the Dual passes.  (Launched eagerly behind the replayed value

@@ -75,5 +75,7 @@ for f in newest_per_dir(os.path.join(root, "gpurun_out", f"{tag}_stats", "**", "
             keep = [x for x in v if x >= 0.5 * max(v)]
             steady[name] = {"launches": len(v), "steady_launches": len(keep), "all_avg_ns": sum(v) / len(v),
                             "steady_avg_ns": sum(keep) / len(keep)}
+steady["_names"] = ("the key 'void pfc::k_narrow<false, 2>' is the clip-only narrowphase kernel of the run, whichever it was "
+                    "(pfc::k_clip_queue since round 3; k_narrow<.., 2 / 3> before and for tet-tet scenarios): one key across rounds")
 json.dump(steady, open(os.path.join(root, "profiles", f"{rnd}_kernel_steady.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
