@@ -764,3 +764,32 @@ def test_two_halves_run_side_by_side_after_an_eager_rccl_init():
         res[mode] = (float(re.search(r": ([0-9.]+) ms per step", line).group(1)), line)
         assert "parts 2" in line and "serial" not in line, line
     assert res["before-nocoll"][0] < 1.10 * res["none"][0], res
+
+
+@pytest.mark.gpu
+def test_host_paths_without_bar_resident_inputs(tmp_path):
+    """On a device with a large BAR the host-buffer entry points write their inputs into device memory and let the kernels work
+    in place up to 4 096 items / (item, direction) pairs; without one (PFC_NO_BAR_INPUTS=1 stands in for it) they read pinned
+    host memory in place up to 512 and stage copies above.  Both forms, in fresh processes, over the sizes on either side of
+    those limits (value and Dual): the same counts, results equal to the summation-order noise of the atomics."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for tag, extra in (("bar", {}), ("nobar", {"PFC_NO_BAR_INPUTS": "1"})):
+        f = str(tmp_path / (tag + ".npz"))
+        env = dict(os.environ, **extra)
+        env.pop("PFC_LIB", None)
+        p = subprocess.run([sys.executable, os.path.join(root, "scripts", "host_paths_dump.py"), f], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=400)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got[tag] = np.load(f)
+    assert sorted(got["bar"].files) == sorted(got["nobar"].files) and len(got["bar"].files) >= 30
+    for k in got["bar"].files:
+        a, b = got["bar"][k], got["nobar"][k]
+        if k.endswith("counts"):
+            assert np.array_equal(a, b), k
+        else:
+            scale = np.abs(a).max(axis=-1, keepdims=True) + 1e-300
+            assert np.all(np.abs(a - b) <= 1e-11 * scale + 1e-13), (k, float(np.max(np.abs(a - b) / scale)))
