@@ -310,3 +310,21 @@ def test_c_example_matches_analytic_normal_wrench(pfc, tmp_path):
     r = subprocess.run([_build_c_example(tmp_path), "200"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "us per pfc_eval" in r.stdout          # the timing loop ran its 200 repeated evaluations without an error
+
+
+def test_array_addresses_through_the_buffer_protocol(pfc):
+    """scenario._addr: the address the foreign call gets is the array's first element, for writable arrays (buffer protocol)
+    and for read-only and empty ones (ndarray.ctypes)."""
+    import sys
+    sc = sys.modules[pfc.MechanismScenario.__module__]
+    a = np.arange(72, dtype=np.float64).reshape(3, 24)
+    assert sc._addr(a) == a.ctypes.data
+    v = a[1:]                      # a C-contiguous view that does not start at the buffer's first byte
+    assert v.flags.c_contiguous and sc._addr(v) == v.ctypes.data == a.ctypes.data + 24 * 8
+    r = a.copy(); r.flags.writeable = False
+    assert sc._addr(r) == r.ctypes.data
+    e = np.zeros((0, 6))
+    assert sc._addr(e) == e.ctypes.data
+    i = np.arange(5, dtype=np.int32)
+    assert sc._ia(i)[1] == i.ctypes.data and sc._da(a)[1] == a.ctypes.data
+    assert sc._da([[1.0, 2.0]])[0].dtype == np.float64      # a list is converted first
