@@ -47,13 +47,36 @@ typedef struct pfc_context *pfc_handle;
 /* Library/ABI version (PFC_VERSION of the build). */
 int pfc_version(void);
 /* 0 for the product build.  Diagnostic builds report themselves: bit 0 = in-kernel phase stamps (-DPFC_STAMPS, graph
- * replay off), bits 8..15 = elimination variant (-DPFC_EXP=n: one phase of the narrowphase compiled out, WRONG results).
+ * replay off), bits 8..15 = elimination variant (-DPFC_EXP=n: one phase of the narrowphase compiled out, WRONG results),
+ * bit 16 = an A/B variant built from patched sources (scripts/mkvar.sh, -DPFC_VARIANT).
  * The Python binding refuses to load a non-product build unless PFC_ALLOW_DIAGNOSTIC=1 is set. */
 int pfc_build_info(void);
 
 /* MechanismScenario() (src/mechanism_scenario.jl:181-198): creates an empty scenario bound to HIP device
  * `device`.  Fails with PFC_ERR_HIP when no device is usable. */
 int pfc_create(int device, pfc_handle *out);
+/*
+ * The same scenario over SEVERAL devices of the node for the one host process the reference is (its calcXd! loops over the
+ * contact instructions in a single Julia process, src/contact_algorithms_non_friction.jl:60-68; SURVEY section 8(b):
+ * "pfc_create(device_mask)").  devices[0..n_devices) are HIP device ordinals (an ordinal may appear more than once: several
+ * shard contexts on one device).  Every other entry point takes the handle unchanged:
+ *   - pfc_add_mesh / pfc_add_instruction / pfc_finalize replicate meshes, trees and instructions on every device;
+ *   - an evaluation cuts its items into contiguous ranges, one per device, balanced by cost (node tests + candidates of the
+ *     previous evaluation of the same item list; the leaf-count product of the two meshes the first time), SURVEY 8(e).  Items
+ *     are independent, there is no collective:
+ *       host-pointer entry points (pfc_eval, pfc_eval_dual, pfc_eval_dual_bp): one library thread per device evaluates its
+ *       range straight from / into the caller's arrays;
+ *       device-pointer entry points (pfc_eval_device, pfc_eval_dual_device[_bp|_more], pfc_scatter_generalized_device): the
+ *       buffers live on devices[0]; the other devices get their ranges by peer copies (xGMI) and write their results back the
+ *       same way, ordered against `stream` by events; pfc_check synchronises every device.
+ *   - option "multi_min" (default 8): with fewer than this many items per device fewer devices take part
+ *     (pfc_last_shards() tells how many did); every other option is forwarded to all devices;
+ *   - pfc_get_stats sums over the devices; pfc_debug_* go to the device that evaluated the item; pfc_last_parts / _team and
+ *     pfc_get_stage_ms report the first device's.
+ * Results are those of the single-device handle (counters bit-equal, sums up to their order).
+ */
+int pfc_create_multi(const int *devices, int n_devices, pfc_handle *out);
+int pfc_last_shards(pfc_handle h);   /* devices that took part in the last evaluation (1 for a single-device handle) */
 void pfc_destroy(pfc_handle h);
 const char *pfc_last_error(pfc_handle h);
 
@@ -133,6 +156,18 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
                   double *sdot, double *d_wrench, double *d_sdot, int *counts);
 
 /*
+ * pfc_eval_dual with the broadphase run on a pose of its own.  The reference culls with the transforms of m.float's state
+ * whatever scenario is being evaluated (calcTriTetIntersections!: `refreshBodyBodyTransform!(m, m.float, c_ins)`,
+ * src/contact_algorithms_non_friction.jl:94-101), and m.float holds what the last Float64 calcXd! left there
+ * (src/extensions.jl:21) -- in Radau's Jacobian that is NOT value.(x_dual) in general.  bp_pose (n_items x 24, the packing of
+ * pose; only the x_r1_r2 half is read) is that pose: typically the `pose` array of the host's last pfc_eval.  NULL: the
+ * candidates come from pose itself, i.e. pfc_eval_dual.  The narrowphase, and every output, is evaluated at pose.
+ */
+int pfc_eval_dual_bp(pfc_handle h, int n_items, int n_dir, const int *ins_ids, const double *pose, const double *bp_pose,
+                     const double *twist, const double *s, const double *d_pose, const double *d_twist, const double *d_s,
+                     double *wrench, double *sdot, double *d_wrench, double *d_sdot, int *counts);
+
+/*
  * pfc_eval_dual with every buffer resident in device memory and no host synchronisation (the Dual sibling of
  * pfc_eval_device; Radau's Jacobian evaluations are half of its calls, src/radau/radau_functions.jl:2-14): value pass and
  * Dual passes are enqueued back to back on `stream`.  The Dual polygons kept between the passes are sized from the
@@ -143,6 +178,11 @@ int pfc_eval_dual_device(pfc_handle h, int n_items, int n_dir, const int *d_ins_
                          const double *d_twist, const double *d_s, const double *d_dpose, const double *d_dtwist,
                          const double *d_ds, double *d_wrench, double *d_sdot, double *d_dwrench, double *d_dsdot,
                          int *d_counts, void *stream);
+/* ... with the broadphase pose of pfc_eval_dual_bp in device memory (d_bp_pose n_items x 24, may be NULL). */
+int pfc_eval_dual_device_bp(pfc_handle h, int n_items, int n_dir, const int *d_ins_ids, const double *d_pose,
+                            const double *d_bp_pose, const double *d_twist, const double *d_s, const double *d_dpose,
+                            const double *d_dtwist, const double *d_ds, double *d_wrench, double *d_sdot, double *d_dwrench,
+                            double *d_dsdot, int *d_counts, void *stream);
 
 /*
  * Further seed directions AT THE POINT OF THE PREVIOUS pfc_eval_dual_device evaluation of this handle: the chunks of one
@@ -228,14 +268,18 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
  * launch sequence -- the scene sizes Radau evaluates, src/radau/radau_functions.jl:2-14,64-70; same results; 0 = always
  * batched; the debug / profile options imply the batched path), "clip_queue" (default 1: the clip-only kernel of a
  * tri-tet launch queues the candidates that pass the trivial reject in its polygon ring and clips 64 of them at a time;
- * 0 = the lane-per-candidate clip rounds; same results bit for bit), "team" (default 48, at most 64; 0 = never: an evaluation of a few
+ * 0 = the lane-per-candidate clip rounds; same results bit for bit), "team" (default 48, at most 48; 0 = never: an evaluation of a few
  * pairs too big for one workgroup -- BASELINE's single 9 680-tet x 5 120-triangle pair -- runs as ONE kernel with a team
  * of up to this many workgroups per item -- while a workgroup of the team has at most ~1 200 leaves of the pair to descend: up
  * to 16 poses of that pair; beyond that the batched path is faster --, and a few mid-sized items -- a 972-tet box on the
  * ground -- with a small team each (one workgroup per 128 leaves, at most 32); same results up to the order of the sums;
  * pfc_last_team().  Team-mates wait for
  * each other inside the launch: several handles evaluating such scenes at the same moment on one device may each get
- * only part of a team resident; the wait is bounded (~65 ms), the evaluation is then re-issued on the batched path). */
+ * only part of a team resident; the wait is bounded (~65 ms), the evaluation is then re-issued on the batched path.  Inside
+ * one process that case does not arise: a device has one team slot, a handle that finds it taken evaluates without a team at
+ * once), "team_fault" (diagnostic, default -1: this rank of every team behaves as if its wait for the team had timed out while
+ * the others saw it arrive; the evaluation must come back re-issued on the batched path, never with a wrong result),
+ * "multi_min" (multi-device handles, see pfc_create_multi). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);
 
 /* Totals of the last checked evaluation: out[0..7] = {node tests, candidate pairs, non-empty pairs, traction

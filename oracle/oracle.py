@@ -65,6 +65,11 @@ def lib():
         L.pfo_eval.restype = C.c_int
         L.pfo_eval.argtypes = [C.POINTER(_Mesh), C.POINTER(_Mesh), C.POINTER(_Ins), _dp, _dp, _dp, _dp, _dp, _ip,
                                C.POINTER(_Debug)]
+        L.pfo_eval_bp.restype = C.c_int
+        L.pfo_eval_bp.argtypes = [C.POINTER(_Mesh), C.POINTER(_Mesh), C.POINTER(_Ins), _dp, _dp, _dp, _dp, _dp, _dp, _ip, C.POINTER(_Debug)]
+        L.pfo_eval_dual_bp.restype = C.c_int
+        L.pfo_eval_dual_bp.argtypes = [C.POINTER(_Mesh), C.POINTER(_Mesh), C.POINTER(_Ins), _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp,
+                                       _dp, _dp, _dp, _dp]
         L.pfo_eval_batch.restype = C.c_int
         L.pfo_eval_batch.argtypes = [C.c_int, C.POINTER(_Mesh), C.POINTER(_Ins), _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp,
                                      _ip, C.c_int]
@@ -149,17 +154,19 @@ class EvalResult:
                  "cop", "wrench_normal", "wrench_fric_cop", "Delta", "has_K")
 
 
-def evaluate(m1: OracleMesh, m2: OracleMesh, ins: _Ins, pose, twist, s=None, debug: bool = True) -> EvalResult:
-    """One force_single_elastic_intersection!.  pose: 24 doubles (see pfc_oracle.h)."""
+def evaluate(m1: OracleMesh, m2: OracleMesh, ins: _Ins, pose, twist, s=None, debug: bool = True, bp_pose=None) -> EvalResult:
+    """One force_single_elastic_intersection!.  pose: 24 doubles (see pfc_oracle.h).  bp_pose: the pose the tree descent
+    culls with (m.float's, non_friction.jl:94-101), default: pose."""
     L = lib()
     pose_a, pose_p = _d(pose)
+    bp_a, bp_p = _d(pose if bp_pose is None else bp_pose)
     tw_a, tw_p = _d(twist)
     s_a, s_p = _d(np.zeros(6) if s is None else s)
     wrench = np.zeros(6); sdot = np.zeros(6); counts = np.zeros(4, dtype=np.int32)
     dbg = L.pfo_debug_new() if debug else None
     try:
-        st = L.pfo_eval(C.byref(m1.c), C.byref(m2.c), C.byref(ins), pose_p, tw_p, s_p,
-                        wrench.ctypes.data_as(_dp), sdot.ctypes.data_as(_dp), counts.ctypes.data_as(_ip), dbg)
+        st = L.pfo_eval_bp(C.byref(m1.c), C.byref(m2.c), C.byref(ins), pose_p, bp_p, tw_p, s_p,
+                           wrench.ctypes.data_as(_dp), sdot.ctypes.data_as(_dp), counts.ctypes.data_as(_ip), dbg)
         r = EvalResult()
         r.status, r.wrench, r.sdot, r.counts = st, wrench, sdot, counts
         r.pairs = r.clip_n = r.trac = None
@@ -224,16 +231,18 @@ def scatter_generalized(wrench, x_w_r2, body_1, body_2, jac, scene=None, n_scene
     return f
 
 
-def evaluate_dual(m1: OracleMesh, m2: OracleMesh, ins: _Ins, pose, twist, s, d_pose, d_twist, d_s):
-    """pfo_eval_dual: one force_single_elastic_intersection! on Duals.  d_pose (n_dir, 24), d_twist (n_dir, 6),
-    d_s (n_dir, 6).  Returns (status, wrench, sdot, d_wrench (n_dir, 6), d_sdot (n_dir, 6))."""
+def evaluate_dual(m1: OracleMesh, m2: OracleMesh, ins: _Ins, pose, twist, s, d_pose, d_twist, d_s, bp_pose=None):
+    """pfo_eval_dual[_bp]: one force_single_elastic_intersection! on Duals.  d_pose (n_dir, 24), d_twist (n_dir, 6),
+    d_s (n_dir, 6); bp_pose: the pose the pair list is taken at (m.float's), default pose.
+    Returns (status, wrench, sdot, d_wrench (n_dir, 6), d_sdot (n_dir, 6))."""
     L = lib()
+    bp_a, bp_p = _d(pose if bp_pose is None else bp_pose)
     pose_a, pose_p = _d(pose); tw_a, tw_p = _d(twist); s_a, s_p = _d(np.zeros(6) if s is None else s)
     dp_a, dp_p = _d(d_pose); dt_a, dt_p = _d(d_twist)
     n_dir = dp_a.size // 24
     ds_a, ds_p = _d(np.zeros((n_dir, 6)) if d_s is None else d_s)
     wrench = np.zeros(6); sdot = np.zeros(6); dw = np.zeros((n_dir, 6)); dsd = np.zeros((n_dir, 6))
-    st = L.pfo_eval_dual(C.byref(m1.c), C.byref(m2.c), C.byref(ins), pose_p, tw_p, s_p, n_dir, dp_p, dt_p, ds_p,
+    st = L.pfo_eval_dual_bp(C.byref(m1.c), C.byref(m2.c), C.byref(ins), pose_p, bp_p, tw_p, s_p, n_dir, dp_p, dt_p, ds_p,
                          wrench.ctypes.data_as(_dp), sdot.ctypes.data_as(_dp), dw.ctypes.data_as(_dp),
                          dsd.ctypes.data_as(_dp))
     return st, wrench, sdot, dw, dsd

@@ -964,18 +964,30 @@ static void yes_contact_bristle(ctx *c, const double s[6], double wrench[6], dou
 /* ------------------------------------------------------------------------------------------------------------ */
 /* force_single_elastic_intersection!: src/contact_algorithms_non_friction.jl:70-84                              */
 /* ------------------------------------------------------------------------------------------------------------ */
-static int eval_impl(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *twist,
-                     const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg);
+static int eval_impl(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *bp_pose,
+                     const double *twist, const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg);
 int pfo_eval(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *twist,
              const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg)
 {
     const unsigned csr = ftz_enter();
-    const int rc = eval_impl(m1, m2, ins, pose, twist, s, wrench, sdot, counts, dbg);
+    const int rc = eval_impl(m1, m2, ins, pose, NULL, twist, s, wrench, sdot, counts, dbg);
     ftz_leave(csr);
     return rc;
 }
-static int eval_impl(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *twist,
-                     const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg)
+/* The same with the broadphase run on bp_pose's x_r1_r2 (24 doubles, the packing of pose; NULL: pose itself): what
+ * calcTriTetIntersections! does when the scenario being evaluated is not m.float -- it always culls with m.float's transforms
+ * (src/contact_algorithms_non_friction.jl:94-101: `refreshBodyBodyTransform!(m, m.float, c_ins)`), the narrowphase then runs on
+ * the evaluated scenario's own pose (:120, refreshBodyBodyCache!(m, tm, c_ins)). */
+int pfo_eval_bp(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *bp_pose,
+                const double *twist, const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg)
+{
+    const unsigned csr = ftz_enter();
+    const int rc = eval_impl(m1, m2, ins, pose, bp_pose, twist, s, wrench, sdot, counts, dbg);
+    ftz_leave(csr);
+    return rc;
+}
+static int eval_impl(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *bp_pose,
+                     const double *twist, const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg)
 {
     ctx c;
     pfo_debug *own = NULL;
@@ -987,8 +999,9 @@ static int eval_impl(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins,
     memset(&c, 0, sizeof c);
     c.m1 = m1; c.m2 = m2; c.ins = ins; c.d = dbg;
     memcpy(c.R21, pose, 9 * sizeof(double));
-    memcpy(c.R12, pose + 12, 9 * sizeof(double));
-    memcpy(c.t12, pose + 21, 3 * sizeof(double));
+    /* TT_Cache.R_a_b, t_a_b (update_TT_Cache!, tree_types.jl:43-50): read by the tree descent only */
+    memcpy(c.R12, (bp_pose ? bp_pose : pose) + 12, 9 * sizeof(double));
+    memcpy(c.t12, (bp_pose ? bp_pose : pose) + 21, 3 * sizeof(double));
     c.x21 = dh_from_Rt(pose, pose + 9);
     c.x12 = dh_from_Rt(pose + 12, pose + 21);
     c.w = ld3(twist); c.vlin = ld3(twist + 3);

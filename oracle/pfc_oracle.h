@@ -79,6 +79,9 @@ int pfo_eval(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const d
              const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg);
 
 /* Batch driver (CPU baseline): independent items over n_threads OpenMP threads (1 = the reference's serial model). */
+/* pfo_eval with the broadphase culling on bp_pose (NULL: pose): non_friction.jl:94-101 on a scenario that is not m.float */
+int pfo_eval_bp(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *bp_pose,
+                const double *twist, const double *s, double *wrench, double *sdot, int *counts, pfo_debug *dbg);
 int pfo_eval_batch(int n_items, const pfo_mesh *meshes, const pfo_ins *ins, const int *ins_m1, const int *ins_m2,
                    const int *ins_ids, const double *pose, const double *twist, const double *s, double *wrench,
                    double *sdot, int *counts, int n_threads);

@@ -589,10 +589,21 @@ void yes_contact_bristle(Ctx &c, const D s[6], D wrench[6], D sdot[6]) {
  * d_twist (n_dir x 6), d_s (n_dir x 6) are the partials of each input; d_wrench, d_sdot (n_dir x 6) the partials of
  * the outputs.  The values written to wrench / sdot come from the Dual evaluation itself.
  */
+extern "C" int pfo_eval_dual_bp(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *bp_pose,
+                                const double *twist, const double *s, int n_dir, const double *d_pose,
+                                const double *d_twist, const double *d_s, double *wrench, double *sdot, double *d_wrench,
+                                double *d_sdot);
 extern "C" int pfo_eval_dual(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose,
                              const double *twist, const double *s, int n_dir, const double *d_pose,
                              const double *d_twist, const double *d_s, double *wrench, double *sdot, double *d_wrench,
                              double *d_sdot) {
+    return pfo_eval_dual_bp(m1, m2, ins, pose, nullptr, twist, s, n_dir, d_pose, d_twist, d_s, wrench, sdot, d_wrench, d_sdot);
+}
+/* ... with the pair list of the value pass taken at bp_pose (m.float's transforms, non_friction.jl:94-101; NULL: pose) */
+extern "C" int pfo_eval_dual_bp(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_ins *ins, const double *pose, const double *bp_pose,
+                                const double *twist, const double *s, int n_dir, const double *d_pose,
+                                const double *d_twist, const double *d_s, double *wrench, double *sdot, double *d_wrench,
+                                double *d_sdot) {
     if (!m1 || !m2 || !ins || !pose || !twist || !wrench || !sdot || n_dir < 0) return PFO_ERR_BAD_ARG;
     if (n_dir > 0 && (!d_pose || !d_twist || !d_wrench || !d_sdot)) return PFO_ERR_BAD_ARG;
     static const double zero6[6] = {0, 0, 0, 0, 0, 0};
@@ -600,7 +611,7 @@ extern "C" int pfo_eval_dual(const pfo_mesh *m1, const pfo_mesh *m2, const pfo_i
     pfo_debug *dbg = pfo_debug_new();
     if (!dbg) return PFO_ERR_NOMEM;
     int counts[4];
-    int st = pfo_eval(m1, m2, ins, pose, twist, s, wrench, sdot, counts, dbg);   /* values + the pair list */
+    int st = pfo_eval_bp(m1, m2, ins, pose, bp_pose, twist, s, wrench, sdot, counts, dbg);   /* values + the pair list */
     if (st) { pfo_debug_free(dbg); return st; }
     for (int dir = 0; dir < n_dir; ++dir) {
         Ctx c;

@@ -27,6 +27,8 @@ SIGNATURES = {
     "pfc_version": (C.c_int, []),
     "pfc_build_info": (C.c_int, []),
     "pfc_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "pfc_create_multi": (C.c_int, [_ip, C.c_int, C.POINTER(C.c_void_p)]),
+    "pfc_last_shards": (C.c_int, [C.c_void_p]),
     "pfc_destroy": (None, [C.c_void_p]),
     "pfc_last_error": (C.c_char_p, [C.c_void_p]),
     "pfc_add_mesh": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _ip, C.c_int, _ip, _dp, C.c_double, C.c_int,
@@ -47,7 +49,9 @@ SIGNATURES = {
     "pfc_last_team": (C.c_int, [C.c_void_p]),
     "pfc_last_dual_reused": (C.c_int, [C.c_void_p]),
     "pfc_eval_dual": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "pfc_eval_dual_bp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "pfc_eval_dual_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 13),
+    "pfc_eval_dual_device_bp": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 14),
     "pfc_eval_dual_device_more": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),
     "pfc_build_tree": (C.c_int, [C.c_int, _dp, C.c_int, C.c_int, _ip, _dp, C.c_int, _dp, _dp, _dp, _ip, _ip]),
     "pfc_tree_last_error": (C.c_char_p, []),
@@ -67,7 +71,7 @@ class PFCError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile csrc/pfc_hip.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("pfc_hip.hip", "pfc_tree.cpp", "pfc_kernels.h", "pfc_bp.h", "pfc_np.h", "pfc_br.h", "pfc_dual.h", "pfc_fused.h", "pfc_clip.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("pfc_hip.hip", "pfc_tree.cpp", "pfc_kernels.h", "pfc_bp.h", "pfc_np.h", "pfc_br.h", "pfc_dual.h", "pfc_fused.h", "pfc_clip.h", "pfc_multi.h")]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "pfc.h"))
     srcs.append(os.path.abspath(__file__))      # the compiler flags live here
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -84,7 +88,7 @@ def lib():
     """Load libpfc_hip.so; raises (never falls back) if it is absent."""
     global _lib
     if _lib is None:
-        # Diagnostic variants (scripts/elimination.sh, scripts/build_stamps.sh) are built to csrc/exp/*.so and selected with
+        # Diagnostic variants (scripts/elimination.sh, scripts/build_stamps.sh) are built to build/variants/*.so (outside the package) and selected with
         # PFC_LIB=<path>; the product library is never overwritten by them.
         path = os.environ.get("PFC_LIB") or LIB_PATH
         if not os.path.exists(path):
@@ -104,5 +108,7 @@ def lib():
         # per pfc_eval -- a third of what a small scene's evaluation takes on the device).
         L.pfc_eval_addr = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, *([C.c_void_p] * 7))(("pfc_eval", L))
         L.pfc_eval_dual_addr = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, *([C.c_void_p] * 12))(("pfc_eval_dual", L))
+        L.pfc_eval_dual_bp_addr = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, *([C.c_void_p] * 13))(("pfc_eval_dual_bp", L))
+        L.pfc_loaded_path = path
         _lib = L
     return _lib

@@ -250,9 +250,9 @@ def vol_vol(n_poses: int = 4, seed: int = 20260104, n_div: int = 4, model: str =
 
 
 # ----------------------------------------------------------------------------------------------------------------
-def build_scenario(w: Workload, device: int = 0, debug: bool = False) -> MechanismScenario:
-    """Workload -> finalized MechanismScenario on the HIP device."""
-    m = MechanismScenario(device=device)
+def build_scenario(w: Workload, device: int = 0, debug: bool = False, devices=None) -> MechanismScenario:
+    """Workload -> finalized MechanismScenario on the HIP device (devices: a list of devices, pfc_create_multi)."""
+    m = MechanismScenario(device=device, devices=devices)
     for ms in w.meshes:
         m.add_contact(ms.name, ms.mesh, c_prop=None if ms.Ebar is None else ContactProperties(ms.Ebar), tree=ms.tree)
     for c in w.instructions:

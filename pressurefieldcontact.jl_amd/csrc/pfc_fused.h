@@ -73,6 +73,11 @@ struct FuArgs {
     int nw;
     int team_seeds;     // the descent of a team is shared out once a level holds this many pairs per workgroup (kTeamSeeds / kTeamSeedsBig)
     unsigned long long *team;
+    int team_fault;     // diagnostic (option "team_fault", default -1): this rank behaves as if its wait for the team after pass 0 had
+                        // timed out while everybody else saw every granule -- stale totals, kStFusedOvf in ITS status word only
+    // Broadphase pose of a Dual evaluation (pfc_eval_dual_bp): the reference culls with m.float's transforms whatever the
+    // state of the Dual scenario (calcTriTetIntersections!, src/contact_algorithms_non_friction.jl:94-101); null: the pose itself
+    const double *bp_pose;
 };
 constexpr int kTeamSlots = 48;           // doubles a workgroup publishes per phase (first phase: 10 sums, 4 counters, status, 27 moments, their reference point)
 constexpr int kTeamMaxWg = 48;           // workgroups per item at most
@@ -160,6 +165,7 @@ __device__ __forceinline__ void team_gather(const FuArgs &g, int item, int nw, i
     // thread -> (rank w2, slot t): every granule of a thread is requested before the first is looked at
     const unsigned long long *base = g.team + ((size_t)(item * nw) * 3 + phase) * (2 * kTeamSlots);
     constexpr int kPer = kTeamMaxWg * kTeamSlots / kFuBlock;
+    static_assert(kTeamMaxWg * kTeamSlots % kFuBlock == 0, "every granule of a full team is requested by exactly one thread");
     unsigned long long lo[kPer], hi[kPer];
     bool need[kPer];
 #pragma unroll
@@ -190,11 +196,13 @@ __device__ __forceinline__ void team_gather(const FuArgs &g, int item, int nw, i
         if (pending) __builtin_amdgcn_s_sleep(1);
     }
     if (pending) *s_flag = 1;
+    const bool fault = phase == 0 && g.team_fault >= 0 && (int)blockIdx.x - item * nw == g.team_fault;      // uniform
+    if (fault && tid == 0) *s_flag = 1;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const int idx = tid + k * kFuBlock;
         if (idx < nw * kTeamSlots)
-            s_team[idx] = __longlong_as_double((long long)(((hi[k] & 0xFFFFFFFFull) << 32) | (lo[k] & 0xFFFFFFFFull)));
+            s_team[idx] = (fault ? 0.5 : 1.0) * __longlong_as_double((long long)(((hi[k] & 0xFFFFFFFFull) << 32) | (lo[k] & 0xFFFFFFFFull)));      // (fault: wrong but finite totals, so that the rank goes on into the friction pass as a rank with stale granules would)
     }
     __syncthreads();
     if (*s_flag) status |= kStFusedOvf;    // a team-mate never arrived: the host re-issues on the batched path (uniform over the workgroup)
@@ -239,6 +247,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     __shared__ double s_acc[kAccStride], s_res[kResStride];
     __shared__ EigScratch E;
     __shared__ double s_aR12[9];
+    __shared__ double s_bp[12];                 // R_a_b (9, column-major), t_a_b (3) of the broadphase
     __shared__ int s_plist[kFuCand];            // candidates that gave a polygon (Dual passes)
     __shared__ int s_npoly;
     __shared__ double s_dacc[16][6];            // per direction: partials of the wrench
@@ -271,6 +280,11 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         }
         if (tid >= 96 && tid < 102) I.twist[tid - 96] = g.twist[6 * (size_t)item + (tid - 96)];
         if (tid >= 128 && tid < 134) I.s[tid - 128] = g.s ? g.s[6 * (size_t)item + (tid - 128)] : 0.0;
+        if (tid >= 160 && tid < 172) {      // x_r1_r2 the broadphase culls with: the pose's own, or m.float's (pfc_eval_dual_bp)
+            const double x = (g.bp_pose ? g.bp_pose : g.pose)[24 * (size_t)item + 12 + (tid - 160)];
+            s_bp[tid - 160] = x;
+            if (!(__builtin_fabs(x) <= 1.79769313486231570815e308)) status |= kStNonFinite;
+        }
     }
     if (tid == 0) s_npoly = 0;
     __syncthreads();
@@ -280,6 +294,8 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     bool pose_ok = true;
 #pragma unroll
     for (int k = 0; k < 24; ++k) pose_ok &= (__builtin_fabs(I.pose[k]) <= 1.79769313486231570815e308);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pose_ok &= (__builtin_fabs(s_bp[k]) <= 1.79769313486231570815e308);
 
     FSTAMP(1);
     // ==== 1. broadphase (tree_tree_intersect, src/obb/tree_types.jl:88-111) ===========================================
@@ -304,10 +320,10 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
             B.stk[0] = make_int2(nn1 == 1 ? ~0 : 0, nn2 == 1 ? ~0 : 0);
         }
-        if (tid < 9) s_aR12[tid] = __builtin_fabs(I.pose[12 + tid]) + 1.0e-14;    // abs_R of an all-identity pair (:10)
+        if (tid < 9) s_aR12[tid] = __builtin_fabs(s_bp[tid]) + 1.0e-14;    // abs_R of an all-identity pair (:10)
         __syncthreads();
         FSTAMP(2);
-        const double *s_pose = I.pose + 12;          // R_a_b (9, column-major), t_a_b (3): x_r1_r2
+        const double *s_pose = s_bp;                 // R_a_b (9, column-major), t_a_b (3): x_r1_r2 (update_TT_Cache!, tree_types.jl:43-50)
         const int reserve = I.ins.reserve;
         int sp = 1;
         bool ovf = false;
@@ -975,6 +991,11 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             // what this workgroup found, one value per thread: the ten sums [0, 10), the four counters, the status word, and for
             // a bristle item the 27 moments about c0 [15, 42) and c0 itself [42, 45)
             double mine = 0.0;
+            if (MW) {
+                // a team-mate's per-thread bits (a non-finite vertex met by one of ITS clip lanes) reach rank 0 only through this
+                // exchange: combine them over the workgroup first
+                if (__syncthreads_or((status & kStNonFinite) != 0)) status |= kStNonFinite;
+            }
             if (tid < 10) mine = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
             else if (tid == 10) mine = (double)n_test;
             else if (tid == 11) mine = (double)n_cand;
@@ -1053,12 +1074,17 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         } else {
             block_partials<6>(acc, red, tid);
             if (MW) {
-                const double mine = tid < 6 ? ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid] : 0.0;
-                const double tot = team_sum(g, item, nw, 2, 6, mine, -1, tid, s_team, &s_tflag, status);
+                // six friction sums and, in slot 6, the rank's status word (OR): a rank whose wait after pass 0 timed out went on
+                // with stale totals and a status word only IT holds -- rank 0, the writer of the outputs, must see it here
+                // (before: rank 0 summed that rank's partials and reported success)
+                const double mine = tid < 6 ? ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid] : (tid == 6 ? (double)status : 0.0);
+                const double tot = team_sum(g, item, nw, 2, 7, mine, 6, tid, s_team, &s_tflag, status);
                 if (tid < 6) s_acc[kAccFric + tid] = tot;
+                if (tid == 6) s_tres[6] = tot;
                 FSTAMP(15);
             } else if (tid < 6) s_acc[kAccFric + tid] = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
             __syncthreads();
+            if (MW) status |= (unsigned)s_tres[6];
         }
     }
 

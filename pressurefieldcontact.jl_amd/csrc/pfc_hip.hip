@@ -16,6 +16,10 @@
 #include "pfc_kernels.h"
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -75,6 +79,7 @@ struct EvalArgs {
     int n_items;
     const int *ins_ids;      // may be null
     const double *pose, *twist, *s;
+    const double *bp_pose;   // may be null: the pose the broadphase culls with (pfc_eval_dual_bp), same packing as pose
     const InsDev *ins;
     const MeshDev *meshes;
     int n_ins;
@@ -86,7 +91,8 @@ struct EvalArgs {
     unsigned *status;
 };
 
-__global__ void k_setup_items(EvalArgs g) {
+// (The record is written field by field: built in registers and stored whole -- 576 bytes -- the kernel spilled 18 VGPRs.)
+__global__ void __launch_bounds__(64) k_setup_items(EvalArgs g) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     {   // the accumulators of the workgroup's items, cleared with consecutive lanes on consecutive doubles (44 stores of 512
         // contiguous bytes per wave instead of 44 stores to 64 different cache lines each)
@@ -97,7 +103,6 @@ __global__ void k_setup_items(EvalArgs g) {
     }
     if (i >= g.n_items) return;
     int id = g.ins_ids ? g.ins_ids[i] : i;
-    ItemRec r;
     if (id < 0 || id >= g.n_ins) {
         atomicOr(g.status, kStBadIns);
         id = 0;
@@ -105,13 +110,33 @@ __global__ void k_setup_items(EvalArgs g) {
     const InsDev in = g.ins[id];
     const MeshDev m1 = g.meshes[in.m1], m2 = g.meshes[in.m2];
     const double *p = g.pose + 24 * (size_t)i;
+    // x_r1_r2 of the broadphase: the pose's own, or the one of m.float's state when the evaluation runs on Duals
+    // (calcTriTetIntersections!, non_friction.jl:94-101; k_repose puts the pose's own back once the broadphase is through)
+    const double *pb = (g.bp_pose ? g.bp_pose + 24 * (size_t)i : p) + 12;
+    ItemRec &r = g.items[i];
+    bool finite = true;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { r.R21[k] = p[k]; r.R12[k] = p[12 + k]; }
+    for (int k = 0; k < 24; ++k) finite &= (__builtin_fabs(p[k]) <= 1.79769313486231570815e308);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        r.t21[k] = p[9 + k]; r.t12[k] = p[21 + k];
-        r.w[k] = g.twist[6 * (size_t)i + k]; r.v[k] = g.twist[6 * (size_t)i + 3 + k];
+    for (int k = 0; k < 9; ++k) r.R21[k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r.t21[k] = p[9 + k];
+    {
+        double R12[9], t12[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { R12[k] = pb[k]; r.R12[k] = R12[k]; finite &= (__builtin_fabs(R12[k]) <= 1.79769313486231570815e308); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { t12[k] = pb[9 + k]; r.t12[k] = t12[k]; finite &= (__builtin_fabs(t12[k]) <= 1.79769313486231570815e308); }
+        float q[4];
+        r.pose_exact = pose_quat(R12, q) ? 0 : 1;
+        r.q12[0] = q[0]; r.q12[1] = q[1]; r.q12[2] = q[2]; r.q12[3] = q[3];
+        // absolute part of the single-precision test's error radius (pfc_bp.h, "Error radius E", (0)); a NaN / huge pose gives
+        // NaN / inf here and every test of the item is settled exactly
+        const double tm = fmax(fmax(__builtin_fabs(t12[0]), __builtin_fabs(t12[1])), __builtin_fabs(t12[2]));
+        r.bp_eabs = (float)(1.4306e-6 * ((m1.cmax + m2.cmax) + tm)) * 1.000001f;
     }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.w[k] = g.twist[6 * (size_t)i + k]; r.v[k] = g.twist[6 * (size_t)i + 3 + k]; }
 #pragma unroll
     for (int k = 0; k < 6; ++k) r.s[k] = (g.s && in.model == PFC_BRISTLE) ? g.s[6 * (size_t)i + k] : 0.0;
     r.chi = in.chi; r.Ebar = m2.Ebar;  // Ē of mesh_2 only: non_friction.jl:131
@@ -120,18 +145,8 @@ __global__ void k_setup_items(EvalArgs g) {
     r.tet1 = m1.tri ? nullptr : m1.tet; r.eps1 = m1.tet_eps; r.eps2 = m2.tet_eps; r.Ebar1 = m1.Ebar;
     r.model = in.model; r.nq = (in.nq == 1) ? 1 : 3;  // quadrature POINTS of rule 1 / rule 2 (quadrature.jl:22,31)
     r.ins = id; r.pad = 0;
-    r.pose_exact = pose_quat(r.R12, r.q12) ? 0 : 1;
-    {   // absolute part of the single-precision test's error radius (pfc_bp.h, "Error radius E", (0)); a NaN / huge pose gives
-        // NaN / inf here and every test of the item is settled exactly
-        const double tm = fmax(fmax(__builtin_fabs(r.t12[0]), __builtin_fabs(r.t12[1])), __builtin_fabs(r.t12[2]));
-        r.bp_eabs = (float)(1.4306e-6 * ((m1.cmax + m2.cmax) + tm)) * 1.000001f;
-    }
     r.pad2[0] = r.pad2[1] = 0;
-    bool finite = true;
-#pragma unroll
-    for (int k = 0; k < 24; ++k) finite &= (__builtin_fabs(p[k]) <= 1.79769313486231570815e308);
     if (!finite) atomicOr(g.status, kStNonFinite);
-    g.items[i] = r;
     WorkRec w;
     // pad: bit 0 / bit 1 = node a / node b is a leaf (a one-element mesh: the root is the leaf), so that the
     // depth-first kernel can start a seed without reading the two nodes first
@@ -139,6 +154,18 @@ __global__ void k_setup_items(EvalArgs g) {
     g.frontier0[i] = w;
     *reinterpret_cast<int4 *>(g.icnt + 4 * (size_t)i) = make_int4(0, 0, 0, 0);
     if (i == 0) g.fcount[0] = g.n_items;
+}
+
+// After the broadphase of an evaluation with a broadphase pose of its own: x_r1_r2 of the item records becomes the pose's
+// (the tet-tet op and the Dual passes read it: find_plane_tet, non_friction.jl:164,174-177).
+__global__ void k_repose(int n_items, const double *__restrict__ pose, ItemRec *__restrict__ items) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const double *p = pose + 24 * (size_t)i + 12;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) items[i].R12[k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) items[i].t12[k] = p[9 + k];
 }
 
 #include "pfc_bp.h"
@@ -194,9 +221,19 @@ enum { EV_START = 0, EV_SETUP, EV_BP, EV_NP, EV_BR, EV_FIN, EV_COUNT };
 
 }  // namespace
 
+struct pfc_multi;
 struct pfc_context {
     int device = 0;
     bool finalized = false;
+    pfc_multi *multi = nullptr;          // non-null: a multi-device handle (pfc_create_multi); everything below belongs to its shards
+    // Broadphase pose of the evaluation being enqueued (device-visible, n_items x 24, only x_r1_r2 is read) or null: set by the
+    // pfc_eval_dual*_bp entry points around the value pass (record_eval, enqueue_fused)
+    const double *bp_dev = nullptr;
+    void *pin_bp = nullptr;              // pinned host copy of the last broadphase pose block (pfc_eval_dual_bp)
+    size_t pin_bp_cap = 0;
+    int pin_bp_n = 0;                    // items it holds (0: the last host-buffer Dual evaluation had none)
+    bool team_owner = false;             // this handle holds its device's team slot (team_acquire)
+    int opt_team_fault = -1;             // diagnostic option "team_fault": rank of every team that simulates a timed-out wait
     std::string err;
     hipStream_t stream = nullptr;
     std::vector<HostMesh> meshes;
@@ -272,7 +309,7 @@ struct pfc_context {
     hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [0] plain evaluation, [1] with the contributing-pair list (Dual)
     struct GraphKey {
         int n_items, levels, L, debug, bristle, surv;
-        const void *p[8];
+        const void *p[9];
         void *stream;
         unsigned long long epoch;
     } gkey[2] = {};
@@ -339,7 +376,7 @@ struct pfc_context {
     int fu_nw = 1;                     // workgroups per item of the next fused launch (teams: k_fused<.., true>)
     int last_fu_nw = 0, last_team = 0; // of the last fused launch / of the last checked evaluation (pfc_last_team)
     int n_cu = 0;                      // compute units of the device (a team launch keeps every workgroup resident: one per CU)
-    int opt_team = 48;                 // option "team": big pairs (more leaves than one workgroup takes) run as teams of up to this many workgroups (0: batched path; <= kTeamMaxWg = 64).  Eight single C3 poses, mean / worst us: 64: 113 / 122, 48: 112 / 118, 32: 113 / 122, 24: 126 / 190, 16: 178 / 249, batched 132 / 136 (scripts/lat_c3_poses.py)
+    int opt_team = 48;                 // option "team": big pairs (more leaves than one workgroup takes) run as teams of up to this many workgroups (0: batched path; <= kTeamMaxWg = 48: s_team and the gather's per-thread granule count are sized from it).  Eight single C3 poses, mean / worst us (an earlier build that allowed 64): 64: 113 / 122, 48: 112 / 118, 32: 113 / 122, 24: 126 / 190, 16: 178 / 249, batched 132 / 136 (scripts/lat_c3_poses.py)
     DevBuf<unsigned long long> team;   // team partial sums: kTeamMaxBlocks x 3 x 2 kTeamSlots granules, zeroed once (tags are launch sequence numbers >= 1)
     DevBuf<int> emit_ctr;              // pair counter of the fused kernel's hand-over to the batched Dual passes
     int *h_emit = nullptr;             // pinned mirror
@@ -578,6 +615,7 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
 
     EvalArgs ea;
     ea.n_items = n_items; ea.ins_ids = d_ins_ids; ea.pose = d_pose; ea.twist = d_twist; ea.s = d_s;
+    ea.bp_pose = h->bp_dev;
     ea.ins = h->d_ins; ea.meshes = h->d_meshes; ea.n_ins = (int)h->ins.size(); ea.items = h->items.p;
     ea.frontier0 = h->frontier[0].p; ea.fcount = fcount; ea.acc = h->acc.p; ea.icnt = h->icnt.p;
     ea.status = h->status.p;
@@ -627,6 +665,8 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
                 hipLaunchKernelGGL((k_bp_dfs32<kDfsBlock>), dim3(grid_for(bound, 1, 256 * 6)), dim3(kDfsBlock), 0, st, f);
         }
     }
+    if (h->bp_dev)      // the broadphase ran on a pose of its own: the item records get the evaluation's x_r1_r2 back
+        hipLaunchKernelGGL(k_repose, dim3(grid_for(n_items, 64, 1 << 20)), dim3(64), 0, st, n_items, d_pose, h->items.p);
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));
 
     NpArgs np;
@@ -725,7 +765,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
         key.bristle = (h->any_bristle ? 1 : 0) | (h->any_tet_tet ? 2 : 0);
         key.surv = h->want_surv ? 1 : 0;
         key.p[0] = d_ins_ids; key.p[1] = d_pose; key.p[2] = d_twist; key.p[3] = d_s; key.p[4] = d_wrench;
-        key.p[5] = d_sdot; key.p[6] = d_counts; key.p[7] = h->tail_dev; key.stream = (void *)st; key.epoch = h->epoch;
+        key.p[5] = d_sdot; key.p[6] = d_counts; key.p[7] = h->tail_dev; key.p[8] = h->bp_dev; key.stream = (void *)st; key.epoch = h->epoch;
         const int gi = key.surv;   // Radau alternates value and Dual evaluations: both graphs stay instantiated
         if (!h->ghave[gi] || std::memcmp(&key, &h->gkey[gi], sizeof key) != 0) {
             if (h->gexec[gi]) { (void)hipGraphExecDestroy(h->gexec[gi]); h->gexec[gi] = nullptr; }
@@ -805,9 +845,11 @@ int check_one(pfc_context *h) {
 
 // Synchronise the pending evaluation (both halves of a split one) and merge the counters.
 int check_fused(pfc_context *h);
+void team_release(pfc_context *h);
 int check_eval(pfc_context *h) {
     if (h->pending_fused) return check_fused(h);
     h->last_fused = false;
+    team_release(h);
     if (!h->split_n0) {
         h->last_parts = 1;
         const int rc0 = check_one(h);
@@ -833,6 +875,26 @@ int check_eval(pfc_context *h) {
 // ---- fused small-scene path (pfc_fused.h) -------------------------------------------------------------------------
 constexpr int kFusedMaxItems = 256;      // one workgroup (one CU) per item
 constexpr int kFusedMaxLeaves = 6144;    // n_leaf(mesh_1) + n_leaf(mesh_2): above this one workgroup's descent is the slower one
+
+// Teams of workgroups wait for each other inside a launch, so two team launches that are each only PARTLY resident can keep
+// each other's missing workgroups off the chip until the bounded spin (~65 ms, kTeamSpinMax) gives up.  Within one process
+// that cannot happen any more: a device has ONE team slot, held by the handle whose team evaluation is in flight (from the
+// enqueue to the check); a handle that finds the slot taken evaluates without a team at once (one workgroup per item, or the
+// batched path).  Kernels that do not wait for anybody (every other kernel of the library) only delay a team, they finish.
+// Across processes the bounded spin stays the safety net.
+std::atomic<pfc_context *> g_team_slot[64];
+bool team_acquire(pfc_context *h) {
+    if (h->team_owner) return true;
+    pfc_context *expect = nullptr;
+    if (!g_team_slot[h->device & 63].compare_exchange_strong(expect, h)) return false;
+    h->team_owner = true;
+    return true;
+}
+void team_release(pfc_context *h) {
+    if (!h->team_owner) return;
+    h->team_owner = false;
+    g_team_slot[h->device & 63].store(nullptr);
+}
 
 bool fused_ok(const pfc_context *h, int n_items) {
     return h->opt_fused && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv &&
@@ -908,6 +970,7 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
     HIP_TRY(h, h->stamps.ensure(16));
     a.stamps = h->stamps.p;
 #endif
+    a.bp_pose = h->bp_dev; a.team_fault = h->opt_team_fault;
     a.nw = h->fu_nw; a.team = nullptr;
     a.team_seeds = h->max_leaves > kFusedMaxLeaves ? kTeamSeedsBig : kTeamSeeds;
     h->last_fu_nw = a.nw;
@@ -956,6 +1019,7 @@ int check_fused(pfc_context *h) {
         }
     }
     h->pending = false; h->pending_fused = false; h->last_parts = 1; h->last_fused = true;
+    team_release(h);
     unsigned status = 0;
     long long tot[4] = {0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
@@ -1057,6 +1121,8 @@ hipError_t ensure_dual(pfc_context *h, DevBuf<T> &b, size_t n) {
     return e;
 }
 
+#include "pfc_multi.h"
+
 extern "C" {
 
 int pfc_version(void) { return PFC_VERSION; }
@@ -1067,6 +1133,9 @@ int pfc_build_info(void) {
     f |= 1;
 #endif
     f |= (PFC_EXP & 0xFF) << 8;
+#ifdef PFC_VARIANT
+    f |= 1 << 16;      // built by scripts/mkvar.sh from patched sources (an A/B variant, not the product)
+#endif
     return f;
 }
 
@@ -1086,11 +1155,69 @@ int pfc_create(int device, pfc_handle *out) {
     return PFC_OK;
 }
 
+int pfc_create_multi(const int *devices, int n_devices, pfc_handle *out) {
+    if (!out) return PFC_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64) return PFC_ERR_BAD_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return PFC_ERR_HIP;
+    for (int k = 0; k < n_devices; ++k)
+        if (devices[k] < 0 || devices[k] >= n) return PFC_ERR_HIP;
+    pfc_context *h = new (std::nothrow) pfc_context();
+    pfc_multi *M = new (std::nothrow) pfc_multi();
+    if (!h || !M) { delete h; delete M; return PFC_ERR_NOMEM; }
+    h->device = devices[0];
+    h->multi = M;
+    M->dev.assign(devices, devices + n_devices);
+    M->stage.resize((size_t)n_devices);
+    int rc = PFC_OK;
+    for (int k = 0; k < n_devices && rc == PFC_OK; ++k) {
+        pfc_handle c = nullptr;
+        rc = pfc_create(devices[k], &c);
+        if (rc != PFC_OK) break;
+        M->shard.push_back(c);
+        if (hipEventCreateWithFlags(&M->stage[k].done, hipEventDisableTiming) != hipSuccess) rc = PFC_ERR_HIP;
+        // direct peer copies between the first device and this one where the hardware allows it (xGMI); failures -- same device,
+        // already enabled, no peer path -- leave the staged copy of hipMemcpyPeerAsync
+        if (devices[k] != devices[0]) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[k], devices[0]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[0], 0);
+            (void)hipGetLastError();
+        }
+    }
+    if (rc == PFC_OK) {
+        (void)hipSetDevice(devices[0]);
+        for (int k = 1; k < n_devices; ++k)
+            if (devices[k] != devices[0]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[0], devices[k]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[k], 0);
+                (void)hipGetLastError();
+            }
+        if (hipEventCreateWithFlags(&M->ev_fork, hipEventDisableTiming) != hipSuccess) rc = PFC_ERR_HIP;
+    }
+    if (rc == PFC_OK) {
+        for (int k = 1; k < n_devices; ++k) {
+            pfc_multi::Worker *w = new (std::nothrow) pfc_multi::Worker();
+            if (!w) { rc = PFC_ERR_NOMEM; break; }
+            M->workers.push_back(w);
+            w->th = std::thread(multi_worker_loop, w, devices[k]);
+        }
+    }
+    if (rc != PFC_OK) { multi_destroy(h); delete h; return rc; }
+    *out = h;
+    return PFC_OK;
+}
+
+int pfc_last_shards(pfc_handle h) { return h ? (h->multi ? h->multi->n_used : 1) : 0; }
+
 void pfc_destroy(pfc_handle h) {
     if (!h) return;
+    if (h->multi) { multi_destroy(h); delete h; return; }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);   // an unchecked pfc_eval_device on the caller's stream
+    team_release(h);
+    if (h->pin_bp) (void)hipHostFree(h->pin_bp);
     if (h->twin) { pfc_destroy(h->twin); h->twin = nullptr; }
     if (h->twin_stream) { (void)hipStreamDestroy(h->twin_stream); h->twin_stream = nullptr; }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1136,6 +1263,16 @@ int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int
                  const double *eps, double Ebar, int n_node, const double *node_c, const double *node_e,
                  const double *node_R, const int *node_child, const int *node_leaf) {
     if (!h) return -PFC_ERR_BAD_ARG;
+    if (h->multi) {      // replicated on every shard (the ids agree: same sequence of calls)
+        int id0 = -1;
+        for (size_t k = 0; k < h->multi->shard.size(); ++k) {
+            const int id = pfc_add_mesh(h->multi->shard[k], n_pt, xyz, n_tri, tri, n_tet, tet, eps, Ebar, n_node, node_c, node_e, node_R,
+                                        node_child, node_leaf);
+            if (id < 0) { h->err = h->multi->shard[k]->err; return id; }
+            if (k == 0) id0 = id;
+        }
+        return id0;
+    }
     if (h->finalized) return -fail(h, PFC_ERR_STATE, "pfc_add_mesh after pfc_finalize");
     if (n_pt <= 0 || !xyz || n_node <= 0 || !node_c || !node_e || !node_R || !node_child || !node_leaf)
         return -fail(h, PFC_ERR_BAD_ARG, "pfc_add_mesh: null or empty argument");
@@ -1269,6 +1406,15 @@ int pfc_add_mesh(pfc_handle h, int n_pt, const double *xyz, int n_tri, const int
 
 int pfc_add_instruction(pfc_handle h, int id_1, int id_2, double chi, int n_quad, int model, const double *params) {
     if (!h) return -PFC_ERR_BAD_ARG;
+    if (h->multi) {
+        int id0 = -1;
+        for (size_t k = 0; k < h->multi->shard.size(); ++k) {
+            const int id = pfc_add_instruction(h->multi->shard[k], id_1, id_2, chi, n_quad, model, params);
+            if (id < 0) { h->err = h->multi->shard[k]->err; return id; }
+            if (k == 0) id0 = id;
+        }
+        return id0;
+    }
     if (h->finalized) return -fail(h, PFC_ERR_STATE, "pfc_add_instruction after pfc_finalize");
     const int nm = (int)h->meshes.size();
     if (id_1 < 0 || id_1 >= nm || id_2 < 0 || id_2 >= nm || !params)
@@ -1296,6 +1442,14 @@ int pfc_add_instruction(pfc_handle h, int id_1, int id_2, double chi, int n_quad
 
 int pfc_finalize(pfc_handle h) {
     if (!h) return PFC_ERR_BAD_ARG;
+    if (h->multi) {      // every device uploads its replica at the same time
+        pfc_multi *M = h->multi;
+        std::vector<std::function<int()>> jobs(M->shard.size());
+        for (size_t k = 0; k < M->shard.size(); ++k) { pfc_context *c = M->shard[k]; jobs[k] = [c]() { return pfc_finalize(c); }; }
+        const int rc = multi_run(h, jobs);
+        h->finalized = rc == PFC_OK;
+        return rc;
+    }
     if (h->finalized) return fail(h, PFC_ERR_STATE, "pfc_finalize called twice");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, h->status.ensure(4));
@@ -1412,6 +1566,9 @@ static int check_eval_args(pfc_context *h, int n_items, const void *ins_ids, con
 int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const double *d_pose, const double *d_twist,
                     const double *d_s, double *d_wrench, double *d_sdot, int *d_counts, void *stream) {
     if (!h) return PFC_ERR_BAD_ARG;
+    if (h->multi)
+        return multi_eval_device(h, n_items, 0, d_ins_ids, d_pose, nullptr, d_twist, d_s, nullptr, nullptr, nullptr, d_wrench, d_sdot,
+                                 nullptr, nullptr, d_counts, stream);
     { const int rc = check_eval_args(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot); if (rc != PFC_OK) return rc; }
     if (n_items == 0) { h->pending = false; h->last_n_items = 0; return PFC_OK; }
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1419,7 +1576,9 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
     h->split_n0 = 0;
     h->pending_fused = false;
     h->dual_reuse_ok = false; h->pending_more = false;
-    if (const int team = fused_team(h, n_items)) {
+    int team = fused_team(h, n_items);
+    if (team > 1 && !team_acquire(h)) team = fused_ok(h, n_items) ? 1 : 0;     // another handle's teams are in flight on this device
+    if (team) {
         h->fu_nw = team;
         const int rc_t = enqueue_fused(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
         h->fu_nw = 1;
@@ -1467,6 +1626,7 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
 
 int pfc_check(pfc_handle h) {
     if (!h) return PFC_ERR_BAD_ARG;
+    if (h->multi) return multi_check(h);
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->pending_more) {       // Dual passes on a value pass that was checked before: nothing to read back
         h->pending_more = false;
@@ -1563,6 +1723,7 @@ static hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes) {
 int pfc_eval(pfc_handle h, int n_items, const int *ins_ids, const double *pose, const double *twist,
              const double *s, double *wrench, double *sdot, int *counts) {
     if (!h) return PFC_ERR_BAD_ARG;
+    if (h->multi) return multi_eval(h, n_items, ins_ids, pose, twist, s, wrench, sdot, counts);
     if (!h->finalized) return fail(h, PFC_ERR_STATE, "pfc_eval before pfc_finalize");
     if (n_items < 0) return fail(h, PFC_ERR_BAD_ARG, "negative n_items");
     if (n_items == 0) return PFC_OK;
@@ -1978,7 +2139,7 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     key.v.n_items = n_items; key.v.levels = levels; key.v.L = L; key.v.debug = 0;
     key.v.bristle = (h->any_bristle ? 1 : 0) | (h->any_tet_tet ? 2 : 0); key.v.surv = 1;
     key.v.p[0] = d_ins; key.v.p[1] = di; key.v.p[2] = di + n * 24; key.v.p[3] = d_sv; key.v.p[4] = dout;
-    key.v.p[5] = dout + n * 6; key.v.p[6] = dout + out_d; key.v.p[7] = v_out; key.v.stream = (void *)st; key.v.epoch = h->epoch;
+    key.v.p[5] = dout + n * 6; key.v.p[6] = dout + out_d; key.v.p[7] = v_out; key.v.p[8] = h->bp_dev; key.v.stream = (void *)st; key.v.epoch = h->epoch;
     key.n_dir = n_dir; key.bound = bound; key.din = ddi; key.dout = ddo;
     h->want_surv = true;
     h->tail_dev = (int *)v_out;
@@ -2033,11 +2194,29 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
 }
 }  // namespace
 
+int pfc_eval_dual_device_bp(pfc_handle h, int n_items, int n_dir, const int *d_ins_ids, const double *d_pose, const double *d_bp_pose,
+                            const double *d_twist, const double *d_s, const double *d_dpose, const double *d_dtwist,
+                            const double *d_ds, double *d_wrench, double *d_sdot, double *d_dwrench, double *d_dsdot,
+                            int *d_counts, void *stream) {
+    if (!h) return PFC_ERR_BAD_ARG;
+    if (h->multi)
+        return multi_eval_device(h, n_items, n_dir, d_ins_ids, d_pose, d_bp_pose, d_twist, d_s, d_dpose, d_dtwist, d_ds, d_wrench, d_sdot,
+                                 d_dwrench, d_dsdot, d_counts, stream);
+    h->bp_dev = d_bp_pose;
+    const int rc = pfc_eval_dual_device(h, n_items, n_dir, d_ins_ids, d_pose, d_twist, d_s, d_dpose, d_dtwist, d_ds, d_wrench, d_sdot,
+                                        d_dwrench, d_dsdot, d_counts, stream);
+    h->bp_dev = nullptr;
+    return rc;
+}
+
 int pfc_eval_dual_device(pfc_handle h, int n_items, int n_dir, const int *d_ins_ids, const double *d_pose,
                          const double *d_twist, const double *d_s, const double *d_dpose, const double *d_dtwist,
                          const double *d_ds, double *d_wrench, double *d_sdot, double *d_dwrench, double *d_dsdot,
                          int *d_counts, void *stream) {
     if (!h) return PFC_ERR_BAD_ARG;
+    if (h->multi)
+        return multi_eval_device(h, n_items, n_dir, d_ins_ids, d_pose, nullptr, d_twist, d_s, d_dpose, d_dtwist, d_ds, d_wrench, d_sdot,
+                                 d_dwrench, d_dsdot, d_counts, stream);
     if (n_dir < 1 || n_dir > 16) return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual_device: n_dir must be in 1..16");
     { const int rc = check_eval_args(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot); if (rc != PFC_OK) return rc; }
     h->pending_dual = false; h->dual_reuse_ok = false; h->pending_more = false;
@@ -2102,6 +2281,7 @@ int pfc_eval_dual_device(pfc_handle h, int n_items, int n_dir, const int *d_ins_
 int pfc_eval_dual_device_more(pfc_handle h, int n_dir, const double *d_dpose, const double *d_dtwist, const double *d_ds,
                               double *d_dwrench, double *d_dsdot, void *stream) {
     if (!h) return PFC_ERR_BAD_ARG;
+    if (h->multi) return multi_eval_dual_device_more(h, n_dir, d_dpose, d_dtwist, d_ds, d_dwrench, d_dsdot, stream);
     if (n_dir < 1 || n_dir > 16) return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual_device_more: n_dir must be in 1..16");
     if (!h->dual_reuse_ok)
         return fail(h, PFC_ERR_STATE, "pfc_eval_dual_device_more: no checked pfc_eval_dual_device evaluation on this handle to extend");
@@ -2135,10 +2315,48 @@ int pfc_eval_dual_device_more(pfc_handle h, int n_dir, const double *d_dpose, co
     return PFC_OK;
 }
 
+// The Dual evaluation with the broadphase pose of m.float's state (calcTriTetIntersections!, non_friction.jl:94-101): the block is
+// kept in pinned host memory, which the value pass reads in place (96 bytes per item, once).
+int pfc_eval_dual_bp(pfc_handle h, int n_items, int n_dir, const int *ins_ids, const double *pose, const double *bp_pose,
+                     const double *twist, const double *s, const double *d_pose, const double *d_twist, const double *d_s,
+                     double *wrench, double *sdot, double *d_wrench, double *d_sdot, int *counts) {
+    if (!h) return PFC_ERR_BAD_ARG;
+    if (h->multi)
+        return multi_eval_dual(h, n_items, n_dir, ins_ids, pose, bp_pose, twist, s, d_pose, d_twist, d_s, wrench, sdot, d_wrench, d_sdot, counts);
+    if (!bp_pose || n_items <= 0)
+        return pfc_eval_dual(h, n_items, n_dir, ins_ids, pose, twist, s, d_pose, d_twist, d_s, wrench, sdot, d_wrench, d_sdot, counts);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = sizeof(double) * 24 * (size_t)n_items;
+    {
+        const void *p0 = h->pin_bp;
+        HIP_TRY(h, ensure_pinned(&h->pin_bp, &h->pin_bp_cap, bytes));
+        if (h->pin_bp != p0) h->pin_bp_n = -1;
+    }
+    if (h->pin_bp_n != n_items || std::memcmp(h->pin_bp, bp_pose, bytes) != 0) {
+        // another broadphase pose: nothing a previous Dual evaluation left can be reused (the candidate lists differ)
+        h->dual_reuse_ok = false; h->hyb_reuse_ok = false; h->small_reuse_ok = false; h->pin_in_dual_n = 0; h->pin_din_valid = false;
+        std::memcpy(h->pin_bp, bp_pose, bytes);
+        h->pin_bp_n = n_items;
+    }
+    void *dev = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer(&dev, h->pin_bp, 0));
+    h->bp_dev = (const double *)dev;
+    const int rc = pfc_eval_dual(h, n_items, n_dir, ins_ids, pose, twist, s, d_pose, d_twist, d_s, wrench, sdot, d_wrench, d_sdot, counts);
+    h->bp_dev = nullptr;
+    return rc;
+}
+
 int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, const double *pose, const double *twist,
                   const double *s, const double *d_pose, const double *d_twist, const double *d_s, double *wrench,
                   double *sdot, double *d_wrench, double *d_sdot, int *counts) {
     if (!h) return PFC_ERR_BAD_ARG;
+    if (h->multi)
+        return multi_eval_dual(h, n_items, n_dir, ins_ids, pose, nullptr, twist, s, d_pose, d_twist, d_s, wrench, sdot, d_wrench, d_sdot, counts);
+    if (!h->bp_dev && h->pin_bp_n != 0) {
+        // the previous host-buffer Dual evaluation culled with a pose of its own: its lists are not this evaluation's
+        h->dual_reuse_ok = false; h->hyb_reuse_ok = false; h->small_reuse_ok = false; h->pin_in_dual_n = 0; h->pin_din_valid = false;
+        h->pin_bp_n = 0;
+    }
     if (n_dir < 1 || n_dir > 16) return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: n_dir must be in 1..16");
     if (n_items > 0 && (!d_pose || !d_twist || !d_wrench || !d_sdot))
         return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual: null buffer");
@@ -2306,6 +2524,14 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
 
 int pfc_set_option(pfc_handle h, const char *name, long long value) {
     if (!h || !name) return PFC_ERR_BAD_ARG;
+    if (h->multi) {
+        if (!std::strcmp(name, "multi_min")) { h->multi->opt_min_items = value < 1 ? 1 : (int)value; h->multi->part_n = 0; return PFC_OK; }
+        for (pfc_context *c : h->multi->shard) {
+            const int rc = pfc_set_option(c, name, value);
+            if (rc != PFC_OK) { h->err = c->err; return rc; }
+        }
+        return PFC_OK;
+    }
     h->dual_reuse_ok = false; h->hyb_reuse_ok = false; h->small_reuse_ok = false;
     if (!std::strcmp(name, "debug")) h->opt_debug = value != 0;
     else if (!std::strcmp(name, "profile")) h->opt_profile = value != 0;
@@ -2323,6 +2549,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "poison")) h->opt_poison = value != 0;
     else if (!std::strcmp(name, "fused")) { h->opt_fused = value != 0; h->fused_skip = 0; }
     else if (!std::strcmp(name, "team")) h->opt_team = value < 0 ? 0 : (value > kTeamMaxWg ? kTeamMaxWg : (int)value);
+    else if (!std::strcmp(name, "team_fault")) h->opt_team_fault = (int)value;
     else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;
@@ -2330,12 +2557,18 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
 
 int pfc_get_stats(pfc_handle h, long long *out8) {
     if (!h || !out8) return PFC_ERR_BAD_ARG;
+    if (h->multi) { for (int k = 0; k < 8; ++k) out8[k] = h->multi->stats[k]; return PFC_OK; }
     for (int k = 0; k < 8; ++k) out8[k] = h->stats[k];
     return PFC_OK;
 }
 
 int pfc_get_stage_ms(pfc_handle h, float *out6) {
     if (!h || !out6) return PFC_ERR_BAD_ARG;
+    if (h->multi) {      // the first shard's stages (every shard runs the same sequence on its range)
+        const int rc = pfc_get_stage_ms(h->multi->shard[0], out6);
+        if (rc != PFC_OK) h->err = h->multi->shard[0]->err;
+        return rc;
+    }
     if (!h->ev_valid) return fail(h, PFC_ERR_STATE, "profile option was off for the last evaluation");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipEventSynchronize(h->ev[EV_FIN]));
@@ -2354,12 +2587,28 @@ int pfc_get_stage_ms(pfc_handle h, float *out6) {
     return PFC_OK;
 }
 
-int pfc_last_parts(pfc_handle h) { return h ? (h->last_fused ? 0 : h->last_parts) : 0; }
-int pfc_last_team(pfc_handle h) { return h ? (h->last_fused ? h->last_fu_nw : 0) : 0; }
-int pfc_last_dual_reused(pfc_handle h) { return h ? (h->last_dual_reused ? 1 : 0) : 0; }
+int pfc_last_parts(pfc_handle h) { return h ? (h->multi ? pfc_last_parts(h->multi->shard[0]) : (h->last_fused ? 0 : h->last_parts)) : 0; }
+int pfc_last_team(pfc_handle h) { return h ? (h->multi ? pfc_last_team(h->multi->shard[0]) : (h->last_fused ? h->last_fu_nw : 0)) : 0; }
+int pfc_last_dual_reused(pfc_handle h) {
+    if (!h) return 0;
+    if (h->multi) {      // 1 only if every shard that took part reused its value pass
+        for (int k = 0; k < h->multi->n_used; ++k)
+            if (h->multi->bound[k + 1] > h->multi->bound[k] && !h->multi->shard[k]->last_dual_reused) return 0;
+        return 1;
+    }
+    return h->last_dual_reused ? 1 : 0;
+}
 
 int pfc_debug_pairs(pfc_handle h, int item, int *pairs, int *clip_n, int cap) {
     if (!h) return -PFC_ERR_BAD_ARG;
+    if (h->multi) {
+        int local = 0;
+        pfc_context *c = multi_locate(h, item, &local);
+        if (!c) return -fail(h, PFC_ERR_BAD_ARG, "bad item");
+        const int r = pfc_debug_pairs(c, local, pairs, clip_n, cap);
+        if (r < 0) h->err = c->err;
+        return r;
+    }
     if (!h->opt_debug) return -fail(h, PFC_ERR_STATE, "debug option is off");
     if (h->pending) { int rc = check_eval(h); if (rc) return -rc; }
     if (item < 0 || item >= h->last_n_items) return -fail(h, PFC_ERR_BAD_ARG, "bad item");
@@ -2385,6 +2634,14 @@ int pfc_debug_pairs(pfc_handle h, int item, int *pairs, int *clip_n, int cap) {
 
 int pfc_debug_tractions(pfc_handle h, int item, double *buf, int cap) {
     if (!h) return -PFC_ERR_BAD_ARG;
+    if (h->multi) {
+        int local = 0;
+        pfc_context *c = multi_locate(h, item, &local);
+        if (!c) return -fail(h, PFC_ERR_BAD_ARG, "bad item");
+        const int r = pfc_debug_tractions(c, local, buf, cap);
+        if (r < 0) h->err = c->err;
+        return r;
+    }
     if (!h->opt_debug) return -fail(h, PFC_ERR_STATE, "debug option is off");
     if (h->pending) { int rc = check_eval(h); if (rc) return -rc; }
     if (item < 0 || item >= h->last_n_items) return -fail(h, PFC_ERR_BAD_ARG, "bad item");
@@ -2410,6 +2667,14 @@ int pfc_debug_tractions(pfc_handle h, int item, double *buf, int cap) {
 
 int pfc_debug_stiffness(pfc_handle h, int item, double *K36, double *Kis36, double *Sinv6, double *cop3) {
     if (!h) return -PFC_ERR_BAD_ARG;
+    if (h->multi) {
+        int local = 0;
+        pfc_context *c = multi_locate(h, item, &local);
+        if (!c) return -fail(h, PFC_ERR_BAD_ARG, "bad item");
+        const int r = pfc_debug_stiffness(c, local, K36, Kis36, Sinv6, cop3);
+        if (r < 0) h->err = c->err;
+        return r;
+    }
     if (h->pending) { int rc = check_eval(h); if (rc) return -rc; }
     if (h->last_fused)      // the fused small-scene kernel keeps K in LDS only
         return -fail(h, PFC_ERR_STATE, "pfc_debug_stiffness: set option debug (or fused = 0) before the evaluation");
@@ -2430,6 +2695,11 @@ int pfc_debug_stiffness(pfc_handle h, int item, double *K36, double *Kis36, doub
 int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, const double *x_w_r2, const int *body_1,
                             const int *body_2, const int *scene, int n_scene, int n_body, int nv, const double *jac,
                             double *f_out) {
+    if (h && h->multi) {      // a few microseconds of work: the first device does it
+        const int rc = pfc_scatter_generalized(h->multi->shard[0], n_items, wrench, x_w_r2, body_1, body_2, scene, n_scene, n_body, nv, jac, f_out);
+        if (rc != PFC_OK) h->err = h->multi->shard[0]->err;
+        return rc;
+    }
     if (!h || n_items < 0 || nv <= 0 || n_scene <= 0 || n_body < 0 || !f_out)
         return fail(h, PFC_ERR_BAD_ARG, "pfc_scatter_generalized: bad argument");
     if (n_items > 0 && (!wrench || !x_w_r2 || !body_1 || !body_2 || (n_body > 0 && !jac)))
@@ -2469,6 +2739,12 @@ int pfc_scatter_generalized(pfc_handle h, int n_items, const double *wrench, con
 int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wrench, const double *d_x_w_r2, const int *d_body_1,
                                    const int *d_body_2, const int *d_scene, int n_scene, int nv, const double *d_jac, double *d_f,
                                    int accumulate, void *stream) {
+    if (h && h->multi) {      // the wrenches of a multi-device evaluation end up on the first device: so does this
+        const int rc = pfc_scatter_generalized_device(h->multi->shard[0], n_items, d_wrench, d_x_w_r2, d_body_1, d_body_2, d_scene, n_scene, nv,
+                                                      d_jac, d_f, accumulate, stream);
+        if (rc != PFC_OK) h->err = h->multi->shard[0]->err;
+        return rc;
+    }
     if (!h || n_items < 0 || nv <= 0 || n_scene <= 0 || !d_f)
         return fail(h, PFC_ERR_BAD_ARG, "pfc_scatter_generalized_device: bad argument");
     if (n_items > 0 && (!d_wrench || !d_x_w_r2 || !d_body_1 || !d_body_2 || !d_jac))
@@ -2489,6 +2765,7 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
 
 int pfc_debug_stamps(pfc_handle h, long long *out16) {
     if (!h || !out16) return PFC_ERR_BAD_ARG;
+    if (h->multi) return pfc_debug_stamps(h->multi->shard[0], out16);
     if (h->pending) { int rc = check_eval(h); if (rc) return rc; }
     unsigned long long v[16] = {0};
     if (h->stamps.p) HIP_TRY(h, copy_sync(h, v, h->stamps.p, sizeof v, hipMemcpyDeviceToHost));
@@ -2502,6 +2779,7 @@ int pfc_debug_stamps(pfc_handle h, long long *out16) {
 
 int pfc_selftest_math(pfc_handle h, int n, const double *x, const double *y, double *out3n) {
     if (!h || n <= 0 || !x || !y || !out3n) return PFC_ERR_BAD_ARG;
+    if (h->multi) return pfc_selftest_math(h->multi->shard[0], n, x, y, out3n);
     HIP_TRY(h, hipSetDevice(h->device));
     double *dx = nullptr, *dy = nullptr, *dout = nullptr;
     HIP_TRY(h, hipMalloc((void **)&dx, sizeof(double) * n));

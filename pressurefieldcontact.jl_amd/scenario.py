@@ -176,12 +176,16 @@ class BoundEvaluation:
                 raise ValueError("ins_ids must have one entry per item")
         self.wrench = np.zeros((n, 6)); self.sdot = np.zeros((n, 6)); self.counts = np.zeros((n, 4), dtype=np.int32)
         self._fn = _lib.lib().pfc_eval_addr
-        self._args = (scenario._h, n, None if self.ins_ids is None else self.ins_ids.ctypes.data, self.pose.ctypes.data,
+        # (the handle is NOT captured: after MechanismScenario.close() a call must raise, not hand a freed handle to the library)
+        self._args = (n, None if self.ins_ids is None else self.ins_ids.ctypes.data, self.pose.ctypes.data,
                       self.twist.ctypes.data, None if self.s is None else self.s.ctypes.data, self.wrench.ctypes.data,
                       self.sdot.ctypes.data, self.counts.ctypes.data)
 
     def __call__(self):
-        rc = self._fn(*self._args)
+        h = self._m._h
+        if h is None:
+            raise RuntimeError("the scenario of this BoundEvaluation has been closed")
+        rc = self._fn(h, *self._args)
         if rc != 0:
             self._m._check(rc)
         return self.wrench, self.sdot, self.counts
@@ -190,11 +194,14 @@ class BoundEvaluation:
 class MechanismScenario:
     """Contact part of MechanismScenario{T} (src/mechanism_scenario.jl:166-199), backed by a pfc_handle."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, devices: Optional[Sequence[int]] = None):
+        """device: the HIP device of the scenario; devices: a list of HIP devices instead (pfc_create_multi: the one host
+        process uses them all, items are cut into ranges per device inside the library)."""
         self.MeshCache: List[MeshCache] = []
         self.ContactInstructions: List[ContactInstructions] = []
         self.n_bristle = 0
         self.device = device
+        self.devices = None if devices is None else [int(d) for d in devices]
         self._h = None
         self._finalized = False
 
@@ -280,7 +287,11 @@ class MechanismScenario:
             raise RuntimeError("finalize called twice")
         L = _lib.lib()
         h = C.c_void_p()
-        rc = L.pfc_create(self.device, C.byref(h))
+        if self.devices is not None:
+            dv = (C.c_int * len(self.devices))(*self.devices)
+            rc = L.pfc_create_multi(dv, len(self.devices), C.byref(h))
+        else:
+            rc = L.pfc_create(self.device, C.byref(h))
         if rc != _lib.OK:
             raise _lib.PFCError(rc, "pfc_create failed: no usable HIP device (there is no CPU fallback)")
         self._h = h
@@ -360,10 +371,12 @@ class MechanismScenario:
         return BoundEvaluation(self, pose, twist, s, ins_ids)
 
     def force_all_elastic_intersections_dual(self, pose, twist, s, d_pose, d_twist, d_s=None,
-                                             ins_ids: Optional[Sequence[int]] = None):
+                                             ins_ids: Optional[Sequence[int]] = None, bp_pose=None):
         """The evaluation on Dual numbers (MechanismScenario.dual, src/mechanism_scenario.jl:187): values plus, for
         each of n_dir seed directions, the partials.  d_pose (n, n_dir, 24), d_twist (n, n_dir, 6), d_s (n, n_dir, 6)
-        or None.  Returns (wrench, sdot, d_wrench (n, n_dir, 6), d_sdot (n, n_dir, 6), counts)."""
+        or None.  bp_pose (n, 24) or None: the pose the broadphase culls with -- the reference takes m.float's
+        (calcTriTetIntersections!, src/contact_algorithms_non_friction.jl:94-101), i.e. the pose of the last Float64
+        evaluation; None = pose.  Returns (wrench, sdot, d_wrench (n, n_dir, 6), d_sdot (n, n_dir, 6), counts)."""
         if not self._finalized:
             raise RuntimeError("finalize the scenario first")
         pose_a, pose_p = _da(pose)
@@ -391,8 +404,15 @@ class MechanismScenario:
                 raise ValueError("ins_ids must have one entry per item")
         wrench = np.zeros((n, 6)); sdot = np.zeros((n, 6)); counts = np.zeros((n, 4), dtype=np.int32)
         dw = np.zeros((n, n_dir, 6)); dsd = np.zeros((n, n_dir, 6))
-        rc = _lib.lib().pfc_eval_dual_addr(self._h, n, n_dir, id_p, pose_p, tw_p, s_p, dp_p, dt_p, ds_p, _addr(wrench),
-                                           _addr(sdot), _addr(dw), _addr(dsd), _addr(counts))
+        if bp_pose is not None:
+            bp_a, bp_p = _da(bp_pose)
+            if bp_a.size != 24 * n:
+                raise ValueError("bp_pose must have 24 entries per item")
+            rc = _lib.lib().pfc_eval_dual_bp_addr(self._h, n, n_dir, id_p, pose_p, bp_p, tw_p, s_p, dp_p, dt_p, ds_p, _addr(wrench),
+                                                  _addr(sdot), _addr(dw), _addr(dsd), _addr(counts))
+        else:
+            rc = _lib.lib().pfc_eval_dual_addr(self._h, n, n_dir, id_p, pose_p, tw_p, s_p, dp_p, dt_p, ds_p, _addr(wrench),
+                                               _addr(sdot), _addr(dw), _addr(dsd), _addr(counts))
         if rc != 0:
             self._check(rc)
         return wrench, sdot, dw, dsd, counts
@@ -429,11 +449,11 @@ class MechanismScenario:
 
     def eval_dual_device(self, n_items: int, n_dir: int, d_ins_ids: int, d_pose: int, d_twist: int, d_s: int, d_dpose: int,
                          d_dtwist: int, d_ds: int, d_wrench: int, d_sdot: int, d_dwrench: int, d_dsdot: int, d_counts: int,
-                         stream: int = 0):
-        """pfc_eval_dual_device: raw device addresses; asynchronous; follow with check() (re-issue on ERR_OVERFLOW)."""
-        self._check(_lib.lib().pfc_eval_dual_device(self._h, int(n_items), int(n_dir), d_ins_ids or None, d_pose, d_twist,
-                                                    d_s or None, d_dpose, d_dtwist, d_ds or None, d_wrench, d_sdot,
-                                                    d_dwrench, d_dsdot, d_counts or None, stream or None))
+                         stream: int = 0, d_bp_pose: int = 0):
+        """pfc_eval_dual_device[_bp]: raw device addresses; asynchronous; follow with check() (re-issue on ERR_OVERFLOW)."""
+        self._check(_lib.lib().pfc_eval_dual_device_bp(self._h, int(n_items), int(n_dir), d_ins_ids or None, d_pose, d_bp_pose or None,
+                                                       d_twist, d_s or None, d_dpose, d_dtwist, d_ds or None, d_wrench, d_sdot,
+                                                       d_dwrench, d_dsdot, d_counts or None, stream or None))
 
     def eval_dual_device_more(self, n_dir: int, d_dpose: int, d_dtwist: int, d_ds: int, d_dwrench: int, d_dsdot: int,
                               stream: int = 0):
@@ -459,6 +479,10 @@ class MechanismScenario:
         """1, or 2 if the last checked evaluation ran as two concurrent halves (option split_min); 0 if it ran as the
         single fused small-scene kernel (option fused)."""
         return int(_lib.lib().pfc_last_parts(self._h))
+
+    def last_shards(self) -> int:
+        """Devices that took part in the last evaluation (1 for a single-device scenario)."""
+        return int(_lib.lib().pfc_last_shards(self._h))
 
     def last_team(self) -> int:
         """Workgroups per item of the last checked evaluation if it ran as one fused kernel (> 1: a team per item), else 0."""

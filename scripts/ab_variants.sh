@@ -12,5 +12,5 @@ print('%-10s $ARGS ms_per_step %.3f  bp %.2f np %.2f br %.2f' % ('$1', d['ms_per
 }
 for k in 1 2 3; do
   unset PFC_LIB; run product
-  for v in "$@"; do export PFC_LIB=$PWD/pressurefieldcontact.jl_amd/csrc/exp/$v.so; run $v; done
+  for v in "$@"; do export PFC_LIB=$PWD/build/variants/$v.so; run $v; done
 done

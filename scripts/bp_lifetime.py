@@ -1,6 +1,6 @@
 """Diagnostic: lifetimes of the broadphase workgroups of one launch (span, first exit, mean lifetime, where the time goes).
 Needs the variant build  EXTRA_FLAGS=-DPFC_STAMPS bash scripts/mkvar.sh $PWD/scripts/variants/bp_lifetime.py bplife  and
-PFC_LIB=.../csrc/exp/bplife.so PFC_ALLOW_DIAGNOSTIC=1.  usage: bp_lifetime.py [poses] [split_min]"""
+PFC_LIB=.../build/variants/bplife.so PFC_ALLOW_DIAGNOSTIC=1.  usage: bp_lifetime.py [poses] [split_min]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pfc_pkg

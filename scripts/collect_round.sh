@@ -16,7 +16,7 @@ bash scripts/timeline.sh $T > /dev/null 2>&1
 timeout 300 python scripts/latency.py 2>&1 | grep -v amdgpu > $O/${T}_latency.txt
 timeout 300 python scripts/crossover.py 2>&1 | grep -v amdgpu > $O/${T}_crossover.txt
 gcc -O2 -I include examples/box_on_plane.c -L pressurefieldcontact.jl_amd/csrc -lpfc_hip -Wl,-rpath,$PWD/pressurefieldcontact.jl_amd/csrc -lm -o /tmp/box_on_plane && timeout 60 /tmp/box_on_plane 5000 > $O/${T}_c_example.txt 2>&1
-(export PFC_LIB=$PWD/pressurefieldcontact.jl_amd/csrc/exp/stamps.so PFC_ALLOW_DIAGNOSTIC=1; for c in c1 c2 c4 c3r pencil c3; do timeout 120 python scripts/small_scene.py $c 300 1; done) 2>&1 | grep -v amdgpu > $O/${T}_fused_phases.txt
+(export PFC_LIB=$PWD/build/variants/stamps.so PFC_ALLOW_DIAGNOSTIC=1; for c in c1 c2 c4 c3r pencil c3; do timeout 120 python scripts/small_scene.py $c 300 1; done) 2>&1 | grep -v amdgpu > $O/${T}_fused_phases.txt
 (timeout 200 python scripts/lat_c3.py; timeout 300 python scripts/lat_c3_poses.py 48,32,24,16,0) 2>&1 | grep -v amdgpu > $O/${T}_team_sizes.txt
 timeout 200 python scripts/pencil_like.py 2>&1 | grep -v amdgpu > $O/${T}_pencil_like.txt
 echo collected

@@ -1,10 +1,10 @@
-"""Experiment (variant library csrc/exp/phase.so, scripts/variants/phase_probe.py): what would the 8 192-pose step cost if
+"""Experiment (variant library build/variants/phase.so, scripts/variants/phase_probe.py): what would the 8 192-pose step cost if
 the narrowphase + bristle passes of PARTS of the batch ran beside ONE broadphase launch over the whole batch (a device-side
 hand-over per part instead of the two-half scheme)?  The probe runs the broadphase of the whole batch (handle A, phase 1) on
 one stream and the narrowphase + bristle passes of k parts (handles B, C: phase 2 on candidate lists of earlier normal
 evaluations) on one or two other streams, all enqueued at once -- the upper bound of what such a hand-over could gain
 (nothing waits for its producer).
-usage: PFC_LIB=.../exp/phase.so PFC_ALLOW_DIAGNOSTIC=1 python scripts/dataflow_probe.py [poses] [parts]"""
+usage: PFC_LIB=.../build/variants/phase.so PFC_ALLOW_DIAGNOSTIC=1 python scripts/dataflow_probe.py [poses] [parts]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

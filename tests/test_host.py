@@ -200,6 +200,37 @@ def test_c_abi_exports_every_declared_symbol(pfc):
     assert declared <= exported
 
 
+def test_the_package_ships_exactly_one_shared_library(pfc):
+    """Variant / diagnostic builds (scripts/mkvar.sh, build_stamps.sh, elimination.sh) go to build/variants/, never into the
+    package: whatever PFC_LIB could point at inside csrc/ is the product library, whose pfc_build_info() is 0."""
+    import glob
+    so = sorted(glob.glob(os.path.join(os.path.dirname(pfc._lib.LIB_PATH), "**", "*.so"), recursive=True))
+    assert so == [pfc._lib.LIB_PATH], so
+    if not os.environ.get("PFC_LIB"):
+        assert pfc._lib.lib().pfc_build_info() == 0
+
+
+def test_multi_device_handle_needs_devices_too(pfc):
+    """pfc_create_multi without a usable HIP device fails like pfc_create (no CPU fallback); bad device lists are refused."""
+    import ctypes as C
+    import torch
+    L = pfc._lib.lib()
+    h = C.c_void_p()
+    assert L.pfc_create_multi(None, 2, C.byref(h)) == pfc._lib.ERR_BAD_ARG and not h
+    dv = (C.c_int * 2)(0, 0)
+    assert L.pfc_create_multi(dv, 0, C.byref(h)) == pfc._lib.ERR_BAD_ARG and not h
+    if not torch.cuda.is_available():
+        assert L.pfc_create_multi(dv, 2, C.byref(h)) == pfc._lib.ERR_HIP and not h
+        m = pfc.MechanismScenario(devices=[0, 0])
+        G = pfc.geometry
+        i1 = m.add_contact("plane", G.as_tet_emesh(G.emesh_half_plane()), c_prop=pfc.ContactProperties(1.0e6))
+        i2 = m.add_contact("box", G.as_tri_emesh(G.emesh_box(0.05)))
+        m.add_friction_regularize(i1, i2, mu_d=0.2)
+        with pytest.raises(pfc._lib.PFCError) as ei:
+            m.finalize()
+        assert ei.value.status == pfc._lib.ERR_HIP
+
+
 def test_no_cpu_fallback(pfc):
     """Without a HIP device the product path must fail loudly (pfc_create -> PFC_ERR_HIP), not compute on the CPU."""
     import torch
