@@ -61,28 +61,43 @@ def oracle_setup(pfc, w):
     return O, om, oi, m1, m2
 
 
-def cpu_baseline(pfc, w, budget_s: float, n_threads: int = 1):
-    """Oracle ("port") timed on the host cores: items evaluated independently by pfo_eval_batch, serially
-    (n_threads = 1, the reference's own execution model) or spread over OpenMP threads."""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(pfc, w, budget_s: float, n_threads: int = 1, reps: int = 5):
+    """Oracle ("port") timed on the host cores as BASELINE.md section 5 states it: the same items, a warm pass, then `reps` (>= 5)
+    warm repetitions of ONE bounded sample of the batch, the MEDIAN repetition reported; items evaluated independently by
+    pfo_eval_batch, serially (n_threads = 1, the reference's own execution model) or spread over OpenMP threads.  The sample
+    (the first items of the batch) is sized from a calibration pass so that the repetitions together take about budget_s."""
     O, om, oi, m1, m2 = oracle_setup(pfc, w)
-    chunk = max(8 * n_threads, 16)
-    O.evaluate_batch(om, oi, m1, m2, w.ins_ids[:chunk], w.pose[:chunk], w.twist[:chunk], w.s[:chunk], n_threads)  # warm
-    ops = items = 0
-    k = 0
-    t0 = time.perf_counter()
-    while True:
-        lo = k % w.n_items
-        sl = slice(lo, min(lo + chunk, w.n_items))
-        st, _, _, ct = O.evaluate_batch(om, oi, m1, m2, w.ins_ids[sl], w.pose[sl], w.twist[sl], w.s[sl], n_threads)
-        assert st == 0
-        ops += int(ct[:, 1].sum()); items += int(ct.shape[0]); k += chunk
-        dt = time.perf_counter() - t0
-        if dt >= budget_s:
-            break
+    chunk = min(max(8 * n_threads, 16), w.n_items)
+    run = lambda k: O.evaluate_batch(om, oi, m1, m2, w.ins_ids[:k], w.pose[:k], w.twist[:k], w.s[:k], n_threads)
+    run(chunk)                                                          # cold: page in meshes, start the thread team
+    t0 = time.perf_counter(); run(chunk); t_cal = max(time.perf_counter() - t0, 1e-6)
+    n_sample = int(min(w.n_items, max(chunk, chunk * (budget_s / (reps + 1)) / t_cal)))
+    st, _, _, ct = run(n_sample)                                        # warm pass over the sample itself
+    assert st == 0
+    ops, items = int(ct[:, 1].sum()), int(ct.shape[0])
+    dts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        st, _, _, ct = run(n_sample)
+        dts.append(time.perf_counter() - t0)
+        assert st == 0 and int(ct[:, 1].sum()) == ops
+    dt = statistics.median(dts)
     return {"value": ops / dt, "unit": "ops/s", "cores": n_threads, "kind": "port",
-            "sample": f"{items} items of the same batch, {ops} ops, {dt:.1f} s, oracle/pfc_oracle.c "
+            "sample": f"the first {items} items of the same batch ({ops} ops), median of {reps} warm repetitions "
+                      f"({min(dts):.2f} .. {max(dts):.2f} s each), oracle/pfc_oracle.c "
                       f"({'single thread' if n_threads == 1 else str(n_threads) + ' OpenMP threads over items'})",
-            "contact_pairs_per_s": items / dt}
+            "reps": reps, "seconds_per_rep": {"median": dt, "min": min(dts), "max": max(dts)},
+            "contact_pairs_per_s": items / dt, "cpu_model": cpu_model()}
 
 
 def validate(pfc, w, local_ids, wrench, sdot, counts, k: int, seed: int = 7):
@@ -187,6 +202,9 @@ def main():
     ap.add_argument("--clip-min", type=int, default=-1, help="library option clip_min (-1: library default 384; 0: one-kernel narrowphase)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option for A/B runs (pfc_set_option), e.g. --opt clip_dense=0")
     ap.add_argument("--bfs-levels", type=int, default=-1, help="broadphase BFS levels before the DFS kernel (-1 = auto)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process drives the --gpus devices through a multi-device handle (pfc_create_multi: the form the "
+                         "single-process Julia host uses) instead of one rank per GPU; PFC_BENCH_DEVICES=0,0 rehearses it on one GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -196,7 +214,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    multi_devs = None
+    if args.single_process:
+        if world != 1:
+            print("bench.py: --single-process is ONE process (do not launch it under torch.distributed.run)", file=sys.stderr)
+            sys.exit(2)
+        multi_devs = ([int(x) for x in os.environ["PFC_BENCH_DEVICES"].split(",")] if os.environ.get("PFC_BENCH_DEVICES")
+                      else list(range(args.gpus)))
+    if world != args.gpus and not args.single_process:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
@@ -215,7 +240,11 @@ def main():
     force_x = os.environ.get("PFC_BENCH_FORCE_EXCHANGE") == "1"
     if world > 1 or force_x:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
+        if "MASTER_PORT" not in os.environ:      # (a one-rank rehearsal: any free port, so that two of them can share a box)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -233,13 +262,17 @@ def main():
     P = pfc.parallel
 
     # ---- workload; meshes are identical on every rank ------------------------------------------------------------
+    n_dev = len(multi_devs) if multi_devs else 1
     if args.config == "C3":
-        w = pfc.configs.c3_blob_tool(args.poses, seed=20260103 + 7919 * rank)     # weak scaling: rank-specific poses
+        # weak scaling: rank-specific poses (single process: n_dev x poses in the one batch)
+        w = pfc.configs.c3_blob_tool(args.poses * n_dev, seed=20260103 + 7919 * rank)
         if args.friction == "regularized":
             w.instructions[0].model = "regularized"
         mine = np.arange(w.n_items)
         parts, n_global, scaling = None, w.n_items * world, "weak"
         desc = (f"C3: 9680-tet blob x 5120-tri tool, {args.friction} friction, quad rule 2, {args.poses} Monte-Carlo poses per GPU per step")
+        if multi_devs:
+            mine = np.arange(w.n_items)
     elif args.config == "C4":
         w = pfc.configs.c2_box_on_plane(256, montecarlo=True)
         parts = P.shard_block(w.n_items, world)
@@ -252,7 +285,10 @@ def main():
         parts = P.shard_by_cost(cost, world)
         mine, n_global, scaling = parts[rank], w.n_items, "strong"
         desc = "C5: pile of 64 compliant boxes (108..2352 tets), all 2016 body pairs as bristle instructions, cost-weighted shards"
-    m = pfc.configs.build_scenario(w, device=local_rank)
+    if multi_devs:      # one process, every device behind one handle: the library cuts the items into ranges per device
+        mine = np.arange(w.n_items)
+        desc += f"; ONE process, multi-device handle over devices {multi_devs} (pfc_create_multi)"
+    m = pfc.configs.build_scenario(w, device=local_rank, devices=multi_devs)
     if args.bfs_levels >= 0:
         m.set_option("bfs_levels", args.bfs_levels)
     if args.split_min >= 0:
@@ -388,7 +424,7 @@ def main():
         K = args.steps
         np_ms = stage["narrowphase"] / K
         bp_ms = stage["broadphase"] / K
-        parts_n = parts_prof
+        parts_n = parts_prof * (max(m.last_shards(), 1) if multi_devs else 1)      # launches the step's units are spread over
         # SURVEY §8(d) accounting: algorithmic bytes / kernel time against the HBM peak (well below 1: these kernels re-read
         # their 64..256-byte records from L2 / Infinity Cache and are bound by vector issue, see "valu").
         roof_np = {"kernel": "k_clip_queue + k_integ (the narrowphase of a big batch: clip-only kernel -- k_narrow<.., 2 / 3> for scenarios with tet-tet instructions --, "
@@ -466,7 +502,7 @@ def main():
             "metric": "tet-tri clip+integrate ops/s",
             "value": ops_step * K / dt,
             "unit": "ops/s",
-            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "n_gpus": (len(set(multi_devs)) if multi_devs else world), "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3,
             "higher_is_better": True,
             "scaling": scaling,
@@ -488,6 +524,10 @@ def main():
             "exchange_ms_per_step": xchg_per_step,
             "exchange_share": (xchg_per_step / (dt / K * 1e3)) if (world > 1 or force_x) else 0.0,
             "path": {0: "fused small-scene kernel", 1: "batched", 2: "batched, two concurrent halves"}[path],
+            "single_process_devices": multi_devs, "shards_used": (m.last_shards() if n else 0),
+            # which library did the work: a variant build (scripts/mkvar.sh) reports bit 16, stamps bit 0, elimination bits 8..15
+            "library": {"path": getattr(pfc._lib.lib(), "pfc_loaded_path", None), "build_info": int(pfc._lib.lib().pfc_build_info()),
+                        "version": int(pfc._lib.lib().pfc_version())},
             "concurrent_parts": max(path, 1),
             "roofline": roof_np if (args.config != "C3" or np_ms >= bp_ms) else roof_bp,
             "roofline_other": roof_bp if (args.config != "C3" or np_ms >= bp_ms) else roof_np,
@@ -501,14 +541,21 @@ def main():
             out["single_pose_ops_per_s"] = out["small_scenes"]["C3_single_pose"]["ops_per_s"]
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pfc, w, args.cpu_seconds, 1)
+            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            out["cpu_baseline"]["host_cores_usable_by_this_process"] = usable
             import shutil
             # the Julia reference itself can only be timed where a Julia toolchain exists
             out["cpu_baseline"]["julia_on_box"] = shutil.which("julia")
-            # second leg: the same port over the box's CPU share for one GPU (16 cores)
-            nt = max(1, min(16, os.cpu_count() or 1))
-            if nt > 1:
-                out["cpu_baseline_multicore"] = cpu_baseline(pfc, w, args.cpu_seconds / 2, nt)
+            # second leg: the same port over ALL host cores the process may use, and beside it
+            # over the box's CPU share for one GPU (16 cores)
+            if usable > 1:
+                out["cpu_baseline_multicore"] = cpu_baseline(pfc, w, args.cpu_seconds / 2, usable)
+            if usable > 16:
+                out["cpu_baseline_16_cores"] = cpu_baseline(pfc, w, args.cpu_seconds / 2, 16)
+                out["cpu_baseline_16_cores"]["note"] = ("the CPU share of a one-GPU job on the bench box (gpurun: 16 cores); the scheduler may grant "
+                                                        "the job less CPU time than the affinity mask shows, in which case the all-core leg is "
+                                                        "time-sliced and comes out SLOWER than this one")
         print(json.dumps(out))
     m.close()
     if world > 1 or force_x:

@@ -177,10 +177,66 @@ def c3_blob_tool(n_poses: int = 1, seed: int = 20260103, n_div_blob: int = 22, n
                     {"n_tet": blob.n_tet, "n_tri": tool.n_tri, "distance": distance})
 
 
-def c5_pile(n_side: int = 4, seed: int = 20260102, n_divs=(3, 5, 14), overlap: float = 0.02) -> Workload:
+import os as _os
+
+SPOON_FIXTURE = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests", "golden", "spoon_quads.npz")
+
+
+def spoon_emesh(path: Optional[str] = None) -> G.EMesh:
+    """The reference's spoon (test/data/spoon.obj: 2 504 vertices, 2 502 quads, a closed manifold; loaded and scaled by 0.01 as
+    test/spoon.jl:39-41 does) from the fixture tests/golden/spoon_quads.npz (vertex / face data only,
+    tests/golden/make_spoon_fixture.py): 5 004 triangles, 17.7 cm long."""
+    d = np.load(path or SPOON_FIXTURE)
+    return G.emesh_from_quads(d["point"], d["quad"], 0.01)
+
+
+def pencil_emesh() -> G.EMesh:
+    """The pencil of test/pencil.jl:31-33,198-200: a 12-sided swept mesh along +y, 16 cm long, radius 3.5 mm, with a 13 mm
+    cone tip (create_swept_mesh, src/geometry/mesh_create_swept.jl:73-104): 48 surface triangles, 72 tets."""
+    m = G.create_swept_mesh(G.f_swept_triv, [0.0, 0.013, 0.16], [0.0, 0.0035, 0.0035], 12, True, rot_half=True)
+    return m.transformed(t=np.array([0.0, 0.0, 0.0035]))      # transform!(eM_penci, SVector(0, 0, penci_rad)), pencil.jl:200
+
+
+def spoon_pencil_pads(n_poses: int = 32, seed: int = 20260105) -> Workload:
+    """Real geometry through the path ("lets real reference scenes run"): the reference's spoon surface and its
+    swept pencil surface, each against the compliant finger pad of test/pencil.jl:188-190 (sphere n_div 4 of radius 3.5 mm
+    stretched by (2, 1, 2): 320 tets, Ebar 1e6), bristle friction mu_d 0.5, chi 0.6 (pencil.jl:214-215).  Per pose the pad sits
+    on a random surface triangle of the spoon / pencil, pressed in by U(0.2, 1.2) mm along the triangle's normal, in a random
+    orientation, with a random relative twist.  Items alternate spoon, pencil."""
+    spoon = spoon_emesh()
+    pencil = G.as_tri_emesh(pencil_emesh())
+    pad = G.as_tet_emesh(G.emesh_sphere(0.0035, 4)).transformed(R=np.diag([2.0, 1.0, 2.0]))
+    meshes = [_mesh("spoon", spoon), _mesh("pencil", pencil), _mesh("pad", pad, 1.0e6)]
+    ins = [InsSpec(0, 2, "bristle", chi=0.6, mu_d=0.5), InsSpec(1, 2, "bristle", chi=0.6, mu_d=0.5)]
+    ids, pose, twist, s = [], [], [], []
+    for k in range(n_poses):
+        g = _rng(seed, k)
+        which = k % 2
+        srf = spoon if which == 0 else pencil
+        t = srf.point[srf.tri[int(g.integers(0, srf.n_tri))]]
+        cen = t.mean(axis=0)
+        nrm = np.cross(t[1] - t[0], t[2] - t[1]); nrm /= np.linalg.norm(nrm)
+        Rp = random_rotation(g)
+        # the pad's extent along the contact normal in this orientation: support of the ellipsoid (7, 3.5, 7) mm
+        ext = np.linalg.norm(np.array([0.007, 0.0035, 0.007]) * (Rp.T @ nrm))
+        tp = cen + nrm * (ext - g.uniform(0.2e-3, 1.2e-3))
+        ids.append(which)
+        pose.append(relative_pose(np.eye(3), np.zeros(3), Rp, tp))       # body 1 = the rigid surface (world), body 2 = the pad
+        ang, lin = g.uniform(-1, 1, size=3), g.uniform(-0.05, 0.05, size=3)
+        twist.append(relative_twist(Rp, tp, np.zeros(6), np.concatenate([ang, lin - np.cross(ang, tp)])))
+        s.append(g.standard_normal(6) * 1.0e-2)
+    return Workload("spoon / pencil against finger pads", meshes, ins, np.asarray(ids, dtype=np.int32), np.array(pose),
+                    np.array(twist), np.array(s), {"n_tri_spoon": spoon.n_tri, "n_tri_pencil": pencil.n_tri, "n_tet_pad": pad.n_tet})
+
+
+def c5_pile(n_side: int = 4, seed: int = 20260102, n_divs=(3, 5, 14), overlap: float = 0.02, pencil_spoon: bool = False) -> Workload:
     """C5: n_side^3 compliant boxes (12*n_div^2 tets each, n_div cycling through n_divs) plus their surface
     triangle meshes on a jittered lattice with 2 % overlap; every unordered body pair is a bristle instruction
-    (mesh_1 = surface triangles of body i, mesh_2 = tets of body j), 2 016 instructions for 64 bodies."""
+    (mesh_1 = surface triangles of body i, mesh_2 = tets of body j), 2 016 instructions for 64 bodies.
+    pencil_spoon: BASELINE config 5 as worded ("pencil/spoon-scale meshes"): the reference's spoon (rigid surface, 5 004
+    triangles) and its swept pencil (compliant: 48 surface triangles, 72 tets) are laid on top of the pile, 2 mm / 1 mm into the
+    top layer; they add the pairs spoon-box (x n_body), pencil-box (x n_body: pencil surface against the box's tets) and
+    spoon-pencil (spoon surface against the pencil's tets) -- 2 145 instructions for 64 boxes."""
     r = 0.05
     g = _rng(seed, 0)
     protos = {}
@@ -208,9 +264,33 @@ def c5_pile(n_side: int = 4, seed: int = 20260102, n_divs=(3, 5, 14), overlap: f
             pose.append(relative_pose(Ri, ti, Rj, tj))
             twist.append(relative_twist(Rj, tj, twi, twj))
             s.append(g.standard_normal(6) * 1.0e-2)
+    if pencil_spoon:
+        top = (n_side - 1) * pitch + r
+        mid = 0.5 * (n_side - 1) * pitch
+        spoon = spoon_emesh()
+        pen = pencil_emesh()
+        sp_spec = _mesh("spoon_tri", spoon)
+        pen_tri, pen_tet = _mesh("pencil_tri", G.as_tri_emesh(pen)), _mesh("pencil_tet", G.as_tet_emesh(pen), 1.0e6)
+        i_sp = len(meshes); meshes.append(sp_spec)
+        i_pt = len(meshes); meshes.append(pen_tri)
+        i_pv = len(meshes); meshes.append(pen_tet)
+        Rs, ts = rot_z(0.3), np.array([mid, mid - 0.01, top - 0.002 - float(spoon.point[:, 2].min())])
+        tws = np.concatenate([g.uniform(-1, 1, size=3), g.uniform(-0.1, 0.1, size=3)])
+        Rq, tq = rot_z(-0.2), np.array([0.03, 0.6 * pitch, top - 0.001])      # the pencil lies on z in [0, 2 r_pencil]
+        twq = np.concatenate([g.uniform(-1, 1, size=3), g.uniform(-0.1, 0.1, size=3)])
+        for j in range(n_body):
+            Rj, tj, twj = body[j]
+            ins.append(InsSpec(i_sp, 2 * j + 1, "bristle", chi=0.5, mu_d=0.3))
+            pose.append(relative_pose(Rs, ts, Rj, tj)); twist.append(relative_twist(Rj, tj, tws, twj)); s.append(g.standard_normal(6) * 1.0e-2)
+        for j in range(n_body):
+            Rj, tj, twj = body[j]
+            ins.append(InsSpec(i_pt, 2 * j + 1, "bristle", chi=0.5, mu_d=0.3))
+            pose.append(relative_pose(Rq, tq, Rj, tj)); twist.append(relative_twist(Rj, tj, twq, twj)); s.append(g.standard_normal(6) * 1.0e-2)
+        ins.append(InsSpec(i_sp, i_pv, "bristle", chi=0.5, mu_d=0.3))
+        pose.append(relative_pose(Rs, ts, Rq, tq)); twist.append(relative_twist(Rq, tq, tws, twq)); s.append(g.standard_normal(6) * 1.0e-2)
     n = len(ins)
-    return Workload(f"C5 pile of {n_body} boxes", meshes, ins, np.arange(n, dtype=np.int32), np.array(pose),
-                    np.array(twist), np.array(s), {"n_body": n_body})
+    return Workload(f"C5 pile of {n_body} boxes" + (" + spoon + pencil" if pencil_spoon else ""), meshes, ins,
+                    np.arange(n, dtype=np.int32), np.array(pose), np.array(twist), np.array(s), {"n_body": n_body})
 
 
 def vol_vol(n_poses: int = 4, seed: int = 20260104, n_div: int = 4, model: str = "regularized") -> Workload:

@@ -264,6 +264,121 @@ def emesh_box_div(r=1.0, n_div: int = 1, c=(0.0, 0.0, 0.0)) -> EMesh:
     return m.transformed(t=np.asarray(c, dtype=np.float64)) if np.any(np.asarray(c) != 0) else m
 
 
+# ---- swept meshes (src/geometry/mesh_create_swept.jl) and mesh repair (src/geometry/mesh.jl:235-361) -------------------
+def _tri_area(p: np.ndarray) -> np.ndarray:
+    return 0.5 * np.linalg.norm(np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 1]), axis=1)
+
+
+def _remove_unused_points(point, tri, tet, eps):
+    """mesh_remove_unused_points! (mesh.jl:302-319): points keep their order."""
+    used = np.zeros(point.shape[0], dtype=bool)
+    for e in (tri, tet):
+        if e is not None and e.size:
+            used[e.reshape(-1)] = True
+    new_key = np.cumsum(used) - 1
+    tri = None if tri is None else new_key[tri]
+    tet = None if tet is None else new_key[tet]
+    return point[used], tri, tet, (None if eps is None else eps[used])
+
+
+def mesh_repair(point, tri, tet, eps):
+    """mesh_repair! (mesh.jl:235-240): drop unused points, merge points closer than 0.499 x the shortest element side onto the
+    lowest index of their cluster (mesh_inplace_rekey!, :266-300; the reference asks a BallTree, here a k-d tree), drop unused
+    points again, delete opposing duplicate triangle pairs (delete_triangles!, :322-361).  Returns (point, tri, tet, eps)."""
+    from scipy.spatial import cKDTree
+    point, tri, tet, eps = _remove_unused_points(point, tri, tet, eps)
+    d_min = np.inf
+    for e in (tri, tet):
+        if e is not None and e.size:
+            v = point[e]
+            for a in range(e.shape[1]):
+                for b in range(a):
+                    d_min = min(d_min, float(np.linalg.norm(v[:, a] - v[:, b], axis=1).min()))
+    if np.isfinite(d_min):
+        near = cKDTree(point).query_ball_point(point, d_min * 0.499)
+        new_key = np.asarray([min(ix) for ix in near], dtype=np.int64)
+        tri = None if tri is None else new_key[tri]
+        tet = None if tet is None else new_key[tet]
+        point, tri, tet, eps = _remove_unused_points(point, tri, tet, eps)
+    if tri is not None and tri.size:
+        seen = {}
+        for k, t in enumerate(tri):
+            seen.setdefault(tuple(sorted(int(v) for v in t)), []).append(k)
+        drop = []
+        for ks in seen.values():
+            if len(ks) == 2:
+                drop += ks
+            elif len(ks) >= 3:
+                raise ValueError("something is wrong")
+        if drop:
+            tri = np.delete(tri, np.asarray(sorted(drop)), axis=0)
+    return point, tri, tet, eps
+
+
+def f_swept_triv(theta: float):
+    """mesh_create_swept.jl:20-24: a straight path along +y; returns (position, a normal of the path, its direction)."""
+    n1 = np.array([0.0, 0.0, -1.0]); n2 = np.array([0.0, 1.0, 0.0])
+    return n2 * theta, n1, n2
+
+
+def _angle_axis(phi: float, axis: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """AngleAxis(phi, axis...) * v (Rodrigues)."""
+    k = axis / np.linalg.norm(axis)
+    return v * np.cos(phi) + np.cross(k, v) * np.sin(phi) + k * np.dot(k, v) * (1.0 - np.cos(phi))
+
+
+def create_swept_mesh(fun_gen, lr, rad, n_side: int = 4, is_open: bool = True, rot_half: bool = True) -> EMesh:
+    """create_swept_mesh (mesh_create_swept.jl:73-104) with add_rot_sym_segment! (:25-58): per path segment and side one
+    7-point wedge -- 2 surface triangles (+ an end cap where the path is open), 4 tets, eps = 1 on the path and 0 on the
+    surface and at open ends -- then remove_degenerate! (mesh.jl:242-255: elements below 1e-6 of the largest go, e.g. the
+    zero-radius tip of test/pencil.jl:199) and mesh_repair!."""
+    lr = np.asarray(lr, dtype=np.float64)
+    rad = np.zeros(lr.size) + np.asarray(rad, dtype=np.float64)
+    if rad.size != lr.size:
+        raise ValueError("the length of lr and length of rad must be the same")
+    d_phi = 2 * np.pi / n_side
+    rad = rad / np.cos(d_phi / 2)
+    pts, tri, tet, eps = [], [], [], []
+    n_th = lr.size - 1
+    for k_th in range(n_th):
+        for k_phi in range(1, n_side + 1):
+            phi0 = d_phi * (k_phi - 0.5 * (1.0 if rot_half else 0.0))
+            phi1 = phi0 + d_phi
+            open0, open1 = (is_open and k_th == 0), (is_open and k_th == n_th - 1)
+            p1, x1, y1 = fun_gen(float(lr[k_th]))
+            p2, x2, y2 = fun_gen(float(lr[k_th + 1]))
+            p3 = (p1 + p2) * 0.5
+            p4 = p1 + _angle_axis(phi0, y1, x1) * rad[k_th]
+            p6 = p1 + _angle_axis(phi1, y1, x1) * rad[k_th]
+            p5 = p2 + _angle_axis(phi0, y2, x2) * rad[k_th + 1]
+            p7 = p2 + _angle_axis(phi1, y2, x2) * rad[k_th + 1]
+            o = len(pts) - 1                      # the reference's indices are 1-based
+            pts += [p1, p2, p3, p4, p5, p6, p7]
+            tet += [[o + 1, o + 3, o + 4, o + 6], [o + 3, o + 2, o + 5, o + 7], [o + 3, o + 4, o + 6, o + 7], [o + 4, o + 3, o + 5, o + 7]]
+            tri += [[o + 4, o + 6, o + 7], [o + 4, o + 7, o + 5]]
+            e = [1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0]
+            if open0:
+                e[0] = 0.0
+                tri.append([o + 1, o + 6, o + 4])
+            if open1:
+                e[1] = 0.0
+                tri.append([o + 2, o + 5, o + 7])
+            eps += e
+    P = np.asarray(pts); T = np.asarray(tri, dtype=np.int64); Q = np.asarray(tet, dtype=np.int64); E = np.asarray(eps)
+    vol = tet_volume(P[Q]); Q = Q[~(vol < vol.max() * 1.0e-6)]
+    ar = _tri_area(P[T]); T = T[~(ar < ar.max() * 1.0e-6)]
+    P, T, Q, E = mesh_repair(P, T, Q, E)
+    return EMesh(P, T, Q, E)
+
+
+def emesh_from_quads(point: np.ndarray, quad: np.ndarray, scale: float = 1.0) -> EMesh:
+    """A surface eMesh from a quad mesh file's data (test/spoon.jl:39-41 loads test/data/spoon.obj through MeshIO into a
+    triangle mesh and scales it by 0.01): every quad (a, b, c, d) becomes the triangles (a, b, c), (a, c, d)."""
+    quad = np.asarray(quad, dtype=np.int64).reshape(-1, 4)
+    tri = np.concatenate([quad[:, [0, 1, 2]], quad[:, [0, 2, 3]]], axis=1).reshape(-1, 3)
+    return EMesh(np.asarray(point, dtype=np.float64) * scale, tri, None, None)
+
+
 def emesh_ground(half_w: float = 1.0, z: float = 0.0) -> EMesh:
     """Open rigid ground patch: 2 triangles forming a (2*half_w)^2 square at height z, normal +z
     (BASELINE.md C2).  The reference's blob builder cannot build a tree for an open mesh

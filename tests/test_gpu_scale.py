@@ -785,7 +785,7 @@ def test_host_paths_without_bar_resident_inputs(tmp_path):
                            capture_output=True, text=True, timeout=400)
         assert p.returncode == 0, p.stderr[-2000:]
         got[tag] = np.load(f)
-    assert sorted(got["bar"].files) == sorted(got["nobar"].files) and len(got["bar"].files) >= 30
+    assert sorted(got["bar"].files) == sorted(got["nobar"].files) and len(got["bar"].files) >= 70
     for k in got["bar"].files:
         a, b = got["bar"][k], got["nobar"][k]
         if k.endswith("counts"):

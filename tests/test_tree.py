@@ -131,3 +131,33 @@ def test_contact_result_independent_of_tree(pfc, O):
     a, b = res["blob"], res["median"]
     assert np.array_equal(a[1], b[1]) and a[1].shape[0] > 0
     np.testing.assert_allclose(a[0], b[0], rtol=1e-11, atol=1e-11 * np.abs(b[0]).max())
+
+
+def test_reference_spoon_and_swept_pencil_meshes(pfc):
+    """The reference's real test geometry: test/data/spoon.obj (fixture tests/golden/spoon_quads.npz: vertex / face data only) is a
+    closed, outward-oriented manifold of 2 502 quads; the pencil of test/pencil.jl:198-200 (create_swept_mesh, 12 sides, two
+    segments, zero-radius tip) has fewer than 100 surface triangles and is closed too.  Both go through the
+    blob and the median tree builder (pfc_build_tree), whose leaves are the triangles."""
+    from collections import Counter
+    G, Cf = pfc.geometry, pfc.configs
+    spoon = Cf.spoon_emesh()
+    pen = Cf.pencil_emesh()
+    pen_tri = G.as_tri_emesh(pen)
+    assert (spoon.n_point, spoon.n_tri) == (2504, 5004)
+    assert (pen.n_point, pen_tri.n_tri, pen.n_tet) == (29, 48, 72) and pen_tri.n_tri < 100
+    assert pen.eps.min() == 0.0 and pen.eps.max() == 1.0
+    for msh, vol_ref in ((spoon, None), (pen_tri, np.pi * 0.0035 ** 2 * (0.147 + 0.013 / 3))):
+        e = Counter()
+        for t in msh.tri:
+            for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+                e[(int(a), int(b))] += 1
+        assert max(e.values()) == 1 and all((b, a) in e for (a, b) in e), "not a closed, consistently oriented manifold"
+        P = msh.point[msh.tri]
+        vol = np.einsum("ij,ij->i", P[:, 0], np.cross(P[:, 1], P[:, 2])).sum() / 6.0
+        assert vol > 0.0
+        if vol_ref is not None:      # a 12-gon circumscribing the circle of radius r: area factor n tan(pi / n) / pi
+            assert abs(vol / (vol_ref * 12 * np.tan(np.pi / 12) / np.pi) - 1.0) < 1e-9
+        for method in ("blob", "median"):
+            tr = G.build_tree(msh, method)
+            assert tr.n_node == 2 * msh.n_tri - 1
+            assert sorted(int(v) for v in tr.leaf[tr.leaf >= 0]) == list(range(msh.n_tri))
