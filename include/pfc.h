@@ -279,7 +279,10 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
  * one process that case does not arise: a device has one team slot, a handle that finds it taken evaluates without a team at
  * once), "team_fault" (diagnostic, default -1: this rank of every team behaves as if its wait for the team had timed out while
  * the others saw it arrive; the evaluation must come back re-issued on the batched path, never with a wrong result),
- * "multi_min" (multi-device handles, see pfc_create_multi). */
+ * "multi_min" (multi-device handles, see pfc_create_multi), "fused_f32" (default 1: the one-launch kernel runs the batched
+ * broadphase's single-precision SAT filter in front of the exact Float64 test, undecided pairs settled in the same iteration;
+ * same node tests, candidates and results; 0 = exact test only; items whose pose has a frame axis parallel to one of the other
+ * body's -- a box resting on a plane -- run with the filter off by themselves). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);
 
 /* Totals of the last checked evaluation: out[0..7] = {node tests, candidate pairs, non-empty pairs, traction

@@ -336,28 +336,33 @@ __device__ __forceinline__ void exact_pairs_coop(const NodeRec *nodes1, const No
         __syncthreads();
         bool sep = false;
         if (valid && sub < 15) {
-            const double ea[3] = {na->e[0], na->e[1], na->e[2]}, eb[3] = {nb->e[0], nb->e[1], nb->e[2]};
+            // (the extents are read from the node records by a lane-dependent index: as private arrays `ea[u]` they lived in
+            // scratch memory -- 32 bytes per lane of the library's largest kernel, for a path 5e-4 of the node tests take)
+#define EA_(i) (na->e[(i)])
+#define EB_(i) (nb->e[(i)])
 #define R_(i, j) R[(i) + 3 * (j)]
 #define AR_(i, j) aR[(i) + 3 * (j)]
             if (sub < 3) {          // face test 1/2 (:29-32)
                 const int i = sub;
-                const double rb = (AR_(i, 0) * eb[0] + AR_(i, 1) * eb[1]) + AR_(i, 2) * eb[2];
-                sep = (ea[i] + rb) < __builtin_fabs(t[i]);
+                const double rb = (AR_(i, 0) * EB_(0) + AR_(i, 1) * EB_(1)) + AR_(i, 2) * EB_(2);
+                sep = (EA_(i) + rb) < __builtin_fabs(t[i]);
             } else if (sub < 6) {   // face test 2/2 (:35-38)
                 const int jj = sub - 3;
                 const double tl = __builtin_fabs((R_(0, jj) * t[0] + R_(1, jj) * t[1]) + R_(2, jj) * t[2]);
-                const double ra = (AR_(0, jj) * ea[0] + AR_(1, jj) * ea[1]) + AR_(2, jj) * ea[2];
-                sep = (ra + eb[jj]) < tl;
+                const double ra = (AR_(0, jj) * EA_(0) + AR_(1, jj) * EA_(1)) + AR_(2, jj) * EA_(2);
+                sep = (ra + EB_(jj)) < tl;
             } else {                // cross tests (:56-72): row m of the cross block, column jj
                 const int m = (sub - 6) / 3, jj = (sub - 6) % 3;
                 const int u = (m + 1) % 3, v = (m + 2) % 3;
                 const int p100 = jj == 0 ? 1 : 0, p221 = jj == 2 ? 1 : 2;
                 const double tl = __builtin_fabs(t[v] * R_(u, jj) - t[u] * R_(v, jj));
                 // sat15 writes the two products of ra with the lower axis index first; a + b == b + a exactly
-                const double ra = ea[u] * AR_(v, jj) + ea[v] * AR_(u, jj);
-                const double rb = eb[p100] * AR_(m, p221) + eb[p221] * AR_(m, p100);
+                const double ra = EA_(u) * AR_(v, jj) + EA_(v) * AR_(u, jj);
+                const double rb = EB_(p100) * AR_(m, p221) + EB_(p221) * AR_(m, p100);
                 sep = (ra + rb) < tl;
             }
+#undef EA_
+#undef EB_
 #undef R_
 #undef AR_
         }
@@ -423,10 +428,15 @@ __global__ void __launch_bounds__(BLK, 4) k_bp_dfs32(Dfs32Args g) {
     int n_seed = *g.n_seed;
     if (n_seed > g.seed_cap) n_seed = g.seed_cap;
     // the first seed record is fetched together with the seed count (blockIdx.x < grid <= seed_cap: in bounds)
-    const WorkRec s_first = g.seeds[blockIdx.x];
+    // (as a 16-byte vector: a WorkRec selected by `cond ? s_first : g.seeds[sd]` was given a stack slot -- one dead 16-byte store,
+    // but 32 bytes of scratch per lane in the dispatch of the library's largest kernel)
+    const vec4i s_first = ((const gvec4i *)g.seeds)[blockIdx.x];
     // one ticket per workgroup (same loop shape as k_bp_dfs: condition in the for header, no break)
     for (int sd = blockIdx.x; sd < n_seed; sd = next_ticket_block(g.next_seed, &s_seed, n_seed)) {
-        const WorkRec s = (sd == (int)blockIdx.x) ? s_first : g.seeds[__builtin_amdgcn_readfirstlane(sd)];
+        vec4i s_v = s_first;
+        if (sd != (int)blockIdx.x) s_v = ((const gvec4i *)g.seeds)[__builtin_amdgcn_readfirstlane(sd)];
+        WorkRec s;
+        s.item = s_v.x; s.a = s_v.y; s.b = s_v.z; s.pad = s_v.w;
         if ((unsigned)s.item >= (unsigned)g.n_items) {   // uniform over the workgroup: an unwritten seed slot is skipped, not followed
             if (tid == 0) atomicOr(g.status, kStHole);
             continue;

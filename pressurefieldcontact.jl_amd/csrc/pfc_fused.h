@@ -43,7 +43,9 @@ struct alignas(16) InsFull {
     const TetRec *tet1;      // mesh_1 tets (tet-tet) or null
     const double *eps1, *eps2;
     double chi, Ebar, Ebar1, mu_s, mu_d, v_c, tau, k_bar, magic;
-    int model, nq, n_node1, n_node2, reserve, pad[11];
+    int model, nq, n_node1, n_node2, reserve, pad0;
+    double cmax12;           // cmax(mesh_1) + cmax(mesh_2): the absolute part of the single-precision test's error radius (ItemRec.bp_eabs)
+    int pad[8];
 };
 static_assert(sizeof(InsFull) == 208 || sizeof(InsFull) == 256 || sizeof(InsFull) % 16 == 0, "InsFull layout");
 
@@ -78,6 +80,7 @@ struct FuArgs {
     // Broadphase pose of a Dual evaluation (pfc_eval_dual_bp): the reference culls with m.float's transforms whatever the
     // state of the Dual scenario (calcTriTetIntersections!, src/contact_algorithms_non_friction.jl:94-101); null: the pose itself
     const double *bp_pose;
+    int f32;            // option "fused_f32" (default 1): single-precision SAT filter in front of the exact test (0: Float64 only)
 };
 constexpr int kTeamSlots = 48;           // doubles a workgroup publishes per phase (first phase: 10 sums, 4 counters, status, 27 moments, their reference point)
 constexpr int kTeamMaxWg = 48;           // workgroups per item at most
@@ -196,13 +199,20 @@ __device__ __forceinline__ void team_gather(const FuArgs &g, int item, int nw, i
         if (pending) __builtin_amdgcn_s_sleep(1);
     }
     if (pending) *s_flag = 1;
-    const bool fault = phase == 0 && g.team_fault >= 0 && (int)blockIdx.x - item * nw == g.team_fault;      // uniform
-    if (fault && tid == 0) *s_flag = 1;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const int idx = tid + k * kFuBlock;
         if (idx < nw * kTeamSlots)
-            s_team[idx] = (fault ? 0.5 : 1.0) * __longlong_as_double((long long)(((hi[k] & 0xFFFFFFFFull) << 32) | (lo[k] & 0xFFFFFFFFull)));      // (fault: wrong but finite totals, so that the rank goes on into the friction pass as a rank with stale granules would)
+            s_team[idx] = __longlong_as_double((long long)(((hi[k] & 0xFFFFFFFFull) << 32) | (lo[k] & 0xFFFFFFFFull)));
+    }
+    if (phase == 0 && g.team_fault >= 0 && (int)blockIdx.x - item * nw == g.team_fault) {      // uniform; diagnostic option only
+        // wrong but finite totals, so that the rank goes on into the friction pass as a rank with stale granules would
+        if (tid == 0) *s_flag = 1;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int idx = tid + k * kFuBlock;
+            if (idx < nw * kTeamSlots) s_team[idx] *= 0.5;
+        }
     }
     __syncthreads();
     if (*s_flag) status |= kStFusedOvf;    // a team-mate never arrived: the host re-issues on the batched path (uniform over the workgroup)
@@ -248,6 +258,8 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     __shared__ EigScratch E;
     __shared__ double s_aR12[9];
     __shared__ double s_bp[12];                 // R_a_b (9, column-major), t_a_b (3) of the broadphase
+    __shared__ float s_posef[13], s_q12[4];     // single-precision filter: fl32 of R_a_b, t_a_b, the error radius' absolute part; R_a_b as a quaternion
+    __shared__ int s_pose_exact;                // the pose is not a proper rotation (pose_quat): every test of the item is the exact one
     __shared__ int s_plist[kFuCand];            // candidates that gave a polygon (Dual passes)
     __shared__ int s_npoly;
     __shared__ double s_dacc[16][6];            // per direction: partials of the wrench
@@ -274,14 +286,16 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         static_assert(nw <= 64, "InsFull is loaded by the first wave");
         if (tid < nw) reinterpret_cast<int *>(&I.ins)[tid] = reinterpret_cast<const int *>(g.ins + id)[tid];
         if (tid >= 64 && tid < 88) {
-            const double x = g.pose[24 * (size_t)item + (tid - 64)];
+            // I.pose: x_r2_r1 of the pose, then the x_r1_r2 the BROADPHASE culls with -- the pose's own, or (pfc_eval_dual_bp) the
+            // one of m.float's state; in that case the pose's own x_r1_r2 (read by the tet-tet op and the hand-over only) is s_bp
+            const double x = ((g.bp_pose && tid >= 76) ? g.bp_pose : g.pose)[24 * (size_t)item + (tid - 64)];
             I.pose[tid - 64] = x;
             if (!(__builtin_fabs(x) <= 1.79769313486231570815e308)) status |= kStNonFinite;
         }
         if (tid >= 96 && tid < 102) I.twist[tid - 96] = g.twist[6 * (size_t)item + (tid - 96)];
         if (tid >= 128 && tid < 134) I.s[tid - 128] = g.s ? g.s[6 * (size_t)item + (tid - 128)] : 0.0;
-        if (tid >= 160 && tid < 172) {      // x_r1_r2 the broadphase culls with: the pose's own, or m.float's (pfc_eval_dual_bp)
-            const double x = (g.bp_pose ? g.bp_pose : g.pose)[24 * (size_t)item + 12 + (tid - 160)];
+        if (g.bp_pose && tid >= 160 && tid < 172) {
+            const double x = g.pose[24 * (size_t)item + 12 + (tid - 160)];
             s_bp[tid - 160] = x;
             if (!(__builtin_fabs(x) <= 1.79769313486231570815e308)) status |= kStNonFinite;
         }
@@ -294,8 +308,10 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     bool pose_ok = true;
 #pragma unroll
     for (int k = 0; k < 24; ++k) pose_ok &= (__builtin_fabs(I.pose[k]) <= 1.79769313486231570815e308);
+    if (g.bp_pose) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) pose_ok &= (__builtin_fabs(s_bp[k]) <= 1.79769313486231570815e308);
+        for (int k = 0; k < 12; ++k) pose_ok &= (__builtin_fabs(s_bp[k]) <= 1.79769313486231570815e308);
+    }
 
     FSTAMP(1);
     // ==== 1. broadphase (tree_tree_intersect, src/obb/tree_types.jl:88-111) ===========================================
@@ -320,10 +336,30 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             // stack entries hold node links: ~index (negative) for a leaf, index for an internal node
             B.stk[0] = make_int2(nn1 == 1 ? ~0 : 0, nn2 == 1 ? ~0 : 0);
         }
-        if (tid < 9) s_aR12[tid] = __builtin_fabs(s_bp[tid]) + 1.0e-14;    // abs_R of an all-identity pair (:10)
+        const double *s_pose = I.pose + 12;          // R_a_b (9, column-major), t_a_b (3) of the broadphase (update_TT_Cache!, tree_types.jl:43-50)
+        if (tid < 9) s_aR12[tid] = __builtin_fabs(s_pose[tid]) + 1.0e-14;    // abs_R of an all-identity pair (:10)
+        if (tid < 12) s_posef[tid] = (float)s_pose[tid];
+        if (tid == 192) {
+            // what k_setup_items forms per item for the batched broadphase (pose_quat; "Error radius E", (0), pfc_bp.h)
+            double R12[9];
+            float q[4];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R12[k] = s_pose[k];
+            // A frame axis of body 2 parallel to one of body 1 (|R_ij| = 1: a box resting on a plane, a yaw-only pose): the cross
+            // axis of those two edges is exactly degenerate for every pair of merged boxes, the filter can never prove "no
+            // separation" on it and every overlapping pair would come back undecided -- such an item starts with the filter off
+            // (test/boxes.jl: one wasted single-precision test and the quaternion below, 1 us of a 31 us evaluation).
+            bool aligned = false;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) aligned |= __builtin_fabs(R12[k]) > 1.0 - 1.0e-12;
+            q[0] = 1.0f; q[1] = q[2] = q[3] = 0.0f;
+            s_pose_exact = (aligned || !pose_quat(R12, q)) ? 1 : 0;
+            s_q12[0] = q[0]; s_q12[1] = q[1]; s_q12[2] = q[2]; s_q12[3] = q[3];
+            const double tm = fmax(fmax(__builtin_fabs(s_pose[9]), __builtin_fabs(s_pose[10])), __builtin_fabs(s_pose[11]));
+            s_posef[12] = (float)(1.4306e-6 * (I.ins.cmax12 + tm)) * 1.000001f;
+        }
         __syncthreads();
         FSTAMP(2);
-        const double *s_pose = s_bp;                 // R_a_b (9, column-major), t_a_b (3): x_r1_r2 (update_TT_Cache!, tree_types.jl:43-50)
         const int reserve = I.ins.reserve;
         int sp = 1;
         bool ovf = false;
@@ -347,6 +383,28 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         }                                                                                           \
     } while (0)
         union NodeU { vec4i v[9]; NodeRec r; __device__ NodeU() {} };
+        // the single-precision view of a node (NodeF, pfc_kernels.h): converted from the cached head of an axis-aligned box (its
+        // quaternion is the identity; (float) of the Float64 centre / extent is what pfc_add_mesh stored), else loaded
+#define FU_FETCHF(f, LDSARR, FULL, NC, GLOBF, IDX)                                                  \
+    do {                                                                                            \
+        const int idx_ = (IDX);                                                                     \
+        bool done_ = false;                                                                         \
+        if (idx_ < (NC)) {                                                                          \
+            const int base_ = (FULL) ? idx_ * 9 : idx_ * 4;                                         \
+            const vec4i h3_ = LDSARR[base_ + 3];                                                    \
+            if (h3_.w) {                                                                            \
+                union { vec4i v[3]; double d[6]; } u_;                                              \
+                u_.v[0] = LDSARR[base_]; u_.v[1] = LDSARR[base_ + 1]; u_.v[2] = LDSARR[base_ + 2];  \
+                f.c[0] = (float)u_.d[0]; f.c[1] = (float)u_.d[1]; f.c[2] = (float)u_.d[2];          \
+                f.e[0] = (float)u_.d[3]; f.e[1] = (float)u_.d[4]; f.e[2] = (float)u_.d[5];          \
+                f.q[0] = 1.0f; f.q[1] = 0.0f; f.q[2] = 0.0f; f.q[3] = 0.0f;                         \
+                f.link0 = h3_.z == kInternal ? h3_.x : h3_.z;                                       \
+                f.link1 = h3_.z == kInternal ? h3_.y : -1;                                          \
+                done_ = true;                                                                       \
+            }                                                                                       \
+        }                                                                                           \
+        if (!done_) f = load_nodef((GLOBF) + idx_);                                                 \
+    } while (0)
 #ifdef PFC_STAMPS
         unsigned long long cy[4] = {0, 0, 0, 0}, it_n = 0;
 #endif
@@ -357,6 +415,14 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         // alone.  (Shared out from the depth-first stack at 128 pairs, a single C3 pose had nearly all its work under two or
         // three of them: 270 us, slower than the batched path.)
         bool bfs = MW;
+        // Single-precision filter in front of the exact test (the batched kernel's test_pair_f32: a third of the exact test's
+        // cycles at one wave per SIMD).  A pair it leaves undecided is settled by the exact test IN THE SAME ITERATION (no parking:
+        // one workgroup has nothing else to run meanwhile), so node tests, candidates and their order are unchanged.  Scenes whose
+        // boxes are axis aligned to each other -- a box resting on a plane: every parallel-edge cross axis is exactly degenerate,
+        // the filter cannot prove "no separation" on it -- would pay for both tests on every pair: once more than a quarter of an
+        // iteration's live pairs come back undecided the workgroup stays with the exact test for the rest of the item (uniform
+        // over the workgroup and, the traversal being deterministic, over a team).
+        bool f32_on = g.f32 != 0 && s_pose_exact == 0;
         int lo = 0, hi = MW ? 1 : 0, hi0 = hi;      // the level: stk[lo, hi); its children from hi0 on
         const int t_share = nw * g.team_seeds < kTeamShareMax ? nw * g.team_seeds : kTeamShareMax;
         for (int guard = 0; (bfs ? hi > lo : sp > 0) && guard < (1 << 22); ++guard) {
@@ -421,37 +487,69 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             bool hit = false;
             int a0 = 0, a1 = 0, b0 = 0, b1 = 0, la_id = 0, lb_id = 0;
             const bool la = act && e.x < 0, lb = act && e.y < 0;
-            NodeU ua, ub;
-            bool both_aabb = true;
-            if (act) {
-                FU_FETCH(ua, B.na, full1, nc1, I.ins.nodes1, node_index(e.x), la);
-                FU_FETCH(ub, B.nb, full2, nc2, I.ins.nodes2, node_index(e.y), lb);
-                const NodeRec &a = ua.r, &b = ub.r;
-                a0 = a.child0; a1 = a.child1; b0 = b.child0; b1 = b.child1; la_id = a.leaf; lb_id = b.leaf;
+            bool need_exact = act, und = false;
+#ifndef PFC_FUSED_F32
+#define PFC_FUSED_F32 1      // 0: compile the single-precision filter out (A/B builds)
+#endif
+            // (restricted to waves that hold tight-fitted leaf boxes -- merged boxes have the exact test's axis-aligned shortcut --
+            // the filter gained nothing: single full-size pose 93.3 us against 81.6 with the filter in every wave)
+            const bool wave_f32 = PFC_FUSED_F32 && f32_on;
+            if (wave_f32 && act) {
+                // 48-byte single-precision nodes: a merged (axis-aligned) box held in LDS is converted from its cached head, every
+                // other node comes from the NodeF array (three 16-byte loads instead of the four to nine of a NodeRec)
+                NodeF fa, fb;
+                FU_FETCHF(fa, B.na, full1, nc1, I.ins.nf1, node_index(e.x));
+                FU_FETCHF(fb, B.nb, full2, nc2, I.ins.nf2, node_index(e.y));
 #ifdef PFC_STAMPS
-                { double keep = a.c[0] + b.c[0] + a.R[4] + b.R[4]; asm volatile("" ::"v"(keep)); }   // the loads have landed
+                { float keep = fa.e[0] + fb.e[0] + fa.q[3] + fb.q[3]; asm volatile("" ::"v"(keep)); }
                 STAMP(u1);
 #endif
-                both_aabb = a.aabb && b.aabb;
+                float R12f[9], t12f[3], q12f[4];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) R12f[k] = s_posef[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) t12f[k] = s_posef[9 + k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q12f[k] = s_q12[k];
+                const int verdict = test_pair_f32(fa, fb, la || lb, R12f, q12f, t12f, s_posef[12]);
+                a0 = fa.link0; a1 = fa.link1; b0 = fb.link0; b1 = fb.link1; la_id = fa.link0; lb_id = fb.link0;
+                und = verdict == 2;
+                need_exact = und;
+                hit = verdict == 1;
             }
-            // The form of the test is chosen per wave, never per lane (a lane-level branch would make a mixed wave run
-            // both): the axis-aligned shortcut only if every active lane holds two merged boxes; the general composition
-            // is exact for identity rotations too.
-            const bool wave_aabb = __all(!act || both_aabb);
-            if (act) {
-                const NodeRec &a = ua.r, &b = ub.r;
-                double R12[9], t12[3];
+            if (__any(need_exact)) {       // (per wave: a wave whose pairs were all decided skips the exact test altogether)
+                NodeU ua, ub;
+                bool both_aabb = true;
+                if (need_exact) {
+                    FU_FETCH(ua, B.na, full1, nc1, I.ins.nodes1, node_index(e.x), la);
+                    FU_FETCH(ub, B.nb, full2, nc2, I.ins.nodes2, node_index(e.y), lb);
+                    const NodeRec &a = ua.r, &b = ub.r;
+                    a0 = a.child0; a1 = a.child1; b0 = b.child0; b1 = b.child1; la_id = a.leaf; lb_id = b.leaf;
+#ifdef PFC_STAMPS
+                    { double keep = a.c[0] + b.c[0] + a.R[4] + b.R[4]; asm volatile("" ::"v"(keep)); }   // the loads have landed
+                    if (!f32_on) STAMP(u1);
+#endif
+                    both_aabb = a.aabb && b.aabb;
+                }
+                // The form of the test is chosen per wave, never per lane (a lane-level branch would make a mixed wave run
+                // both): the axis-aligned shortcut only if every active lane holds two merged boxes; the general composition
+                // is exact for identity rotations too.
+                const bool wave_aabb = __all(!need_exact || both_aabb);
+                if (need_exact) {
+                    const NodeRec &a = ua.r, &b = ub.r;
+                    double R12[9], t12[3];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) R12[k] = s_pose[k];
+                    for (int k = 0; k < 9; ++k) R12[k] = s_pose[k];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
-                if (wave_aabb) {
-                    double aR12[9];
+                    for (int k = 0; k < 3; ++k) t12[k] = s_pose[9 + k];
+                    if (wave_aabb) {
+                        double aR12[9];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) aR12[k] = s_aR12[k];
-                    hit = bb_bb_intersect_aabb(a.c, a.e, b.c, b.e, R12, aR12, t12);
-                } else {
-                    hit = bb_bb_intersect(a, b, R12, t12);
+                        for (int k = 0; k < 9; ++k) aR12[k] = s_aR12[k];
+                        hit = bb_bb_intersect_aabb(a.c, a.e, b.c, b.e, R12, aR12, t12);
+                    } else {
+                        hit = bb_bb_intersect(a, b, R12, t12);
+                    }
                 }
             }
             STAMP(u2);
@@ -465,21 +563,25 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             const bool two = fin && (la != lb);
             const bool four = fin && !la && !lb;
             const unsigned long long mc = __ballot(is_cand), m2 = __ballot(two), m4 = __ballot(four), ml = __ballot(live);
+            const unsigned long long mu = __ballot(und && live);
             if (lane == 0) {
                 s_cnt[wave][0] = __builtin_popcountll(mc);
                 s_cnt[wave][1] = 2 * __builtin_popcountll(m2) + 4 * __builtin_popcountll(m4);
                 s_cnt[wave][2] = __builtin_popcountll(ml);
+                s_cnt[wave][3] = __builtin_popcountll(mu);
             }
             __syncthreads();
             STAMP(u3);
-            int c_off = 0, p_off = 0, c_tot = 0, p_tot = 0;
+            int c_off = 0, p_off = 0, c_tot = 0, p_tot = 0, live_it = 0, und_it = 0;
 #pragma unroll
             for (int w = 0; w < kFuWaves; ++w) {
                 const int c = s_cnt[w][0], q = s_cnt[w][1];
                 if (w < wave) { c_off += c; p_off += q; }
                 c_tot += c; p_tot += q;
-                n_test += s_cnt[w][2];
+                live_it += s_cnt[w][2]; und_it += s_cnt[w][3];
             }
+            n_test += live_it;
+            if (4 * und_it > live_it) f32_on = false;      // uniform: see above
             if (is_cand) {
                 const int pos = n_cand + c_off + prefix_count(mc);
                 if (pos < kFuCand) cand[pos] = make_int2(la_id, lb_id);     // element indices
@@ -542,6 +644,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         }
 #endif
 #undef FU_FETCH
+#undef FU_FETCHF
         if (MW && bfs) {      // the descent ended before it was shared out: every level is used up, rank 0 has it all
             sp = 0;
             if (wr != 0) { n_cand = 0; n_test = 0; }
@@ -703,9 +806,9 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                         // ϵ_plane_r2 = (Ē2 ϵ2) x_ζ2_r2 - (Ē1 ϵ1) (x_ζ1_r1 x_r1_r2)   (find_plane_tet :164, :174-177)
                         double R12[9], t12[3], Z1[16], X1[16];
     #pragma unroll
-                        for (int k = 0; k < 9; ++k) R12[k] = I.pose[12 + k];
+                        for (int k = 0; k < 9; ++k) R12[k] = (g.bp_pose ? s_bp : I.pose + 12)[k];
     #pragma unroll
-                        for (int k = 0; k < 3; ++k) t12[k] = I.pose[21 + k];
+                        for (int k = 0; k < 3; ++k) t12[k] = (g.bp_pose ? s_bp : I.pose + 12)[9 + k];
     #pragma unroll
                         for (int k = 0; k < 16; ++k) Z1[k] = t1->xzr[k];
     #pragma unroll
@@ -983,19 +1086,18 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             block_totals<10>(acc, tot10, red, tid);
             // counts: non-empty polygons and traction points
             const int ne_w = wave_total_i(my_ne, lane), nt_w = wave_total_i(my_nt, lane);
+            // (a team-mate's per-thread status bits -- a non-finite vertex met by one of ITS clip lanes -- reach rank 0 only through
+            // the exchange below: they ride on this reduction)
+            const bool nf_w = MW && __ballot((status & kStNonFinite) != 0) != 0ull;
             __syncthreads();
-            if (lane == 0) { s_cnt[wave][0] = ne_w; s_cnt[wave][1] = nt_w; }
+            if (lane == 0) { s_cnt[wave][0] = ne_w; s_cnt[wave][1] = nt_w; s_cnt[wave][2] = nf_w ? 1 : 0; }
             __syncthreads();
             n_nonempty = ((s_cnt[0][0] + s_cnt[1][0]) + s_cnt[2][0]) + s_cnt[3][0];
             n_trac = ((s_cnt[0][1] + s_cnt[1][1]) + s_cnt[2][1]) + s_cnt[3][1];
+            if (MW && (((s_cnt[0][2] | s_cnt[1][2]) | s_cnt[2][2]) | s_cnt[3][2])) status |= kStNonFinite;
             // what this workgroup found, one value per thread: the ten sums [0, 10), the four counters, the status word, and for
             // a bristle item the 27 moments about c0 [15, 42) and c0 itself [42, 45)
             double mine = 0.0;
-            if (MW) {
-                // a team-mate's per-thread bits (a non-finite vertex met by one of ITS clip lanes) reach rank 0 only through this
-                // exchange: combine them over the workgroup first
-                if (__syncthreads_or((status & kStNonFinite) != 0)) status |= kStNonFinite;
-            }
             if (tid < 10) mine = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
             else if (tid == 10) mine = (double)n_test;
             else if (tid == 11) mine = (double)n_cand;
@@ -1074,17 +1176,22 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         } else {
             block_partials<6>(acc, red, tid);
             if (MW) {
-                // six friction sums and, in slot 6, the rank's status word (OR): a rank whose wait after pass 0 timed out went on
-                // with stale totals and a status word only IT holds -- rank 0, the writer of the outputs, must see it here
-                // (before: rank 0 summed that rank's partials and reported success)
-                const double mine = tid < 6 ? ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid] : (tid == 6 ? (double)status : 0.0);
-                const double tot = team_sum(g, item, nw, 2, 7, mine, 6, tid, s_team, &s_tflag, status);
+                // A rank whose wait after pass 0 timed out went on with stale totals and a status word only IT holds; rank 0, the
+                // writer of the outputs, must learn of it here (before: it summed that rank's friction partials and reported
+                // success).  Such a rank -- and one that met a non-finite vertex or an aborted descent after the first exchange --
+                // publishes NaN instead of its sums: every rank's total is then NaN and the item reports kStFusedOvf (the host
+                // re-issues on the batched path, which reports what there is to report).  No extra slot, no extra pass: a seventh
+                // value OR-ed over the ranks cost the single pose 2.7 us.
+                const bool bad = (status & (kStFusedOvf | kStNonFinite | kStAbort)) != 0;
+                double mine = tid < 6 ? ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid] : 0.0;
+                if (bad) mine = __builtin_nan("");
+                const double tot = team_sum(g, item, nw, 2, 6, mine, -1, tid, s_team, &s_tflag, status);
                 if (tid < 6) s_acc[kAccFric + tid] = tot;
-                if (tid == 6) s_tres[6] = tot;
+                if (tid == 0) s_tres[6] = (tot != tot) ? 1.0 : 0.0;
                 FSTAMP(15);
             } else if (tid < 6) s_acc[kAccFric + tid] = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
             __syncthreads();
-            if (MW) status |= (unsigned)s_tres[6];
+            if (MW && s_tres[6] != 0.0) status |= kStFusedOvf;
         }
     }
 
@@ -1096,9 +1203,9 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         if (tid == 0) {
             ItemRec &r = s_it;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) { r.R21[k] = I.pose[k]; r.R12[k] = I.pose[12 + k]; }
+            for (int k = 0; k < 9; ++k) { r.R21[k] = I.pose[k]; r.R12[k] = (g.bp_pose ? s_bp : I.pose + 12)[k]; }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { r.t21[k] = I.pose[9 + k]; r.t12[k] = I.pose[21 + k]; r.w[k] = I.twist[k]; r.v[k] = I.twist[3 + k]; }
+            for (int k = 0; k < 3; ++k) { r.t21[k] = I.pose[9 + k]; r.t12[k] = (g.bp_pose ? s_bp : I.pose + 12)[9 + k]; r.w[k] = I.twist[k]; r.v[k] = I.twist[3 + k]; }
 #pragma unroll
             for (int k = 0; k < 6; ++k) r.s[k] = (I.ins.model == PFC_BRISTLE) ? I.s[k] : 0.0;
             r.chi = I.ins.chi; r.Ebar = I.ins.Ebar; r.mu_s = I.ins.mu_s; r.mu_d = I.ins.mu_d; r.v_c = I.ins.v_c; r.tau = I.ins.tau;

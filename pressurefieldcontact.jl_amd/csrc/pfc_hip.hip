@@ -234,6 +234,7 @@ struct pfc_context {
     int pin_bp_n = 0;                    // items it holds (0: the last host-buffer Dual evaluation had none)
     bool team_owner = false;             // this handle holds its device's team slot (team_acquire)
     int opt_team_fault = -1;             // diagnostic option "team_fault": rank of every team that simulates a timed-out wait
+    int opt_fused_f32 = 1;               // option "fused_f32": single-precision SAT filter in the one-launch kernel (A/B knob; same results)
     std::string err;
     hipStream_t stream = nullptr;
     std::vector<HostMesh> meshes;
@@ -970,7 +971,7 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
     HIP_TRY(h, h->stamps.ensure(16));
     a.stamps = h->stamps.p;
 #endif
-    a.bp_pose = h->bp_dev; a.team_fault = h->opt_team_fault;
+    a.bp_pose = h->bp_dev; a.team_fault = h->opt_team_fault; a.f32 = h->opt_fused_f32;
     a.nw = h->fu_nw; a.team = nullptr;
     a.team_seeds = h->max_leaves > kFusedMaxLeaves ? kTeamSeedsBig : kTeamSeeds;
     h->last_fu_nw = a.nw;
@@ -1539,6 +1540,7 @@ int pfc_finalize(pfc_handle h) {
             f.tau = in.tau; f.k_bar = in.k_bar; f.magic = in.magic;
             f.model = in.model; f.nq = in.nq; f.n_node1 = m1.n_node; f.n_node2 = m2.n_node;
             f.reserve = 3 * (m1.depth + m2.depth + 1) + 3;
+            f.cmax12 = m1.cmax + m2.cmax;
             full[k] = f;
         }
         HIP_TRY(h, hipMalloc((void **)&h->d_insfull, sizeof(InsFull) * full.size()));
@@ -2550,6 +2552,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "fused")) { h->opt_fused = value != 0; h->fused_skip = 0; }
     else if (!std::strcmp(name, "team")) h->opt_team = value < 0 ? 0 : (value > kTeamMaxWg ? kTeamMaxWg : (int)value);
     else if (!std::strcmp(name, "team_fault")) h->opt_team_fault = (int)value;
+    else if (!std::strcmp(name, "fused_f32")) h->opt_fused_f32 = value != 0;
     else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;
