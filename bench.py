@@ -184,6 +184,72 @@ def small_scene_latencies(pfc, reps: int = 200):
     return out
 
 
+def dual_block(pfc, dev, n_dir: int = 6):
+    """roofline_dual: what Radau's Jacobian evaluations cost on this path.  Device-resident Dual(n_dir) evaluations
+    with dense seeds of C5 (2 016 pile instructions) and of a 2 048-pose C3 batch: a first chunk (value pass + Dual passes,
+    pfc_eval_dual_device) and the further chunks of the same Jacobian (pfc_eval_dual_device_more: Dual passes on the kept value
+    pass), medians; units = contributing (pair, direction) lanes per chunk; the wave-level instruction counts of the Dual kernels
+    come from profiles/pmc_dual.json (rocprofv3 --pmc of the same calls, scripts/profile_dual.sh)."""
+    import numpy as np
+    import torch
+    out = {}
+    pj = os.path.join(ROOT, "profiles", "pmc_dual.json")
+    pm = json.load(open(pj)) if os.path.exists(pj) else {}
+    for name, key, w in (("C5", "c5", pfc.configs.c5_pile()), ("C3x2048", "c3b", pfc.configs.c3_blob_tool(2048))):
+        m = pfc.configs.build_scenario(w)
+        ni = w.n_items
+        T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+        rng = np.random.default_rng(7)
+        t = [T(w.ins_ids, torch.int32), T(w.pose), T(w.twist), T(w.s), T(rng.standard_normal((ni, n_dir, 24)) * 1e-3),
+             T(rng.standard_normal((ni, n_dir, 6)) * 1e-2), T(rng.standard_normal((ni, n_dir, 6)) * 1e-4)]
+        o = [torch.zeros((ni, 6), dtype=torch.float64, device=dev), torch.zeros((ni, 6), dtype=torch.float64, device=dev),
+             torch.zeros((ni, n_dir, 6), dtype=torch.float64, device=dev), torch.zeros((ni, n_dir, 6), dtype=torch.float64, device=dev),
+             torch.zeros((ni, 4), dtype=torch.int32, device=dev)]
+        st = torch.cuda.current_stream().cuda_stream
+
+        def first():
+            for _ in range(40):
+                m.eval_dual_device(ni, n_dir, *[x.data_ptr() for x in t], *[x.data_ptr() for x in o], st)
+                if m.check() == 0:
+                    return
+            raise RuntimeError("Dual work lists kept overflowing")
+
+        def more():
+            m.eval_dual_device_more(n_dir, t[4].data_ptr(), t[5].data_ptr(), t[6].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), st)
+            assert m.check() == 0
+
+        for _ in range(3):
+            first(); more()
+        tf, tm_ = [], []
+        reps = 7 if key == "c5" else 3
+        for _ in range(reps):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); first(); tf.append(time.perf_counter() - t0)
+            for _ in range(3):
+                t0 = time.perf_counter(); more(); tm_.append(time.perf_counter() - t0)
+        cnt = o[4].cpu().numpy()
+        pairs = int(cnt[:, 2].sum())               # pairs with a polygon: the Dual passes' work list (those without a traction point are skipped)
+        units = pairs * n_dir
+        e = {"items": ni, "n_dir": n_dir, "pairs_with_polygon": pairs, "pair_directions_per_chunk": units,
+             "first_chunk_us": statistics.median(tf) * 1e6, "further_chunk_us": statistics.median(tm_) * 1e6,
+             "pair_directions_per_s_further_chunks": units / statistics.median(tm_)}
+        kern = pm.get(key, {})
+        if kern:
+            # the Dual kernels of ONE chunk: k_narrow_dual (pass A), k_dual_poly<1>, k_dual_eig, k_dual_poly<2>, k_dual_final
+            tot_i = sum(v.get("valu_insts_per_launch", 0.0) for v in kern.values())
+            tot_b = sum(v.get("issue_bound_us", 0.0) for v in kern.values())
+            tot_t = sum(v.get("mean_us", 0.0) for k, v in kern.items() if "flags" not in k and "select" not in k)
+            e["valu"] = {"wave_instructions_per_pair_direction": tot_i / max(units, 1) , "issue_bound_us_per_chunk": tot_b,
+                         "kernel_us_per_chunk_profiled": tot_t, "frac_of_issue_bound": tot_b / tot_t if tot_t else None,
+                         "per_kernel": {k.replace("pfc::", ""): {"us": round(v["mean_us"], 1), "wave_instr": int(v.get("valu_insts_per_launch", 0)),
+                                                                 "frac_of_issue_bound": (round(v["frac_of_issue_bound"], 3) if v.get("frac_of_issue_bound") else None),
+                                                                 "active_lanes": (round(v["active_lanes"], 1) if v.get("active_lanes") else None)}
+                                        for k, v in kern.items()},
+                         "note": "wave64 VALU instructions from profiles/pmc_dual.json (" + str(pm.get("measured")) + "); issue cost 4.2 cycles Float64 / 3.4 other, 1024 SIMDs, 2.4 GHz"}
+        out[name] = e
+        m.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -539,6 +605,7 @@ def main():
             # single-pose rate of the C3 scene and the small reference-sized scenes (latency, not throughput)
             out["small_scenes"] = small_scene_latencies(pfc)
             out["single_pose_ops_per_s"] = out["small_scenes"]["C3_single_pose"]["ops_per_s"]
+            out["roofline_dual"] = dual_block(pfc, dev)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pfc, w, args.cpu_seconds, 1)
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

@@ -138,6 +138,13 @@ struct DualArgs {
     int2 *dpoly_key;         // (item * n_dir + dir, n_poly)
     long long dpcap;
     int tri_split;           // k_dual_poly: 1 = one lane per (kept polygon, fan triangle) instead of one per polygon (small scenes)
+    // Fold of pass B into pass A (batched value pass only): the value pass's result rows (kRes* layout; the cop VALUE c0 of a
+    // bristle item in contact).  Non-null: k_narrow_dual<.., FOLD> also forms the 21 stiffness sums, about the fixed point
+    // c0 instead of the Dual cop (not known before pass A ends), and k_dual_eig moves them to the Dual cop by the
+    // parallel-axis rule -- the shift d = cop - c0 has a rounding-sized value and the cop's partials, nothing cancels.
+    // k_dual_poly<1> and its read of every kept polygon are not launched.  Null (hand-over from the fused small-scene
+    // kernel, which keeps its cop in LDS): three passes as before.
+    const double *vres;
 };
 constexpr int kDpFields = 64;
 
@@ -170,10 +177,33 @@ __device__ __forceinline__ bool seed_nonzero_wave(const DualArgs &g, int key, in
 // integrand: MODE 0 normal wrench + regularized friction + cop sums, 1 patch stiffness about the cop, 2 bristle force
 // [k0, k1): the fan triangles (v_{k-1}, v_k, centroid) this lane integrates: all of them (0, n) with one lane per
 // polygon; one of them when the fused small-scene kernel deals the triangles out one per thread.
-template <int MODE, class VF>
+// the 21 patch-stiffness entries of one polygon (n̂ constant) from W = sum w, m1 = sum w x, Q = sum w x x' (x = r - reference point):
+//   K22 = W (I - n n'),  K12 = [m1]x - (m1 x n) n',  K11 = -(Q - tr(Q) I) - [n]x Q [n]x'   (Q symmetric)
+__device__ __forceinline__ void dual_stiffness_entries(Du kW, const Du *km, const Du *kQ, Du3 nh, Du *sum) {
+    const Du3 m1 = dmk(km[0], km[1], km[2]);
+    const Du3 mn = dcross(m1, nh);
+    const Du tr = (kQ[0] + kQ[3]) + kQ[5];
+    const Du3 c0 = dmk(kQ[0], kQ[1], kQ[2]), c1 = dmk(kQ[1], kQ[3], kQ[4]), c2 = dmk(kQ[2], kQ[4], kQ[5]);
+    const Du3 a0 = dcross(nh, c0), a1 = dcross(nh, c1), a2 = dcross(nh, c2);                 // M = [n]x Q (columns)
+    // S = M [n]x': row i of S = n x (row i of M)
+    const Du3 r0 = dcross(nh, dmk(a0.x, a1.x, a2.x)), r1 = dcross(nh, dmk(a0.y, a1.y, a2.y));
+    const Du3 r2 = dcross(nh, dmk(a0.z, a1.z, a2.z));
+    sum[0] += -((kQ[0] - tr) + r0.x); sum[1] += -(kQ[1] + r0.y); sum[2] += -(kQ[2] + r0.z);
+    sum[3] += -((kQ[3] - tr) + r1.y); sum[4] += -(kQ[4] + r1.z); sum[5] += -((kQ[5] - tr) + r2.z);
+    sum[6] += du(0.0) - mn.x * nh.x; sum[7] += m1.z - mn.y * nh.x; sum[8] += -m1.y - mn.z * nh.x;
+    sum[9] += -m1.z - mn.x * nh.y; sum[10] += du(0.0) - mn.y * nh.y; sum[11] += m1.x - mn.z * nh.y;
+    sum[12] += m1.y - mn.x * nh.z; sum[13] += -m1.x - mn.y * nh.z; sum[14] += du(0.0) - mn.z * nh.z;
+    sum[15] += kW * (du(1.0) - nh.x * nh.x); sum[16] += kW * (du(0.0) - nh.x * nh.y);
+    sum[17] += kW * (du(0.0) - nh.x * nh.z); sum[18] += kW * (du(1.0) - nh.y * nh.y);
+    sum[19] += kW * (du(0.0) - nh.y * nh.z); sum[20] += kW * (du(1.0) - nh.z * nh.z);
+}
+
+// FOLD (MODE 0, bristle lanes): also m1 = sum w x and Q = sum w x x' about the FIXED point c0 (fold[0..2], fold[3..8]): what
+// pass B would accumulate, had it the cop c0 (DualArgs::vres).
+template <int MODE, bool FOLD = false, class VF>
 __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, const double *er, const ItemRec *it,
                                        const double *dt, bool reg, Du3 cop, Du3 Da, Du3 Dl, Du *sum, int &n_trac,
-                                       int k0, int k1) {
+                                       int k0, int k1, const double *c0 = nullptr, Du *fold = nullptr) {
     const double er0 = er[0], er1 = er[1], er2 = er[2], er3 = er[3];
     const Du3 w = dmk(du(it->w[0], dt[0]), du(it->w[1], dt[1]), du(it->w[2], dt[2]));
     const Du3 vl = dmk(du(it->v[0], dt[3]), du(it->v[1], dt[4]), du(it->v[2], dt[5]));
@@ -262,6 +292,13 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
                 // torque follow from W and sum w r after the loop
                 sum[6] += p_dA;
                 sum[7] += p_dA * r.x; sum[8] += p_dA * r.y; sum[9] += p_dA * r.z;
+                if constexpr (FOLD) {
+                    const Du3 x = dmk(r.x - du(c0[0]), r.y - du(c0[1]), r.z - du(c0[2]));
+                    const Du wx = p_dA * x.x, wy = p_dA * x.y, wz = p_dA * x.z;
+                    fold[0] += wx; fold[1] += wy; fold[2] += wz;
+                    fold[3] += wx * x.x; fold[4] += wx * x.y; fold[5] += wx * x.z;
+                    fold[6] += wy * x.y; fold[7] += wy * x.z; fold[8] += wz * x.z;
+                }
             }
             }
         }
@@ -273,25 +310,7 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
             sum[3] = nh.x * sum[6]; sum[4] = nh.y * sum[6]; sum[5] = nh.z * sum[6];
         }
     }
-    if constexpr (MODE == 1) {
-        // K22 = W (I - n n'),  K12 = [m1]x - (m1 x n) n',  K11 = -(Q - tr(Q) I) - [n]x Q [n]x'   (Q symmetric)
-        const Du3 m1 = dmk(km[0], km[1], km[2]);
-        const Du3 mn = dcross(m1, nh);
-        const Du tr = (kQ[0] + kQ[3]) + kQ[5];
-        const Du3 c0 = dmk(kQ[0], kQ[1], kQ[2]), c1 = dmk(kQ[1], kQ[3], kQ[4]), c2 = dmk(kQ[2], kQ[4], kQ[5]);
-        const Du3 a0 = dcross(nh, c0), a1 = dcross(nh, c1), a2 = dcross(nh, c2);                 // M = [n]x Q (columns)
-        // S = M [n]x': row i of S = n x (row i of M)
-        const Du3 r0 = dcross(nh, dmk(a0.x, a1.x, a2.x)), r1 = dcross(nh, dmk(a0.y, a1.y, a2.y));
-        const Du3 r2 = dcross(nh, dmk(a0.z, a1.z, a2.z));
-        sum[0] += -((kQ[0] - tr) + r0.x); sum[1] += -(kQ[1] + r0.y); sum[2] += -(kQ[2] + r0.z);
-        sum[3] += -((kQ[3] - tr) + r1.y); sum[4] += -(kQ[4] + r1.z); sum[5] += -((kQ[5] - tr) + r2.z);
-        sum[6] += du(0.0) - mn.x * nh.x; sum[7] += m1.z - mn.y * nh.x; sum[8] += -m1.y - mn.z * nh.x;
-        sum[9] += -m1.z - mn.x * nh.y; sum[10] += du(0.0) - mn.y * nh.y; sum[11] += m1.x - mn.z * nh.y;
-        sum[12] += m1.y - mn.x * nh.z; sum[13] += -m1.x - mn.y * nh.z; sum[14] += du(0.0) - mn.z * nh.z;
-        sum[15] += kW * (du(1.0) - nh.x * nh.x); sum[16] += kW * (du(0.0) - nh.x * nh.y);
-        sum[17] += kW * (du(0.0) - nh.x * nh.z); sum[18] += kW * (du(1.0) - nh.y * nh.y);
-        sum[19] += kW * (du(0.0) - nh.y * nh.z); sum[20] += kW * (du(1.0) - nh.z * nh.z);
-    }
+    if constexpr (MODE == 1) dual_stiffness_entries(kW, km, kQ, nh, sum);
 }
 
 // Polygon rings of pass A in LDS.  The VALUE ring is shared by the n_dir lanes of a candidate: they hold the same
@@ -303,6 +322,46 @@ __device__ __forceinline__ void dual_integrate(VF vert, int n, Du3 nh, Du3 cen, 
 #define PD(k, c) pd[((((rbase) + (k)) & 7) * 4 + (c)) * 64 + lane]
 __host__ __device__ inline int dual_pv_stride(int n_dir) { return 64 / n_dir <= 16 ? 16 : 64; }
 __host__ inline size_t dual_lds_bytes(int n_dir) { return sizeof(double) * (size_t)(8 * 4 * 64 + 8 * 4 * dual_pv_stride(n_dir)); }
+
+// Per-key sums of a wave of the Dual passes.  Lane l of a wave of k_narrow_dual / k_dual_poly holds candidate l % cpw in
+// direction l / cpw (cpw = 64 / n_dir), so a key's lanes are the cpw consecutive lanes of its direction -- if the wave's
+// contributing candidates all belong to ONE item, which is nearly always so (an item's pairs sit in runs).  Then the N sums go
+// through LDS: every lane stores its values as a column, lane (d, j) adds the cpw entries of direction d in row j and issues
+// the atomic: ~6 N instructions per wave instead of the ~30 N of N segmented scans (accumulate_items, the fallback for a
+// wave that straddles items).  buf: 21 x 65 doubles (row stride 65: the row walk of consecutive lanes is conflict-free).
+constexpr int kDualRedRows = 21, kDualRedStride = 65;
+template <int N>
+__device__ __forceinline__ void dual_accumulate(double *buf, double *acc, int key, bool listed, bool any, const double *v, int n0,
+                                                int n_dir, int lane) {
+    const unsigned long long am = __ballot(any);
+    if (am == 0) return;
+    const int item = key >= 0 ? key / n_dir : -1;
+    const int item0 = __builtin_amdgcn_readlane(item, __builtin_ctzll(am));
+    if (__ballot(any && item != item0) != 0) {      // uniform
+        accumulate_items<N>(acc, key, listed, any, v, n0, kDaStride);
+        return;
+    }
+    const int cpw = 64 / n_dir;
+    constexpr int R = (N + kDualRedRows - 1) / kDualRedRows, NB = (N + R - 1) / R;
+    wave_lds_sync();      // (the buffer may be the polygon ring the lanes have just read)
+#pragma unroll
+    for (int rd = 0; rd < R; ++rd) {
+        const int base = rd * NB;
+        const int nb = (N - base < NB) ? N - base : NB;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (j < nb) buf[j * kDualRedStride + lane] = any ? v[base + j] : 0.0;
+        wave_lds_sync();
+        for (int t = lane; t < n_dir * nb; t += 64) {
+            const int d = t / nb, j = t - d * nb;
+            const double *row = buf + j * kDualRedStride + d * cpw;
+            double x = 0.0;
+            for (int c = 0; c < cpw; ++c) x += row[c];
+            if (x != 0.0) unsafeAtomicAdd(&acc[(size_t)(item0 * n_dir + d) * kDaStride + n0 + base + j], x);
+        }
+        wave_lds_sync();
+    }
+}
 
 // Selection of the contributing pairs a chunk has work for (scenes of many items): k_dual_flags marks the items with a
 // non-zero seed in any direction (one wave per item), k_dual_select copies the contributing pairs of marked items into a
@@ -374,7 +433,10 @@ __global__ void __launch_bounds__(256) k_dual_select(DualArgs g, const int *flag
 
 // Pass A: gather, clip and integrate in Dual arithmetic (normal wrench, regularized friction fused, cop sums); the
 // Dual polygon of every contributing bristle lane is kept for passes B and C (k_dual_poly).  TT as in k_narrow.
-template <bool TT>
+// PVS: the column stride of the shared value ring, dual_pv_stride(n_dir), as a compile-time constant: with a run-time stride every
+// ring slot the code names -- (slot, coordinate) pairs with rbase = 0 -- became a loop-invariant address in a register of its
+// own, and those registers were what the tet-tet instantiation spilled (round 3: 15 VGPRs + 64 bytes of scratch per lane).
+template <bool TT, int PVS, bool FOLD = false>
 __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
     extern __shared__ double dual_lds[];     // dual_lds_bytes(n_dir): partial ring (16 KiB), then the value ring
     double *pd = dual_lds, *pv = dual_lds + 8 * 4 * 64;
@@ -385,7 +447,8 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
     const int cpw = 64 / n_dir;
     const int n_group = (n_c + cpw - 1) / cpw;
     const int dir = lane / cpw, cl = lane - dir * cpw;
-    const int pvs = dual_pv_stride(n_dir), pvi = pvs == 16 ? cl : lane;
+    constexpr int pvs = PVS;
+    const int pvi = PVS == 16 ? cl : lane;
     for (int grp = blockIdx.x; grp < n_group; grp += gridDim.x) {
         const int idx = grp * cpw + cl;
         const bool active = dir < n_dir && idx < n_c;
@@ -415,15 +478,19 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
             for (int k = 0; k < 9; ++k) R21[k] = du(it->R21[k], dp[k]);
 #pragma unroll
             for (int k = 0; k < 3; ++k) t21[k] = du(it->t21[k], dp[9 + k]);
-            Du z[4][4];
+            // Each op ends with its polygon in the ring (slots 0 .. n_in - 1, rbase 0) and the verdict of the bit-exact trivial
+            // reject; nothing but n_in, nh_in and that verdict lives across the two forms (with the tri-tet op's z[4][4] and the
+            // tet-tet op's vertices in common variables the TT kernel needed 15 ... 75 spilled registers and scratch).
             int n_in = 0;
             Du3 nh_in = nh;
+            bool reject = true;
             double Z[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) Z[k] = tp->xzr[k];
             if (!TT || it->tet1 == nullptr) {
                 // tri-tet op (non_friction.jl:196-215)
                 const GTriRec *tr = (const GTriRec *)(it->tri + cw.a);
+                Du z[3][4];
                 Du X[16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -437,32 +504,34 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         z[k][i] = ((X[i] * tr->v[3 * k] + X[i + 4] * tr->v[3 * k + 1]) + X[i + 8] * tr->v[3 * k + 2]) + X[i + 12];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) z[3][i] = du(0.0);
                 n_in = 3;
                 nh_in = dmk((R21[0] * tr->n[0] + R21[3] * tr->n[1]) + R21[6] * tr->n[2],
                             (R21[1] * tr->n[0] + R21[4] * tr->n[1]) + R21[7] * tr->n[2],
                             (R21[2] * tr->n[0] + R21[5] * tr->n[1]) + R21[8] * tr->n[2]);
+                bool finite = true;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) finite &= (__builtin_fabs(z[k][i].v) <= 1.79769313486231570815e308);
+                reject = !finite;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) reject |= (z[0][i].v <= 0.0) && (z[1][i].v <= 0.0) && (z[2][i].v <= 0.0);
+                if (!reject) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { PV(k, i) = z[k][i].v; PD(k, i) = z[k][i].d; }
+                }
             } else {
                 // tet-tet op (non_friction.jl:166-194)
                 const GTetRec *t1 = (const GTetRec *)(it->tet1 + cw.a);
                 Du plane[4];
                 {
-                    Du R12[9], t12[3], X1[16];
+                    // x_zeta1_r2 = x_zeta1_r1 * x_r1_r2 one COLUMN at a time, each reduced to its plane coefficient at once (the same
+                    // expressions, entry for entry, as the whole 4 x 4 product held in 64 registers)
                     double Z1[16];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) R12[k] = du(it->R12[k], dp[12 + k]);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) t12[k] = du(it->t12[k], dp[21 + k]);
-#pragma unroll
                     for (int k = 0; k < 16; ++k) Z1[k] = t1->xzr[k];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int j = 0; j < 3; ++j)
-                            X1[i + 4 * j] = (Z1[i] * R12[3 * j] + Z1[i + 4] * R12[3 * j + 1]) + Z1[i + 8] * R12[3 * j + 2];
-                        X1[i + 12] = ((Z1[i] * t12[0] + Z1[i + 4] * t12[1]) + Z1[i + 8] * t12[2]) + du(Z1[i + 12]);
-                    }
                     double Ee1[4], Ee2[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -471,29 +540,46 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const Du p1 = ((Ee1[0] * X1[4 * j] + Ee1[1] * X1[4 * j + 1]) + Ee1[2] * X1[4 * j + 2]) + Ee1[3] * X1[4 * j + 3];
+                        Du Xc[4];
+                        if (j < 3) {
+                            const Du r0 = du(it->R12[3 * j], dp[12 + 3 * j]), r1 = du(it->R12[3 * j + 1], dp[12 + 3 * j + 1]),
+                                     r2 = du(it->R12[3 * j + 2], dp[12 + 3 * j + 2]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) Xc[i] = (Z1[i] * r0 + Z1[i + 4] * r1) + Z1[i + 8] * r2;
+                        } else {
+                            const Du r0 = du(it->t12[0], dp[21]), r1 = du(it->t12[1], dp[22]), r2 = du(it->t12[2], dp[23]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) Xc[i] = ((Z1[i] * r0 + Z1[i + 4] * r1) + Z1[i + 8] * r2) + du(Z1[i + 12]);
+                        }
+                        const Du p1 = ((Ee1[0] * Xc[0] + Ee1[1] * Xc[1]) + Ee1[2] * Xc[2]) + Ee1[3] * Xc[3];
                         const double p2 = ((Ee2[0] * Z[4 * j] + Ee2[1] * Z[4 * j + 1]) + Ee2[2] * Z[4 * j + 2]) + Ee2[3] * Z[4 * j + 3];
                         plane[j] = du(p2) - p1;
                     }
                 }
-                Du3 P[4];
-                Du proj[4];
+                // The four vertices of tet 1 in frame r2 and their projections wait in the upper half of the lane's polygon ring
+                // (slots 4..7: coordinates 0..2 the vertex, 3 its projection) instead of in 64 registers: with them the kernel needed
+                // 256 VGPRs + 15 spilled ones and 64 bytes of scratch per lane (round 3).  rbase is 0 here; the clip below starts
+                // from slots 0..3.  (The value ring is shared by the directions of a candidate: they write the same numbers.)
                 int n_neg = 0, n_pos = 0;
                 unsigned posm = 0, negm = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const double vx = t1->xrz[3 * j], vy = t1->xrz[3 * j + 1], vz = t1->xrz[3 * j + 2];
-                    P[j] = dmk(((R21[0] * vx + R21[3] * vy) + R21[6] * vz) + t21[0],
-                               ((R21[1] * vx + R21[4] * vy) + R21[7] * vz) + t21[1],
-                               ((R21[2] * vx + R21[5] * vy) + R21[8] * vz) + t21[2]);
-                    proj[j] = ((plane[0] * P[j].x + plane[1] * P[j].y) + plane[2] * P[j].z) + plane[3];
-                    if (proj[j].v < 0.0) { ++n_neg; negm |= 1u << j; }
-                    if (0.0 < proj[j].v) { ++n_pos; posm |= 1u << j; }
+                    const Du3 Pj = dmk(((R21[0] * vx + R21[3] * vy) + R21[6] * vz) + t21[0],
+                                       ((R21[1] * vx + R21[4] * vy) + R21[7] * vz) + t21[1],
+                                       ((R21[2] * vx + R21[5] * vy) + R21[8] * vz) + t21[2]);
+                    const Du pj = ((plane[0] * Pj.x + plane[1] * Pj.y) + plane[2] * Pj.z) + plane[3];
+                    PV(4 + j, 0) = Pj.x.v; PV(4 + j, 1) = Pj.y.v; PV(4 + j, 2) = Pj.z.v; PV(4 + j, 3) = pj.v;
+                    PD(4 + j, 0) = Pj.x.d; PD(4 + j, 1) = Pj.y.d; PD(4 + j, 2) = Pj.z.d; PD(4 + j, 3) = pj.d;
+                    if (pj.v < 0.0) { ++n_neg; negm |= 1u << j; }
+                    if (0.0 < pj.v) { ++n_pos; posm |= 1u << j; }
                 }
                 Du3 q[4];
                 q[0] = q[1] = q[2] = q[3] = dmk(du(0.0), du(0.0), du(0.0));
                 int n_q = 0;
-#define PW_(i1, i2) (P[i2] * (proj[i1] / (proj[i1] - proj[i2])) - P[i1] * (proj[i2] / (proj[i1] - proj[i2])))
+#define PJ_(j) dmk(du(PV(4 + (j), 0), PD(4 + (j), 0)), du(PV(4 + (j), 1), PD(4 + (j), 1)), du(PV(4 + (j), 2), PD(4 + (j), 2)))
+#define PR_(j) du(PV(4 + (j), 3), PD(4 + (j), 3))
+#define PW_(i1, i2) (PJ_(i2) * (PR_(i1) / (PR_(i1) - PR_(i2))) - PJ_(i1) * (PR_(i2) / (PR_(i1) - PR_(i2))))
                 if (n_pos != 0 && n_neg != 0) {
                     int lone = -1;
                     if (n_pos == 1) lone = __builtin_ctz(posm);
@@ -504,7 +590,7 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
                         else if (lone == 1) { a = PW_(0, 1); b = PW_(2, 1); c = PW_(3, 1); }
                         else if (lone == 2) { a = PW_(0, 2); b = PW_(3, 2); c = PW_(1, 2); }
                         else { a = PW_(0, 3); b = PW_(1, 3); c = PW_(2, 3); }
-                        const double pl = (lone == 0) ? proj[0].v : (lone == 1) ? proj[1].v : (lone == 2) ? proj[2].v : proj[3].v;
+                        const double pl = (lone == 0) ? PV(4, 3) : (lone == 1) ? PV(5, 3) : (lone == 2) ? PV(6, 3) : PV(7, 3);
                         n_q = 3;
                         if (0.0 < pl) { q[0] = a; q[1] = b; q[2] = c; } else { q[0] = c; q[1] = b; q[2] = a; }
                     } else {
@@ -514,42 +600,41 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
                         else if (p0 == p2) { a = PW_(0, 1); b = PW_(0, 3); c = PW_(2, 3); d = PW_(2, 1); }
                         else { a = PW_(0, 2); b = PW_(0, 1); c = PW_(3, 1); d = PW_(3, 2); }
                         n_q = 4;
-                        if (0.0 < proj[0].v) { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+                        if (0.0 < PV(4, 3)) { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
                         else { q[0] = d; q[1] = c; q[2] = b; q[3] = a; }
                     }
                 }
 #undef PW_
+#undef PJ_
+#undef PR_
+                // (written straight into the ring, where the clip wants them: as 32 more live doubles they were what spilled)
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const Du v = ((Z[i] * q[k].x + Z[i + 4] * q[k].y) + Z[i + 8] * q[k].z) + du(Z[i + 12]);
-                        z[k][i] = v * ((1.0e-14 < __builtin_fabs(v.v)) ? 1.0 : 0.0);   // zero_small_coordinates
+                        const Du vz = v * ((1.0e-14 < __builtin_fabs(v.v)) ? 1.0 : 0.0);   // zero_small_coordinates
+                        PV(k, i) = vz.v; PD(k, i) = vz.d;
                     }
                 n_in = n_q;
                 nh_in = dnormalize(dmk(plane[0], plane[1], plane[2]));
+                bool finite = true;
+                reject = n_in < 3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double z0 = PV(0, i), z1 = PV(1, i), z2 = PV(2, i), z3 = PV(3, i);      // the values just written
+                    finite &= (__builtin_fabs(z0) <= 1.79769313486231570815e308) && (__builtin_fabs(z1) <= 1.79769313486231570815e308) &&
+                              (__builtin_fabs(z2) <= 1.79769313486231570815e308) && (n_in < 4 || __builtin_fabs(z3) <= 1.79769313486231570815e308);
+                    reject |= (z0 <= 0.0) && (z1 <= 0.0) && (z2 <= 0.0) && (n_in < 4 || z3 <= 0.0);
+                }
+                reject |= !finite;
             }
-            bool finite = true;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) finite &= (k >= n_in) || (__builtin_fabs(z[k][i].v) <= 1.79769313486231570815e308);
-            bool reject = !finite || n_in < 3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                reject |= (z[0][i].v <= 0.0) && (z[1][i].v <= 0.0) && (z[2][i].v <= 0.0) && (n_in < 4 || z[3][i].v <= 0.0);
             if (!reject) {
                 // clip_in_tet_coordinates (static_clip.jl:7-23,34-201), polygon ring in LDS, clipped in place
                 int n = n_in;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < n_in) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { PV(k, i) = z[k][i].v; PD(k, i) = z[k][i].d; }
-                    }
                 {
                     bool err = false;      // "Non-finite vertex likely": the value pass has reported it
-                    RingDu<> ring{pv, pd, pvs, pvi, 64, lane, rbase};
+                    RingDu<PVS> ring{pv, pd, pvs, pvi, 64, lane, rbase};
                     n = clip_ring_in_tet_coordinates(ring, n_in, err);     // pfc_clip.h
                     rbase = ring.rbase;
                 }
@@ -564,6 +649,9 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
         for (int k = 0; k < NS; ++k) sum[k] = du(0.0);
         int n_trac_lane = 0;
         Du3 cen_keep = dmk(du(0.0), du(0.0), du(0.0));
+        Du fold[9];      // FOLD: m1 (3), Q (6) about the value cop
+#pragma unroll
+        for (int k = 0; k < 9; ++k) fold[k] = du(0.0);
         if (n_poly >= 3) {
             const int n = n_poly;
             {
@@ -598,8 +686,13 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
             }
             const double er[4] = {tp->epsr[0], tp->epsr[1], tp->epsr[2], tp->epsr[3]};
             Du3 cop = dmk(du(0.0), du(0.0), du(0.0)), Da = cop, Dl = cop;
-            dual_integrate<0>([&](int k) { return PVT(k); }, n, nh, cen, er, it, g.d_twist + (size_t)key * 6, reg, cop, Da,
-                              Dl, sum, n_trac_lane, 0, n);
+            double c0[3] = {0.0, 0.0, 0.0};
+            if (FOLD && !reg) {
+                const double *vr = g.vres + (size_t)cw.item * kResStride + kResCop;
+                c0[0] = vr[0]; c0[1] = vr[1]; c0[2] = vr[2];
+            }
+            dual_integrate<0, FOLD>([&](int k) { return PVT(k); }, n, nh, cen, er, it, g.d_twist + (size_t)key * 6, reg, cop, Da,
+                                    Dl, sum, n_trac_lane, 0, n, c0, fold);
             cen_keep = cen;
 #undef PVT
         }
@@ -631,7 +724,22 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
         double flat[2 * NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) { flat[k] = sum[k].v; flat[NS + k] = sum[k].d; }
-        accumulate_items<2 * NS>(g.dacc, key, live, work && n_trac_lane > 0, flat, kDaA, kDaStride);
+        if constexpr (FOLD) dual_accumulate<2 * NS>(pd, g.dacc, key, live, work && n_trac_lane > 0, flat, kDaA, n_dir, lane);
+        else accumulate_items<2 * NS>(g.dacc, key, live, work && n_trac_lane > 0, flat, kDaA, kDaStride);
+        if constexpr (FOLD) {
+            // pass B's sums of this polygon, about c0 (a wave without a contributing bristle lane adds nothing)
+            const bool cb = work && n_trac_lane > 0 && !reg;
+            if (__ballot(cb) != 0) {
+                Du k21[21];
+#pragma unroll
+                for (int k = 0; k < 21; ++k) k21[k] = du(0.0);
+                dual_stiffness_entries(sum[6], fold, fold + 3, nh, k21);
+                double flat_b[42];
+#pragma unroll
+                for (int k = 0; k < 21; ++k) { flat_b[k] = k21[k].v; flat_b[21 + k] = k21[k].d; }
+                dual_accumulate<42>(pd, g.dacc, key, live, cb, flat_b, kDaB, n_dir, lane);
+            }
+        }
     }
 }
 #undef PV
@@ -641,6 +749,7 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
 // the kept Dual polygons: one lane per slot, coalesced loads, same fan / quadrature arithmetic as pass A.
 template <int MODE>
 __global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
+    __shared__ double red[MODE == 2 ? kDualRedRows * kDualRedStride : 1];
     const int lane = threadIdx.x;
     // the slots k_narrow_dual owns: 64 per group of 64 / n_dir contributing pairs (markers where no polygon was kept)
     int n_c = *g.scount;
@@ -698,7 +807,10 @@ __global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
         double flat[2 * NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) { flat[k] = sum[k].v; flat[NS + k] = sum[k].d; }
-        accumulate_items<2 * NS>(g.dacc, key, key >= 0, n_trac > 0, flat, MODE == 1 ? kDaB : kDaC, kDaStride);
+        // (pass B keeps the scans: with both forms in the kernel it would need more than 256 registers, and it only runs behind the
+        // fused small-scene kernel's hand-over and for tet-tet scenes now)
+        if (MODE == 2 && ts == 1) dual_accumulate<2 * NS>(red, g.dacc, key, key >= 0, n_trac > 0, flat, MODE == 1 ? kDaB : kDaC, g.n_dir, lane);
+        else accumulate_items<2 * NS>(g.dacc, key, key >= 0, n_trac > 0, flat, MODE == 1 ? kDaB : kDaC, kDaStride);
     }
 }
 
@@ -713,6 +825,7 @@ __global__ void __launch_bounds__(64) k_dual_eig(DualArgs g) {
     __shared__ double Kv[36], Kd[36], A[36], dK[36], V[36], T[36], M[36], KisV[36], KisD[36];
     __shared__ double SinvV[6], SinvD[6], f[6], fp[6], fx[6], lam[6];
     __shared__ int clamped[6];
+    __shared__ double copV[3], copD[3];
     const int key = blockIdx.x, lane = threadIdx.x;
     if (key >= g.n_items * g.n_dir) return;
     const int item = key / g.n_dir;
@@ -725,20 +838,51 @@ __global__ void __launch_bounds__(64) k_dual_eig(DualArgs g) {
         const Du ip = du(a[kDaA + 6], a[kDaA + 16]);
         const Du c = du(a[kDaA + 7 + lane], a[kDaA + 17 + lane]) / ip;
         res[kDrCop + lane] = c.v; res[kDrCop + 3 + lane] = c.d;
+        copV[lane] = c.v; copD[lane] = c.d;
     }
+    const bool fold = g.vres != nullptr;      // uniform
+    if (fold) wave_lds_sync();
     const bool ent = lane < 36;
     const int i = ent ? lane % 6 : 0, j = ent ? lane / 6 : 0;
     if (ent) {
         // K from the 21 sums of pass B: K11 (xx xy xz yy yz zz), K12 (9, column-major), K22 (6); K21 = K12'
-        const int u11[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+        // packed index of entry (r, c) of a symmetric 3 x 3 block (xx xy xz yy yz zz) -- arithmetic, not a table: a local array
+        // indexed by the lane lives in scratch memory
+        auto u11 = [](int r, int c) { const int lo = r < c ? r : c, hi = r < c ? c : r; return lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo); };
         const int bi = i % 3, bj = j % 3;
         int k;
-        if (i < 3 && j < 3) k = u11[bi][bj];
-        else if (i >= 3 && j >= 3) k = 15 + u11[bi][bj];
+        if (i < 3 && j < 3) k = u11(bi, bj);
+        else if (i >= 3 && j >= 3) k = 15 + u11(bi, bj);
         else if (i < 3) k = 6 + bi + 3 * bj;
         else k = 6 + bj + 3 * bi;
         const double *b = a + kDaB;
-        const Du kv = du(b[k], b[21 + k]) * it->k_bar;
+        Du kx = du(b[k], b[21 + k]);
+        if (fold && (i < 3 || j < 3)) {
+            // The sums were formed about c0 (the value pass's cop); about the Dual cop = c0 + d, with D = [d]x:
+            //   K22' = K22      K12' = K12 - D K22      K11' = K11 + K12 D + D' K12' + D' K22 D
+            // (x' = x - d in calc_patch_spatial_stiffness!, friction.jl:147-169; checked entry by entry against the three-pass form)
+            const double *c0 = g.vres + (size_t)item * kResStride + kResCop;
+            auto D = [&](int r, int c) -> Du {      // [d]x, d = cop - c0 (read from LDS / the result row by index: no private array)
+                if (r == c) return du(0.0);
+                const int m = 3 - r - c;
+                const Du x = du(copV[m] - c0[m], copD[m]);
+                return ((c - r + 3) % 3 == 1) ? -x : x;
+            };
+            auto K12 = [&](int r, int c) -> Du { return du(b[6 + r + 3 * c], b[21 + 6 + r + 3 * c]); };
+            auto K22 = [&](int r, int c) -> Du { return du(b[15 + u11(r, c)], b[21 + 15 + u11(r, c)]); };
+            if (i < 3 && j < 3) {
+                for (int m = 0; m < 3; ++m) {
+                    kx += K12(bi, m) * D(m, bj) + D(m, bi) * K12(bj, m);
+                    Du t = du(0.0);
+                    for (int l = 0; l < 3; ++l) t += K22(m, l) * D(l, bj);
+                    kx += D(m, bi) * t;
+                }
+            } else {
+                const int r = i < 3 ? bi : bj, c = i < 3 ? bj : bi;      // entry (r, c) of K12
+                for (int m = 0; m < 3; ++m) kx = kx - D(r, m) * K22(m, c);
+            }
+        }
+        const Du kv = kx * it->k_bar;
         Kv[lane] = kv.v; Kd[lane] = kv.d;
     }
     wave_lds_sync();

@@ -234,6 +234,7 @@ struct pfc_context {
     int pin_bp_n = 0;                    // items it holds (0: the last host-buffer Dual evaluation had none)
     bool team_owner = false;             // this handle holds its device's team slot (team_acquire)
     int opt_team_fault = -1;             // diagnostic option "team_fault": rank of every team that simulates a timed-out wait
+    int opt_dual_fold = 1;               // option "dual_fold": pass B of the Dual evaluation formed inside pass A (tri-tet scenes, batched value pass)
     int opt_fused_f32 = 1;               // option "fused_f32": single-precision SAT filter in the one-launch kernel (A/B knob; same results)
     std::string err;
     hipStream_t stream = nullptr;
@@ -1849,14 +1850,26 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
                            h->dual_sel.p, selcount);
         a.surv = h->dual_sel.p; a.scount = selcount;
     }
-    if (tt) hipLaunchKernelGGL((k_narrow_dual<true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
-    else hipLaunchKernelGGL((k_narrow_dual<false>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+    // Pass B folded into pass A wherever the value pass was the batched one (its cop is in h->res; DualArgs::vres) and the scene
+    // is tri-tet: one read of the kept polygons less.  (Option "dual_fold", default 1; PFC_NO_DUAL_FOLD=1 for A/B runs.)
+    static const bool no_fold = std::getenv("PFC_NO_DUAL_FOLD") != nullptr;
+    a.vres = (h->any_bristle && !pair_count && !no_fold && !tt && h->opt_dual_fold) ? h->res.p : nullptr;
+    if (a.vres) {
+        if (dual_pv_stride(n_dir) == 16) hipLaunchKernelGGL((k_narrow_dual<false, 16, true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+        else hipLaunchKernelGGL((k_narrow_dual<false, 64, true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+    } else if (dual_pv_stride(n_dir) == 16) {
+        if (tt) hipLaunchKernelGGL((k_narrow_dual<true, 16>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+        else hipLaunchKernelGGL((k_narrow_dual<false, 16>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+    } else {
+        if (tt) hipLaunchKernelGGL((k_narrow_dual<true, 64>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+        else hipLaunchKernelGGL((k_narrow_dual<false, 64>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+    }
     // a few dozen kept polygons only (pencil-scale pair: 116 -> 103 us per chunk): with more, the eightfold number of
     // waves costs more in per-key atomics on the same few rows than the shorter walk saves (single C3 pose: 97 -> 113 us)
     a.tri_split = (h->any_bristle && dpcap * 8 <= 16384) ? 1 : 0;
     if (h->any_bristle) {
         const int pgrid = grid_for(dpcap * (a.tri_split ? 8 : 1), 64, 256 * 16);
-        hipLaunchKernelGGL((k_dual_poly<1>), dim3(pgrid), dim3(64), 0, st, a);
+        if (!a.vres) hipLaunchKernelGGL((k_dual_poly<1>), dim3(pgrid), dim3(64), 0, st, a);
         hipLaunchKernelGGL(k_dual_eig, dim3((unsigned)nk), dim3(64), 0, st, a);   // one wave per (item, direction)
         hipLaunchKernelGGL((k_dual_poly<2>), dim3(pgrid), dim3(64), 0, st, a);
     }
@@ -2553,6 +2566,7 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "team")) h->opt_team = value < 0 ? 0 : (value > kTeamMaxWg ? kTeamMaxWg : (int)value);
     else if (!std::strcmp(name, "team_fault")) h->opt_team_fault = (int)value;
     else if (!std::strcmp(name, "fused_f32")) h->opt_fused_f32 = value != 0;
+    else if (!std::strcmp(name, "dual_fold")) { h->opt_dual_fold = value != 0; h->dghave = false; }
     else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;

@@ -1,6 +1,6 @@
-# The evidence set of a round in one GPU call: bash scripts/collect_round.sh [tag]   (default r03) -> gpurun_out/<tag>_*
+# The evidence set of a round in one GPU call: bash scripts/collect_round.sh [tag]   (default r04) -> gpurun_out/<tag>_*
 set -o pipefail
-T=${1:-r03}
+T=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
 timeout -k 10 600 python -m pytest tests -m gpu -q > $O/${T}_gputests.log 2>&1; echo "gpu tests rc=$?"; tail -2 $O/${T}_gputests.log
 timeout -k 10 300 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err; echo "bench rc=$?"
@@ -19,4 +19,8 @@ gcc -O2 -I include examples/box_on_plane.c -L pressurefieldcontact.jl_amd/csrc -
 (export PFC_LIB=$PWD/build/variants/stamps.so PFC_ALLOW_DIAGNOSTIC=1; for c in c1 c2 c4 c3r pencil c3; do timeout 120 python scripts/small_scene.py $c 300 1; done) 2>&1 | grep -v amdgpu > $O/${T}_fused_phases.txt
 (timeout 200 python scripts/lat_c3.py; timeout 300 python scripts/lat_c3_poses.py 48,32,24,16,0) 2>&1 | grep -v amdgpu > $O/${T}_team_sizes.txt
 timeout 200 python scripts/pencil_like.py 2>&1 | grep -v amdgpu > $O/${T}_pencil_like.txt
+bash scripts/profile_dual.sh $T > /dev/null 2>&1; echo "dual profile rc=$?"
+cd $R
+timeout 200 python scripts/ab_fused_f32.py 2>&1 | grep -v amdgpu > $O/${T}_ab_fused_f32.txt
+(for i in 1 2 3; do timeout 120 python scripts/dual_trace.py c5 40 6 4; PFC_NO_DUAL_FOLD=1 timeout 120 python scripts/dual_trace.py c5 40 6 4; done; timeout 120 python scripts/dual_trace.py c5 40 6 0; timeout 200 python scripts/dual_trace.py c3b 5 6 2; PFC_NO_DUAL_FOLD=1 timeout 200 python scripts/dual_trace.py c3b 5 6 2) 2>&1 | grep -v amdgpu > $O/${T}_dual_fold.txt
 echo collected

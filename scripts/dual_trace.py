@@ -1,5 +1,5 @@
 """Diagnostic: N device-resident Dual evaluations (pfc_eval_dual_device) of one config, for a rocprofv3 kernel trace.
-usage: dual_trace.py <c1|c2|c4|c5|c3> [n_evals] [n_dir] [more]      (more: that many further chunks (pfc_eval_dual_device_more) after each evaluation)"""
+usage: dual_trace.py <c1|c2|c4|c5|c3|c3b> [n_evals] [n_dir] [more]      (more: that many further chunks (pfc_eval_dual_device_more) after each evaluation)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, pfc_pkg
@@ -9,7 +9,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 nd = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 more = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 w = {"c1": pfc.configs.c1_boxes, "c2": lambda: pfc.configs.c2_box_on_plane(1), "c3": lambda: pfc.configs.c3_blob_tool(1),
-     "c4": lambda: pfc.configs.c2_box_on_plane(256, montecarlo=True), "c5": pfc.configs.c5_pile}[cfg]()
+     "c4": lambda: pfc.configs.c2_box_on_plane(256, montecarlo=True), "c5": pfc.configs.c5_pile,
+     "c3b": lambda: pfc.configs.c3_blob_tool(2048)}[cfg]()
 m = pfc.configs.build_scenario(w)
 dev = torch.device("cuda", 0)
 T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)

@@ -702,3 +702,29 @@ def test_host_chunk_cache_is_tied_to_its_value_pass(pfc):
     same(f.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *sd3, w.ins_ids), got3)
     f.close()
     m.close()
+
+
+def test_pass_b_folded_into_pass_a_equals_the_three_pass_form(pfc):
+    """Option dual_fold (default 1, tri-tet scenes on the batched value pass): the 21 patch-stiffness sums are formed in pass A about
+    the VALUE pass's cop and moved to the Dual cop per key by the parallel-axis rule (k_dual_eig) instead of in a pass of their
+    own over the kept polygons.  Same partials as the three-pass form (option 0) -- on a batch big enough for the batched path,
+    first chunk and a further chunk; items whose scaled stiffness has a rounding-level eigenvalue excepted."""
+    w = pfc.configs.c3_blob_tool(700, seed=11, n_div_blob=6, n_div_tool=4)
+    rng = np.random.default_rng(3)
+    n, nd = w.n_items, 6
+    dp = rng.standard_normal((n, nd, 24)) * 1e-3; dt = rng.standard_normal((n, nd, 6)) * 1e-2; ds = rng.standard_normal((n, nd, 6)) * 1e-4
+    out = {}
+    for fold in (1, 0):
+        m = pfc.configs.build_scenario(w)
+        m.set_option("dual_fold", fold)
+        a = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, dp, dt, ds, w.ins_ids)
+        b = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, dp * 2.0, dt, ds, w.ins_ids)
+        assert m.last_dual_reused() and m.last_parts() != 0
+        out[fold] = (a, b)
+        m.close()
+    for x, y in zip(out[1], out[0]):
+        assert np.array_equal(x[4], y[4])
+        sw = np.abs(y[2]).max(axis=(1, 2), keepdims=True) + 1e-300
+        ss = np.abs(y[3]).max(axis=(1, 2), keepdims=True) + 1e-300
+        okw = (np.abs(x[2] - y[2]) <= 1e-8 * sw).all(axis=(1, 2)); oks = (np.abs(x[3] - y[3]) <= 1e-6 * ss).all(axis=(1, 2))
+        assert okw.mean() > 0.99 and oks.mean() > 0.98, (okw.mean(), oks.mean())

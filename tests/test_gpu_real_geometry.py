@@ -39,7 +39,8 @@ def test_spoon_and_pencil_against_finger_pads(pfc, method):
     for k, r in enumerate(ref):
         if r.counts[3] > 0:
             assert H.rel_err(a[0][k], r.wrench) < (1e-9 if r.counts[3] >= 200 else 1e-7), k
-            assert H.rel_err(a[1][k], r.sdot) < 1e-6 or H.rel_err(a[1][k], sdot[k]) < 1e-3, k      # (the same items as above)
+            # (the items the 1e-3 rule applied to above -- patches with two or more rounding-level eigenvalues -- get it here too)
+            assert H.rel_err(a[1][k], r.sdot) < (1e-6 if H.rel_err(sdot[k], r.sdot) < 1e-6 else 2e-3), k
     m.close()
 
 
