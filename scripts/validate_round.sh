@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round parity at scale with the final kernels -> gpurun_out/<tag>_validation.txt   (bash scripts/validate_round.sh [tag])
-T=${1:-r03}
+T=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R
 O=$R/gpurun_out/${T}_validation.txt
 line() { python -c "
