@@ -71,12 +71,12 @@ class PFCError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile csrc/pfc_hip.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("pfc_hip.hip", "pfc_tree.cpp", "pfc_kernels.h", "pfc_bp.h", "pfc_np.h", "pfc_br.h", "pfc_dual.h", "pfc_fused.h", "pfc_clip.h", "pfc_multi.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("pfc_hip.hip", "pfc_tree.cpp", "pfc_sort.hip", "pfc_kernels.h", "pfc_bp.h", "pfc_np.h", "pfc_br.h", "pfc_dual.h", "pfc_fused.h", "pfc_clip.h", "pfc_multi.h", "pfc_sort.h")]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "pfc.h"))
     srcs.append(os.path.abspath(__file__))      # the compiler flags live here
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
-        cmd = [HIPCC] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0], srcs[1]]
+        cmd = [HIPCC] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0], srcs[1], srcs[2]]
         subprocess.run(cmd, check=True, cwd=CSRC)
     return LIB_PATH
 

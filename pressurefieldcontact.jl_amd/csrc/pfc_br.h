@@ -113,6 +113,94 @@ __global__ void __launch_bounds__(64) k_shift(ShiftArgs g) {
     }
 }
 
+// ---- option "fixed_order": an item's run records added in CHUNK ORDER ----------------------------------------------------
+// k_integ_fixed leaves one record per (chunk, item) run -- the ten sums, and for a bristle run the 27 moments about the run's
+// reference point -- in a list per item; with the candidate list sorted (pfc_sort.hip) the runs and their values are the same in
+// every evaluation of the same inputs, and so is the result of adding them in the order of their chunks: one wave per item, no
+// atomic.  The chunks of an item are consecutive (its candidates are), so chunk - first chunk indexes a table.
+constexpr int kFixedSpan = 4096;      // chunks one item may span (x 512 candidates)
+struct FixedArgs {
+    const double *rec;
+    int *det;            // per item: last record, first chunk, last chunk
+    int n_items;
+    int n_slots;         // record slots in all (kRgn x rr_cap)
+    const ItemRec *items;
+    double *acc;
+    unsigned *status;
+};
+__global__ void __launch_bounds__(256) k_fixed_init(int n_items, int *det) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_items) { det[3 * (size_t)i] = -1; det[3 * (size_t)i + 1] = 0x7FFFFFFF; det[3 * (size_t)i + 2] = -1; }
+}
+__global__ void __launch_bounds__(64) k_shift_fixed(FixedArgs g) {
+    __shared__ int tab[kFixedSpan];
+    __shared__ double stage[64 * 28];
+    const int item = blockIdx.x, lane = threadIdx.x;
+    if (item >= g.n_items) return;
+    const int head = g.det[3 * (size_t)item], ch0 = g.det[3 * (size_t)item + 1], ch1 = g.det[3 * (size_t)item + 2];
+    if (head < 0 || ch1 < ch0) return;      // no run with a traction point
+    const int span = ch1 - ch0 + 1;
+    if (span > kFixedSpan) {
+        if (lane == 0) atomicOr(g.status, kStFixedSpan);
+        return;
+    }
+    for (int k = lane; k < span; k += 64) tab[k] = -1;
+    wave_lds_sync();
+    if (lane == 0) {
+        // (the list is as long as the item has runs; the guard bounds the walk should a slot ever hold something else)
+        int guard = 0;
+        for (int s = head; s >= 0 && s < g.n_slots && guard <= span; ++guard) {
+            const double *r = g.rec + (size_t)s * kRecStrideFixed;
+            const int k = (int)r[kRecChunk] - ch0;
+            if (k >= 0 && k < span && (int)r[0] == item) tab[k] = s;
+            s = (int)r[kRecNext];
+        }
+    }
+    wave_lds_sync();
+    // (1) the ten sums, chunk by chunk: 64 records fetched at a time (lane l: record l of the window), added in order by lane k
+    double t10 = 0.0;
+    for (int w0 = 0; w0 < span; w0 += 64) {
+        const int s = (w0 + lane < span) ? tab[w0 + lane] : -1;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) stage[lane * 11 + k] = s >= 0 ? g.rec[(size_t)s * kRecStrideFixed + kRecTen + k] : 0.0;
+        wave_lds_sync();
+        const int n_here = span - w0 < 64 ? span - w0 : 64;
+        if (lane < 10)
+            for (int q = 0; q < n_here; ++q) t10 += stage[q * 11 + lane];
+        wave_lds_sync();
+    }
+    double *a = g.acc + (size_t)item * kAccStride;
+    if (lane < 10) a[lane] = t10;
+    if (g.items[item].model != PFC_BRISTLE) return;
+    // (2) the moments, each record moved from its reference point to the cop (k_shift's arithmetic), added in chunk order
+    const double S = __shfl(t10, kAccIp, 64);
+    if (!(S > 0.0)) return;
+    const double cx = __shfl(t10, kAccIpc, 64) / S, cy = __shfl(t10, kAccIpc + 1, 64) / S, cz = __shfl(t10, kAccIpc + 2, 64) / S;
+    double m = 0.0;
+    for (int w0 = 0; w0 < span; w0 += 64) {
+        const int s = (w0 + lane < span) ? tab[w0 + lane] : -1;
+        bool live = false;
+        if (s >= 0) {
+            const double *r = g.rec + (size_t)s * kRecStrideFixed;
+            const double W = r[1];
+            if (W > 0.0) {
+                const double d[3] = {r[2] - cx, r[3] - cy, r[4] - cz};
+                const double m1[3] = {r[32], r[33], r[34]};
+                shift_moments(r + 5, W, m1, d, stage + lane * 28);
+                live = true;
+            }
+        }
+        if (!live)
+            for (int k = 0; k < 27; ++k) stage[lane * 28 + k] = 0.0;
+        wave_lds_sync();
+        const int n_here = span - w0 < 64 ? span - w0 : 64;
+        if (lane < 27)
+            for (int q = 0; q < n_here; ++q) m += stage[q * 28 + lane];
+        wave_lds_sync();
+    }
+    if (lane < 27) a[kAccSnn + lane] = m;
+}
+
 // Jacobi eigen-solver for a symmetric 6x6 (stands in for LAPACK eigen!(Hermitian), friction.jl:88): rotation angle of
 // one pivot, then the wave-cooperative round-robin iteration.
 __device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq, double &cs, double &sn) {

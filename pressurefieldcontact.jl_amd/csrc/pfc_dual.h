@@ -145,6 +145,18 @@ struct DualArgs {
     // k_dual_poly<1> and its read of every kept polygon are not launched.  Null (hand-over from the fused small-scene
     // kernel, which keeps its cop in LDS): three passes as before.
     const double *vres;
+    // Option "fixed_order": the value pass's result rows again (cop, K).  Non-null: k_dual_eig takes the VALUE of the cop and of
+    // K from them -- the same numbers for every direction and every chunk of a Jacobian (src/radau/radau_functions.jl:2-14), summed
+    // in a fixed order by the value pass -- and only the partials from the Dual sums, whose own value parts are the same quantities
+    // summed in another, run-dependent order.  Where decompose_K! clamps an eigenvalue that is zero up to rounding (a flat patch,
+    // friction.jl:92) the last bits of K decide the branch: this way they decide it once per item and evaluation.
+    const double *vres_k;
+    // ... and the sums that feed the eigen-decomposition -- pass A's (cop) and pass B's (patch stiffness) -- leave the passes as
+    // records (FixedSink, pfc_np.h) that k_fixed_reduce adds per key in the order of the waves' positions in the contributing-pair
+    // list, which pfc_sort.hip has sorted: the partials of K are then the same numbers in every evaluation of the same inputs
+    // too.  Pass C's six friction sums go the same way (sink_c): nothing amplifies their last bits, but with them every output of
+    // the evaluation is the same bit pattern in every run.
+    FixedSink sink_a, sink_b, sink_c;
 };
 constexpr int kDpFields = 64;
 
@@ -330,19 +342,26 @@ __host__ inline size_t dual_lds_bytes(int n_dir) { return sizeof(double) * (size
 // the atomic: ~6 N instructions per wave instead of the ~30 N of N segmented scans (accumulate_items, the fallback for a
 // wave that straddles items).  buf: 21 x 65 doubles (row stride 65: the row walk of consecutive lanes is conflict-free).
 constexpr int kDualRedRows = 21, kDualRedStride = 65;
-template <int N>
+template <int N, bool FX = false>
 __device__ __forceinline__ void dual_accumulate(double *buf, double *acc, int key, bool listed, bool any, const double *v, int n0,
-                                                int n_dir, int lane) {
+                                                int n_dir, int lane, const FixedSink *fx = nullptr, int order = 0) {
     const unsigned long long am = __ballot(any);
     if (am == 0) return;
     const int item = key >= 0 ? key / n_dir : -1;
     const int item0 = __builtin_amdgcn_readlane(item, __builtin_ctzll(am));
     if (__ballot(any && item != item0) != 0) {      // uniform
-        accumulate_items<N>(acc, key, listed, any, v, n0, kDaStride);
+        accumulate_items<N, FX>(acc, key, listed, any, v, n0, kDaStride, fx, order);
         return;
     }
     const int cpw = 64 / n_dir;
     constexpr int R = (N + kDualRedRows - 1) / kDualRedRows, NB = (N + R - 1) / R;
+    int slot0 = 0;
+    bool room = true;
+    if constexpr (FX) {      // one record per direction of the wave's item (see accumulate_items)
+        if (lane == 0) slot0 = atomicAdd(fx->count, n_dir);
+        slot0 = __builtin_amdgcn_readfirstlane(slot0);
+        room = slot0 + n_dir <= fx->cap;      // (no room: see accumulate_items)
+    }
     wave_lds_sync();      // (the buffer may be the polygon ring the lanes have just read)
 #pragma unroll
     for (int rd = 0; rd < R; ++rd) {
@@ -357,9 +376,20 @@ __device__ __forceinline__ void dual_accumulate(double *buf, double *acc, int ke
             const double *row = buf + j * kDualRedStride + d * cpw;
             double x = 0.0;
             for (int c = 0; c < cpw; ++c) x += row[c];
+            if constexpr (FX) {
+                if (room) fx->rec[(size_t)(slot0 + d) * kSinkStride + kSinkHdr + base + j] = x;
+            } else {
             if (x != 0.0) unsafeAtomicAdd(&acc[(size_t)(item0 * n_dir + d) * kDaStride + n0 + base + j], x);
+            }
         }
         wave_lds_sync();
+    }
+    if constexpr (FX) {
+        if (room && lane < n_dir) {
+            double *r = fx->rec + (size_t)(slot0 + lane) * kSinkStride;
+            const int k = item0 * n_dir + lane;
+            r[0] = (double)k; r[1] = (double)order; r[2] = (double)atomicExch(&fx->head[k], slot0 + lane);
+        }
     }
 }
 
@@ -436,7 +466,7 @@ __global__ void __launch_bounds__(256) k_dual_select(DualArgs g, const int *flag
 // PVS: the column stride of the shared value ring, dual_pv_stride(n_dir), as a compile-time constant: with a run-time stride every
 // ring slot the code names -- (slot, coordinate) pairs with rbase = 0 -- became a loop-invariant address in a register of its
 // own, and those registers were what the tet-tet instantiation spilled (round 3: 15 VGPRs + 64 bytes of scratch per lane).
-template <bool TT, int PVS, bool FOLD = false>
+template <bool TT, int PVS, bool FOLD = false, bool FX = false>
 __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
     extern __shared__ double dual_lds[];     // dual_lds_bytes(n_dir): partial ring (16 KiB), then the value ring
     double *pd = dual_lds, *pv = dual_lds + 8 * 4 * 64;
@@ -724,8 +754,8 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
         double flat[2 * NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) { flat[k] = sum[k].v; flat[NS + k] = sum[k].d; }
-        if constexpr (FOLD) dual_accumulate<2 * NS>(pd, g.dacc, key, live, work && n_trac_lane > 0, flat, kDaA, n_dir, lane);
-        else accumulate_items<2 * NS>(g.dacc, key, live, work && n_trac_lane > 0, flat, kDaA, kDaStride);
+        if constexpr (FOLD) dual_accumulate<2 * NS, FX>(pd, g.dacc, key, live, work && n_trac_lane > 0, flat, kDaA, n_dir, lane, &g.sink_a, grp);
+        else accumulate_items<2 * NS, FX>(g.dacc, key, live, work && n_trac_lane > 0, flat, kDaA, kDaStride, &g.sink_a, grp);
         if constexpr (FOLD) {
             // pass B's sums of this polygon, about c0 (a wave without a contributing bristle lane adds nothing)
             const bool cb = work && n_trac_lane > 0 && !reg;
@@ -737,7 +767,7 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
                 double flat_b[42];
 #pragma unroll
                 for (int k = 0; k < 21; ++k) { flat_b[k] = k21[k].v; flat_b[21 + k] = k21[k].d; }
-                dual_accumulate<42>(pd, g.dacc, key, live, cb, flat_b, kDaB, n_dir, lane);
+                dual_accumulate<42, FX>(pd, g.dacc, key, live, cb, flat_b, kDaB, n_dir, lane, &g.sink_b, grp);
             }
         }
     }
@@ -747,7 +777,7 @@ __global__ void __launch_bounds__(64, 2) k_narrow_dual(DualArgs g) {
 
 // Passes B (MODE 1: calc_patch_spatial_stiffness! about the Dual cop) and C (MODE 2: calc_spatial_bristle_force) over
 // the kept Dual polygons: one lane per slot, coalesced loads, same fan / quadrature arithmetic as pass A.
-template <int MODE>
+template <int MODE, bool FX = false>
 __global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
     __shared__ double red[MODE == 2 ? kDualRedRows * kDualRedStride : 1];
     const int lane = threadIdx.x;
@@ -809,8 +839,46 @@ __global__ void __launch_bounds__(64) k_dual_poly(DualArgs g) {
         for (int k = 0; k < NS; ++k) { flat[k] = sum[k].v; flat[NS + k] = sum[k].d; }
         // (pass B keeps the scans: with both forms in the kernel it would need more than 256 registers, and it only runs behind the
         // fused small-scene kernel's hand-over and for tet-tet scenes now)
-        if (MODE == 2 && ts == 1) dual_accumulate<2 * NS>(red, g.dacc, key, key >= 0, n_trac > 0, flat, MODE == 1 ? kDaB : kDaC, g.n_dir, lane);
-        else accumulate_items<2 * NS>(g.dacc, key, key >= 0, n_trac > 0, flat, MODE == 1 ? kDaB : kDaC, kDaStride);
+        if (MODE == 2 && ts == 1) dual_accumulate<2 * NS, FX>(red, g.dacc, key, key >= 0, n_trac > 0, flat, MODE == 1 ? kDaB : kDaC, g.n_dir, lane, &g.sink_c, (int)(idx0 >> 6));
+        else accumulate_items<2 * NS, FX>(g.dacc, key, key >= 0, n_trac > 0, flat, MODE == 1 ? kDaB : kDaC, kDaStride, MODE == 1 ? &g.sink_b : &g.sink_c,
+                                          (int)(idx0 >> 6));
+    }
+}
+
+// Option "fixed_order": the records of one accumulator block (pass A's 20 numbers at kDaA, pass B's 42 at kDaB) added per key in
+// the order of the positions they carry.  One wave per key; a key's records are as many as waves of the pass held pairs of its item.
+// (Also the value pass's friction sums: key = item, accumulator rows of kAccStride.)
+constexpr int kSinkSpan = 2048;
+__global__ void __launch_bounds__(64) k_fixed_reduce(FixedSink fx, int n_keys, double *dacc, int stride, int n0, int n_val) {
+    __shared__ int ord[kSinkSpan], slt[kSinkSpan], perm[kSinkSpan];
+    const int key = blockIdx.x, lane = threadIdx.x;
+    if (key >= n_keys) return;
+    const int head = fx.head[key];
+    if (head < 0) return;
+    int n_rec = *fx.count;
+    if (n_rec > fx.cap) n_rec = fx.cap;
+    int n = 0;
+    if (lane == 0) {
+        for (int s = head; s >= 0 && s < n_rec && n < kSinkSpan; ++n) {
+            const double *r = fx.rec + (size_t)s * kSinkStride;
+            ord[n] = (int)r[1]; slt[n] = s;
+            s = (int)r[2];
+            if (n + 1 == kSinkSpan && s >= 0) atomicOr(fx.status, kStFixedList);
+        }
+    }
+    n = __builtin_amdgcn_readfirstlane(n);
+    wave_lds_sync();
+    for (int i = lane; i < n; i += 64) {      // positions are distinct (one record per wave and key): the rank is a permutation
+        int rank = 0;
+        const int oi = ord[i];
+        for (int j = 0; j < n; ++j) rank += (ord[j] < oi || (ord[j] == oi && j < i)) ? 1 : 0;
+        perm[rank] = slt[i];
+    }
+    wave_lds_sync();
+    if (lane < n_val) {
+        double t = 0.0;
+        for (int q = 0; q < n; ++q) t += fx.rec[(size_t)perm[q] * kSinkStride + kSinkHdr + lane];
+        dacc[(size_t)key * stride + n0 + lane] = t;
     }
 }
 
@@ -834,9 +902,11 @@ __global__ void __launch_bounds__(64) k_dual_eig(DualArgs g) {
     if (!seed_nonzero_wave(g, key, lane)) return;      // zero seeds: the passes kept nothing for this key, k_dual_final writes zeros
     const double *a = g.dacc + (size_t)key * kDaStride;
     double *res = g.dres + (size_t)key * kDrStride;
+    const double *vk = g.vres_k ? g.vres_k + (size_t)item * kResStride : nullptr;      // uniform
     if (lane < 3) {
         const Du ip = du(a[kDaA + 6], a[kDaA + 16]);
-        const Du c = du(a[kDaA + 7 + lane], a[kDaA + 17 + lane]) / ip;
+        Du c = du(a[kDaA + 7 + lane], a[kDaA + 17 + lane]) / ip;
+        if (vk) c.v = vk[kResCop + lane];
         res[kDrCop + lane] = c.v; res[kDrCop + 3 + lane] = c.d;
         copV[lane] = c.v; copD[lane] = c.d;
     }
@@ -883,7 +953,7 @@ __global__ void __launch_bounds__(64) k_dual_eig(DualArgs g) {
             }
         }
         const Du kv = kx * it->k_bar;
-        Kv[lane] = kv.v; Kd[lane] = kv.d;
+        Kv[lane] = vk ? vk[kResK + lane] : kv.v; Kd[lane] = kv.d;
     }
     wave_lds_sync();
     if (lane < 6) {

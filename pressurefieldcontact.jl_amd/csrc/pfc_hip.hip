@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/pfc.h"
+#include "pfc_sort.h"
 
 namespace pfc {
 
@@ -372,6 +373,20 @@ struct pfc_context {
     int *fout_dev = nullptr;           // set by pfc_eval: the kernel writes its per-item block straight into pinned host memory
     const int *fout_host = nullptr;    //   ... and this is where the host reads it
     int opt_fused = 1;                 // option "fused"
+    // option "fixed_order": the candidate list sorted (pfc_sort.hip), an item's run records added in chunk order (k_integ_fixed,
+    // k_shift_fixed), the Dual passes' eigen-decomposition on the value pass's K -- batched path only, no graph, no split
+    int opt_fixed_order = 0;
+    int fixed_saved[3] = {1, 1025, 1};        // fused, split_min, graph as they were before the option went on
+    DevBuf<int> det;                          // per item: last record, first chunk, last chunk
+    DevBuf<unsigned long long> sort_keys[2];
+    DevBuf<char> sort_tmp;
+    size_t sort_tmp_for = 0;                  // (capacity, bits) the temporary storage was sized for
+    int sort_tmp_bits = 0;
+    int max_elem1 = 1, max_elem2 = 1;         // most elements of a mesh on side 1 / side 2 of an instruction
+    DevBuf<double> fx_rec, vfx_rec;           // records of the Dual passes' sums / of the value pass's friction sums (FixedSink)
+    DevBuf<int> vfx_head;
+    DevBuf<int> fx_head;                      // per key and accumulator block: last record; then the record counter
+    long long surv_sorted_serial = -1;        // value pass whose list of contributing pairs has been sorted
     int opt_clip_queue = 1;            // option "clip_queue": clip-only narrowphase of big tri-tet batches in k_clip_queue (survivors queued in the ring); 0: k_narrow<.., 2 / 3>
     int fused_skip = 0;                // evaluations left for which the fused kernel stays off after an item did not fit
     int fused_seq = 0;                 // sequence number of the last fused launch (completion word of the polled path)
@@ -492,7 +507,22 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     size_t rc = h->rcap ? h->rcap : 1u << 12;
     while (rc < c / 32 + (size_t)n_items * 2) rc *= 2;   // about one record per wave round and item boundary
     h->fcap = f; h->ccap = c; h->tcap = t; h->rcap = rc;
-    if ((e = h->rec.ensure(rc * kRecStride)) != hipSuccess) return e;
+    if ((e = h->rec.ensure(rc * (h->opt_fixed_order ? kRecStrideFixed : kRecStride))) != hipSuccess) return e;
+    if (h->opt_fixed_order) {
+        if ((e = h->det.ensure((size_t)n_items * 3)) != hipSuccess) return e;
+        if ((e = h->vfx_rec.ensure((c / 32 + (size_t)n_items + 64) * kSinkStride)) != hipSuccess) return e;
+        if ((e = h->vfx_head.ensure((size_t)n_items + 2)) != hipSuccess) return e;
+        if ((e = h->sort_keys[0].ensure(c)) != hipSuccess) return e;
+        if ((e = h->sort_keys[1].ensure(c)) != hipSuccess) return e;
+        int ba, bb;
+        const int bits = pfc_sort_key_bits(n_items, h->max_elem1, h->max_elem2, &ba, &bb);
+        if (h->sort_tmp_for != c || h->sort_tmp_bits != bits) {
+            size_t bytes = 0;
+            if ((e = pfc_sort_temp_bytes(c, bits > 64 ? 64 : bits, &bytes)) != hipSuccess) return e;      // (covers the index sort too)
+            if ((e = h->sort_tmp.ensure(bytes ? bytes : 1)) != hipSuccess) return e;
+            h->sort_tmp_for = c; h->sort_tmp_bits = bits;
+        }
+    }
     if ((e = h->frontier[0].ensure(f)) != hipSuccess) return e;
     if ((e = h->frontier[1].ensure(f)) != hipSuccess) return e;
     if ((e = h->cand.ensure(c)) != hipSuccess) return e;
@@ -669,6 +699,15 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     }
     if (h->bp_dev)      // the broadphase ran on a pose of its own: the item records get the evaluation's x_r1_r2 back
         hipLaunchKernelGGL(k_repose, dim3(grid_for(n_items, 64, 1 << 20)), dim3(64), 0, st, n_items, d_pose, h->items.p);
+    if (h->opt_fixed_order) {
+        int ba, bb;
+        const int bits = pfc_sort_key_bits(n_items, h->max_elem1, h->max_elem2, &ba, &bb);
+        if (bits > 64)
+            return fail(h, PFC_ERR_BAD_ARG, "option fixed_order: (item, element, element) needs %d key bits for %d items, more than 64", bits, n_items);
+        HIP_TRY(h, pfc_sort_candidates(h->cand.p, ccount, h->ccap, h->sort_keys[0].p, h->sort_keys[1].p, h->sort_tmp.p, h->sort_tmp.cap,
+                                       n_items, ba, bb, bits, st));
+        hipLaunchKernelGGL(k_fixed_init, dim3(grid_for(n_items, 256, 1 << 20)), dim3(256), 0, st, n_items, h->det.p);
+    }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));
 
     NpArgs np;
@@ -681,7 +720,8 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     np.pcnt = h->pcnt.p; np.chunk_switch = kNpChunkSwitch; np.poly_cand = h->want_surv ? h->poly_cand.p : nullptr;
     np.surv = h->want_surv ? h->surv.p : nullptr; np.scount = pcount + 1;
     const int np_grid = grid_for(h->ccap, kNpBlock, kNpMaxBlocks);
-    const int np_mode = h->opt_debug ? 1 : ((h->opt_clip_min > 0 && n_items >= h->opt_clip_min) ? 2 : 0);
+    // (fixed_order: always the clip-only kernel + k_integ_fixed, whose run records carry every sum)
+    const int np_mode = h->opt_debug ? 1 : ((h->opt_fixed_order || (h->opt_clip_min > 0 && n_items >= h->opt_clip_min)) ? 2 : 0);
     if (np_mode == 1) {
         if (h->any_tet_tet) hipLaunchKernelGGL((k_narrow<true, 1>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
         else hipLaunchKernelGGL((k_narrow<false, 1>), dim3(np_grid), dim3(kNpBlock), 0, st, np);
@@ -711,7 +751,9 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         ig.pcnt = h->pcnt.p; ig.poly_item = h->poly_item.p; ig.poly = h->poly.p; ig.pcap = np.pcap;
         ig.poly_cand = np.poly_cand; ig.surv = np.surv; ig.scount = np.scount; ig.acc = h->acc.p; ig.rec = h->rec.p;
         ig.rgn = h->rgn.p; ig.rr_cap = np.rr_cap; ig.icnt = h->icnt.p; ig.status = h->status.p;
-        hipLaunchKernelGGL(k_integ, dim3(grid_for(h->ccap, 64, kNpMaxBlocks)), dim3(64), 0, st, ig);
+        ig.det = h->opt_fixed_order ? h->det.p : nullptr;
+        if (h->opt_fixed_order) hipLaunchKernelGGL(k_integ_fixed, dim3(grid_for(h->ccap, 64, kNpMaxBlocks)), dim3(64), 0, st, ig);
+        else hipLaunchKernelGGL(k_integ, dim3(grid_for(h->ccap, 64, kNpMaxBlocks)), dim3(64), 0, st, ig);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_NP], st));
 
@@ -721,18 +763,36 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
     br.counts = d_counts;
     br.ctr = h->ctr.p; br.n_ctr = levels + 12; br.status = h->status.p; br.tail = h->tail_dev ? h->tail_dev : h->tail.p;
     br.rgn = h->rgn.p; br.i_pcount = (levels + 9) & ~1;
+    if (h->opt_fixed_order && np_mode == 2) {
+        FixedArgs fx;
+        fx.rec = h->rec.p; fx.det = h->det.p; fx.n_items = n_items; fx.n_slots = (int)(h->rcap / kRgn) * kRgn; fx.items = h->items.p;
+        fx.acc = h->acc.p; fx.status = h->status.p;
+        hipLaunchKernelGGL(k_shift_fixed, dim3(n_items), dim3(64), 0, st, fx);      // one wave per item
+    }
     if (h->any_bristle) {
         ShiftArgs sh;
         sh.rec = h->rec.p; sh.rgn = h->rgn.p; sh.rr_cap = (int)(h->rcap / kRgn); sh.acc = h->acc.p;
-        hipLaunchKernelGGL(k_shift, dim3(grid_for(h->rcap, 64, 2048)), dim3(64), 0, st, sh);
+        if (!(h->opt_fixed_order && np_mode == 2)) hipLaunchKernelGGL(k_shift, dim3(grid_for(h->rcap, 64, 2048)), dim3(64), 0, st, sh);
         hipLaunchKernelGGL(k_eig, dim3(n_items), dim3(64), 0, st, br);   // one wave per item
         FricArgs fr;
         fr.items = h->items.p; fr.poly_item = h->poly_item.p; fr.poly = h->poly.p; fr.ccount = ccount; fr.ccap = (int)h->ccap;
         fr.chunk_switch = kNpChunkSwitch; fr.pcnt = h->pcnt.p;
         fr.pcap = np.pcap; fr.res = h->res.p; fr.acc = h->acc.p;
         fr.n_items = n_items; fr.status = h->status.p;
+        fr.sink = FixedSink{nullptr, nullptr, nullptr, 0, nullptr};
+        if (h->opt_fixed_order && np_mode == 2) {
+            // records of the friction sums: one per (64-polygon piece, item) incidence -- fewer than pieces + items, and the pieces
+            // of the chunks are fewer than ccap / 64 + chunks
+            const size_t cap = h->ccap / 32 + (size_t)n_items + 64;      // (allocated by ensure_work)
+            HIP_TRY(h, hipMemsetAsync(h->vfx_head.p, 0xFF, sizeof(int) * (size_t)n_items, st));
+            HIP_TRY(h, hipMemsetAsync(h->vfx_head.p + n_items, 0, sizeof(int) * 2, st));
+            fr.sink = FixedSink{h->vfx_rec.p, h->vfx_head.p + n_items, h->vfx_head.p, (int)cap, h->status.p};
+        }
         // (grid cap 256 x 32, twice the other narrowphase kernels': paired A/B 4.32 -> 4.22 ms per 8 192-pose step; x 64 and x 128 alike)
-        hipLaunchKernelGGL(k_fric, dim3(grid_for(h->ccap, 64, 256 * 32)), dim3(64), 0, st, fr);
+        if (fr.sink.rec) {
+            hipLaunchKernelGGL(k_fric_fixed, dim3(grid_for(h->ccap, 64, 256 * 32)), dim3(64), 0, st, fr);
+            hipLaunchKernelGGL(k_fixed_reduce, dim3(n_items), dim3(64), 0, st, fr.sink, n_items, h->acc.p, kAccStride, kAccFric, 6);
+        } else hipLaunchKernelGGL(k_fric, dim3(grid_for(h->ccap, 64, 256 * 32)), dim3(64), 0, st, fr);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BR], st));
     hipLaunchKernelGGL(k_final, dim3(grid_for(n_items, 128, 1 << 20)), dim3(128), 0, st, br);
@@ -838,6 +898,9 @@ int check_one(pfc_context *h) {
     }
     if (status & kStAbort) return fail(h, PFC_ERR_STATE, "broadphase aborted: iteration guard hit (corrupt tree?)");
     if (status & kStPolyOvf) return fail(h, PFC_ERR_STATE, "internal error: a kept-polygon region overflowed");
+    if (status & (kStFixedSpan | kStFixedList))
+        return fail(h, PFC_ERR_STATE, "option fixed_order: the candidates of one item span more than %d chunks of 512, or one key has more than %d sum records (status %u): evaluate it without the option",
+                    kFixedSpan, kSinkSpan, status);
 
     if (status & kStNonFinite) return fail(h, PFC_ERR_NONFINITE, "Non-finite vertex likely");
     h->stats[0] = (long long)tot[0]; h->stats[2] = (long long)tot[1]; h->stats[3] = (long long)tot[2];
@@ -1077,7 +1140,7 @@ int make_twin(pfc_context *h) {
     if (!t) return fail(h, PFC_ERR_NOMEM, "out of host memory");
     t->device = h->device; t->is_twin = true; t->finalized = true;
     t->ins = h->ins; t->d_meshes = h->d_meshes; t->d_ins = h->d_ins; t->max_levels = h->max_levels;
-    t->max_leaves = h->max_leaves;
+    t->max_leaves = h->max_leaves; t->max_elem1 = h->max_elem1; t->max_elem2 = h->max_elem2;
     t->any_bristle = h->any_bristle; t->any_tet_tet = h->any_tet_tet; t->opt_split_min = 0;
     t->stream = h->twin_stream; h->twin_stream = nullptr;
     if ((!t->stream && hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) ||
@@ -1237,6 +1300,8 @@ void pfc_destroy(pfc_handle h) {
     h->fout.release(); h->team.release();
     h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
     h->clip_n.release(); h->icnt.release(); h->trac_item.release(); h->acc.release(); h->res.release();
+    h->fx_rec.release(); h->fx_head.release(); h->vfx_rec.release(); h->vfx_head.release();
+    h->det.release(); h->sort_keys[0].release(); h->sort_keys[1].release(); h->sort_tmp.release();
     h->trac_d.release(); h->rec.release(); h->ctr.release(); h->status.release(); h->stamps.release();
     h->h_pose.release();
     for (int k = 0; k < EV_COUNT; ++k)
@@ -1513,8 +1578,15 @@ int pfc_finalize(pfc_handle h) {
     }
     h->max_levels = 1;
     h->max_leaves = 2;
+    h->max_elem1 = h->max_elem2 = 1;
     h->any_bristle = false;
     for (const InsDev &in : h->ins) {
+        {   // (key widths of the candidate sort, option "fixed_order": a candidate is (element of mesh_1, tet of mesh_2))
+            const HostMesh &m1 = h->meshes[in.m1], &m2 = h->meshes[in.m2];
+            const int e1 = m1.n_tri ? m1.n_tri : m1.n_tet;
+            if (e1 > h->max_elem1) h->max_elem1 = e1;
+            if (m2.n_tet > h->max_elem2) h->max_elem2 = m2.n_tet;
+        }
         int lv = h->meshes[in.m1].depth + h->meshes[in.m2].depth + 1;
         if (lv > h->max_levels) h->max_levels = lv;
         const int lf = h->meshes[in.m1].n_leaf + h->meshes[in.m2].n_leaf;
@@ -1840,7 +1912,8 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     // lists below may have to be allocated; a captured chunk keeps the per-key skip only)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
-    if (!pair_count && n_items >= kDualSelectMin && cap == hipStreamCaptureStatusNone && std::getenv("PFC_NO_SELECT") == nullptr) {
+    // (nor under option fixed_order: the selected list is compacted block by block in the order the blocks come by)
+    if (!pair_count && n_items >= kDualSelectMin && cap == hipStreamCaptureStatusNone && !h->opt_fixed_order && std::getenv("PFC_NO_SELECT") == nullptr) {
         HIP_TRY(h, ensure_dual(h, h->dual_sel, h->ccap));
         HIP_TRY(h, ensure_dual(h, h->dual_flag, (size_t)n_items + 1));
         int *selcount = h->dual_flag.p + n_items;
@@ -1854,7 +1927,43 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     // is tri-tet: one read of the kept polygons less.  (Option "dual_fold", default 1; PFC_NO_DUAL_FOLD=1 for A/B runs.)
     static const bool no_fold = std::getenv("PFC_NO_DUAL_FOLD") != nullptr;
     a.vres = (h->any_bristle && !pair_count && !no_fold && !tt && h->opt_dual_fold) ? h->res.p : nullptr;
-    if (a.vres) {
+    // fixed_order: every key of an item decomposes the K of the VALUE pass (one clamp decision per item and evaluation)
+    a.vres_k = (h->opt_fixed_order && h->any_bristle && !pair_count) ? h->res.p : nullptr;
+    const bool fx = h->opt_fixed_order && !pair_count;
+    a.sink_a = FixedSink{nullptr, nullptr, nullptr, 0, nullptr};
+    a.sink_b = a.sink_a; a.sink_c = a.sink_a;
+    if (fx) {
+        // the contributing pairs in candidate order (k_integ_fixed appended them piece by piece as its workgroups came by) ...
+        if (h->surv_sorted_serial != h->value_serial) {
+            HIP_TRY(h, pfc_sort_indices(h->surv.p, a.scount, h->ccap, reinterpret_cast<unsigned *>(h->sort_keys[0].p),
+                                        reinterpret_cast<unsigned *>(h->sort_keys[1].p), h->sort_tmp.p, h->sort_tmp.cap, st));
+            h->surv_sorted_serial = h->value_serial;
+        }
+        // ... and the records of passes A and B: per accumulator block at most one per (wave, item, direction), and since an item's
+        // pairs are consecutive in the sorted list the (wave, item) incidences are fewer than waves + items
+        const size_t n_grp = (n_pairs_bound + cpw - 1) / cpw;
+        const size_t cap = 3 * (size_t)n_dir * (n_grp + (size_t)n_items) + 64;      // (three blocks: passes A, B, C)
+        if (cap > ((size_t)1 << 30)) return fail(h, PFC_ERR_NOMEM, "option fixed_order: %zu Dual sum records: evaluate the batch in parts", cap);
+        HIP_TRY(h, ensure_dual(h, h->fx_rec, cap * kSinkStride));
+        HIP_TRY(h, ensure_dual(h, h->fx_head, 3 * nk + 2));
+        HIP_TRY(h, hipMemsetAsync(h->fx_head.p, 0xFF, sizeof(int) * 3 * nk, st));
+        HIP_TRY(h, hipMemsetAsync(h->fx_head.p + 3 * nk, 0, sizeof(int) * 2, st));
+        a.sink_a = FixedSink{h->fx_rec.p, h->fx_head.p + 3 * nk, h->fx_head.p, (int)cap, a.status};
+        a.sink_b = FixedSink{h->fx_rec.p, h->fx_head.p + 3 * nk, h->fx_head.p + nk, (int)cap, a.status};
+        a.sink_c = FixedSink{h->fx_rec.p, h->fx_head.p + 3 * nk, h->fx_head.p + 2 * nk, (int)cap, a.status};
+        if (!tt) a.vres = h->res.p;      // tri-tet: always the folded pass (one kernel carries both blocks)
+    }
+    if (fx) {
+        if (tt) {
+            if (dual_pv_stride(n_dir) == 16) hipLaunchKernelGGL((k_narrow_dual<true, 16, false, true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+            else hipLaunchKernelGGL((k_narrow_dual<true, 64, false, true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+        } else {
+            if (dual_pv_stride(n_dir) == 16) hipLaunchKernelGGL((k_narrow_dual<false, 16, true, true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+            else hipLaunchKernelGGL((k_narrow_dual<false, 64, true, true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
+        }
+        hipLaunchKernelGGL(k_fixed_reduce, dim3((unsigned)nk), dim3(64), 0, st, a.sink_a, (int)nk, h->dual_acc.p, kDaStride, kDaA, 20);
+        if (!tt) hipLaunchKernelGGL(k_fixed_reduce, dim3((unsigned)nk), dim3(64), 0, st, a.sink_b, (int)nk, h->dual_acc.p, kDaStride, kDaB, 42);
+    } else if (a.vres) {
         if (dual_pv_stride(n_dir) == 16) hipLaunchKernelGGL((k_narrow_dual<false, 16, true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
         else hipLaunchKernelGGL((k_narrow_dual<false, 64, true>), dim3(grid), dim3(64), dual_lds_bytes(n_dir), st, a);
     } else if (dual_pv_stride(n_dir) == 16) {
@@ -1866,12 +1975,18 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     }
     // a few dozen kept polygons only (pencil-scale pair: 116 -> 103 us per chunk): with more, the eightfold number of
     // waves costs more in per-key atomics on the same few rows than the shorter walk saves (single C3 pose: 97 -> 113 us)
-    a.tri_split = (h->any_bristle && dpcap * 8 <= 16384) ? 1 : 0;
+    a.tri_split = (h->any_bristle && dpcap * 8 <= 16384 && !fx) ? 1 : 0;
     if (h->any_bristle) {
         const int pgrid = grid_for(dpcap * (a.tri_split ? 8 : 1), 64, 256 * 16);
-        if (!a.vres) hipLaunchKernelGGL((k_dual_poly<1>), dim3(pgrid), dim3(64), 0, st, a);
+        if (fx && !a.vres) {
+            hipLaunchKernelGGL((k_dual_poly<1, true>), dim3(pgrid), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k_fixed_reduce, dim3((unsigned)nk), dim3(64), 0, st, a.sink_b, (int)nk, h->dual_acc.p, kDaStride, kDaB, 42);
+        } else if (!a.vres) hipLaunchKernelGGL((k_dual_poly<1>), dim3(pgrid), dim3(64), 0, st, a);
         hipLaunchKernelGGL(k_dual_eig, dim3((unsigned)nk), dim3(64), 0, st, a);   // one wave per (item, direction)
-        hipLaunchKernelGGL((k_dual_poly<2>), dim3(pgrid), dim3(64), 0, st, a);
+        if (fx) {
+            hipLaunchKernelGGL((k_dual_poly<2, true>), dim3(pgrid), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k_fixed_reduce, dim3((unsigned)nk), dim3(64), 0, st, a.sink_c, (int)nk, h->dual_acc.p, kDaStride, kDaC, 12);
+        } else hipLaunchKernelGGL((k_dual_poly<2>), dim3(pgrid), dim3(64), 0, st, a);
     }
     hipLaunchKernelGGL(k_dual_final, dim3(kgrid), dim3(64), 0, st, a);
     HIP_TRY(h, hipGetLastError());
@@ -2407,7 +2522,7 @@ int pfc_eval_dual(pfc_handle h, int n_items, int n_dir, const int *ins_ids, cons
         if (h->dual_dev_hyb_skip < 1) h->dual_dev_hyb_skip = 1;   // (not the same sequence again inside pfc_eval_dual_device)
     }
     if (h->finalized && n_items > 0 && n_items <= 512 && (size_t)n_items * n_dir <= 4096 && h->dual_hint >= 0 && pose && twist &&
-        wrench && sdot && !h->opt_debug && !(h->opt_split_min > 0 && n_items >= h->opt_split_min)) {
+        wrench && sdot && !h->opt_debug && !h->opt_fixed_order && !(h->opt_split_min > 0 && n_items >= h->opt_split_min)) {
         HIP_TRY(h, hipSetDevice(h->device));
         const int rc_small = eval_dual_small(h, n_items, n_dir, ins_ids, pose, twist, s, d_pose, d_twist, d_s, wrench, sdot,
                                              d_wrench, d_sdot, counts);
@@ -2567,6 +2682,21 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "team_fault")) h->opt_team_fault = (int)value;
     else if (!std::strcmp(name, "fused_f32")) h->opt_fused_f32 = value != 0;
     else if (!std::strcmp(name, "dual_fold")) { h->opt_dual_fold = value != 0; h->dghave = false; }
+    else if (!std::strcmp(name, "fixed_order")) {
+        // the batched path only (no one-launch kernel, no two-half split, eager launches: the sort is library code); the three
+        // options come back as they were when the option goes off
+        const int on = value != 0;
+        if (on && !h->opt_fixed_order) {
+            h->fixed_saved[0] = h->opt_fused; h->fixed_saved[1] = h->opt_split_min; h->fixed_saved[2] = h->opt_graph;
+            h->opt_fused = 0; h->opt_split_min = 0; h->opt_graph = 0;
+        } else if (!on && h->opt_fixed_order) {
+            h->opt_fused = h->fixed_saved[0]; h->opt_split_min = h->fixed_saved[1]; h->opt_graph = h->fixed_saved[2];
+        }
+        h->opt_fixed_order = on; h->fused_skip = 0;
+        h->ghave[0] = h->ghave[1] = false; h->dghave = false;
+        h->dual_reuse_ok = false; h->hyb_reuse_ok = false; h->small_reuse_ok = false;
+        h->rec.release();      // (the records change their stride)
+    }
     else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);
     return PFC_OK;

@@ -23,6 +23,9 @@ enum : unsigned {
     kStRecOvf = 64u,
     kStPolyOvf = 128u,   // a kept-polygon region ran full (sized so that it cannot: an internal error)
     kStHole = 256u,      // a work-list entry with an item index out of range was read (unwritten slot: an internal error)
+    // (512, 1024: the one-launch kernel's own bits, pfc_fused.h)
+    kStFixedSpan = 2048u,   // option "fixed_order": the candidates of one item span more chunks than k_shift_fixed's table holds
+    kStFixedList = 4096u,   // option "fixed_order": a key has more sum records than k_fixed_reduce orders at a time
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -150,6 +153,9 @@ constexpr int kAccStride = 44;
 // moment record of one run of an item: item, W, c(3), Snn 6, San 9, Saa 6, Srr 6 (about the reference point c), and the
 // first moment m1 = sum w (r - c) (3; zero when c is the run's own pressure centroid: k_narrow's full modes), padding
 constexpr int kRecStride = 36;
+// records of option "fixed_order" (k_integ_fixed -> k_shift_fixed): the same 35 numbers, then the run's ten sums, its chunk index and
+// the slot of the item's previous record
+constexpr int kRecTen = 35, kRecChunk = 45, kRecNext = 46, kRecStrideFixed = 48;
 // per-item derived results (doubles)
 constexpr int kResCop = 0;      // 3
 constexpr int kResSinv = 3;     // 6

@@ -290,6 +290,13 @@ int multi_eval_dual(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
 }
 
 // ---- device-pointer entry points ---------------------------------------------------------------------------------
+// The enqueueing thread walks over the devices of the list; whichever way an entry point is left (HIP_TRY returns from the middle
+// of a shard's enqueue), the caller's thread is back on the first device -- the one its buffers and its stream live on.
+struct MultiDeviceGuard {
+    int dev;
+    explicit MultiDeviceGuard(int d) : dev(d) {}
+    ~MultiDeviceGuard() { (void)hipSetDevice(dev); }
+};
 hipError_t multi_copy(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t st) {
     if (bytes == 0) return hipSuccess;
     if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
@@ -324,6 +331,7 @@ int multi_eval_device(pfc_context *h, int n_items, int n_dir, const int *d_ins_i
     multi_partition(h, n_items, nullptr, d_ins_ids != nullptr, true);
     const int dev0 = M->dev[0];
     HIP_TRY(h, hipSetDevice(dev0));
+    MultiDeviceGuard back_to_first(dev0);
     hipStream_t st0 = stream ? (hipStream_t)stream : M->shard[0]->stream;
     const size_t nd = (size_t)n_dir;
     if (M->n_used > 1) HIP_TRY(h, hipEventRecord(M->ev_fork, st0));
@@ -400,6 +408,7 @@ int multi_eval_dual_device_more(pfc_context *h, int n_dir, const double *d_dpose
     if (!d_dpose || !d_dtwist || !d_dwrench || !d_dsdot) return fail(h, PFC_ERR_BAD_ARG, "pfc_eval_dual_device_more: null buffer");
     const int dev0 = M->dev[0];
     HIP_TRY(h, hipSetDevice(dev0));
+    MultiDeviceGuard back_to_first(dev0);
     hipStream_t st0 = stream ? (hipStream_t)stream : M->shard[0]->stream;
     const size_t nd = (size_t)n_dir;
     if (M->n_used > 1) HIP_TRY(h, hipEventRecord(M->ev_fork, st0));

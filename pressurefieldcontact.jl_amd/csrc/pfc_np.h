@@ -106,9 +106,20 @@ __device__ __forceinline__ int wave_total_i(int v, int lane) {
 // transposed onto lanes 0..N-1 (readlane from the run's tail) and leave as ONE wave-wide FP64 atomic instruction
 // on N consecutive accumulator slots: single-lane atomics are issue-bound (one wave instruction per ~50 ns per CU,
 // MI355X guide 'Global float atomics'), a 37-lane one costs the same as a 1-lane one.
-template <int N>
+// FX (option "fixed_order", the Dual passes): a run's totals do not join the accumulator by an atomic; they leave as a RECORD
+// -- key, the wave's position in the pass, the key's previous record, N values -- and k_fixed_reduce adds a key's records in the
+// order of their positions (pfc_dual.h).
+constexpr int kSinkHdr = 4, kSinkStride = 48;      // [0] key [1] position [2] previous record of the key [3] -; then up to 44 values
+struct FixedSink {
+    double *rec;
+    int *count;          // records handed out (may exceed cap: the excess is dropped and reported)
+    int *head;           // per key: its last record, -1: none
+    int cap;
+    unsigned *status;
+};
+template <int N, bool FX = false>
 __device__ __forceinline__ void accumulate_items(double *acc, int item, bool listed, bool any, const double *v, int n0,
-                                                 int stride = kAccStride) {
+                                                 int stride = kAccStride, const FixedSink *fx = nullptr, int order = 0) {
     // listed: the lane holds a work-list entry (its item keys the run even if it contributes nothing, so empty
     // polygons do not chop an item's run into pieces); any: the lane has a contribution
     static_assert(N <= 64, "one value per lane");
@@ -129,7 +140,23 @@ __device__ __forceinline__ void accumulate_items(double *acc, int item, bool lis
             const double x = readlane_f64(tot[k], t);
             if (lane == k) mine = x;
         }
+        if constexpr (FX) {
+            static_assert(N <= kSinkStride - kSinkHdr, "a record holds the run's values");
+            // (a run whose totals are all zero -- lanes that hold a list entry and contribute nothing -- adds nothing, as with the atomics)
+            if (__ballot(lane < N && mine != 0.0) == 0) continue;
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(fx->count, 1);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (slot < fx->cap) {
+                double *r = fx->rec + (size_t)slot * kSinkStride;
+                if (lane < N) r[kSinkHdr + lane] = mine;
+                if (lane == 0) { r[0] = (double)item_t; r[1] = (double)order; r[2] = (double)atomicExch(&fx->head[item_t], slot); }
+            }
+            // (no room: the pass runs on more pairs than the capacity it was given was sized for -- the caller finds that out from
+            // the pair count, as for the kept Dual polygons, and re-issues the passes)
+        } else {
         if (lane < N && mine != 0.0) unsafeAtomicAdd(&acc[(size_t)item_t * stride + n0 + lane], mine);
+        }
     }
 }
 
@@ -1037,6 +1064,7 @@ struct IntegArgs {
     int rr_cap;
     int *icnt;
     unsigned *status;
+    int *det;                // k_integ_fixed: per item (last record, first chunk, last chunk) -- k_fixed_init, k_shift_fixed
 };
 
 // the row-summing half of lds_row_sums on rows that already sit in LDS (row k at buf[k (64 + L) + lane])
@@ -1065,9 +1093,12 @@ __device__ __forceinline__ double lds_rows_total(const double *buf, int lane, in
     return (dst_row >= 0 && dst_row < N) ? out : 0.0;
 }
 
-__global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
+// DET (option "fixed_order", the candidate list sorted: pfc_sort.hip): a run leaves NO atomic sum behind -- its ten sums travel in
+// its record next to the moments, the record carries its chunk index and hangs in a list per item, and k_shift_fixed adds an
+// item's records in chunk order.
+template <bool DET>
+__device__ __forceinline__ void integ_body(const IntegArgs &g, double *m27) {
     constexpr int RS = 66;                  // row stride of lds_row_sums / lds_rows_total with two lanes per row
-    __shared__ double m27[27 * RS];         // the 27 running moments of the current run, one column per lane
     const int lane = threadIdx.x;
     int n_c = *g.ccount;
     if (n_c > g.ccap) n_c = g.ccap;
@@ -1091,12 +1122,45 @@ __global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
 #pragma unroll
             for (int k = 0; k < 10; ++k) {
                 const double t = wave_total(s10[k], lane);
-                if (lane == k) t10 = t;
+                if (lane == (DET ? kRecTen + k : k)) t10 = t;
                 if (k == 6) Wt = t;
                 if (k == 7) sx = t;
                 if (k == 8) sy = t;
                 if (k == 9) sz = t;
             }
+            if constexpr (DET) {
+                // one record per run whatever the model: [0] item [1] W (0: no moments) [2..4] c0 [5..31] moments [32..34] m1
+                // [kRecTen..+10) the ten sums [kRecChunk] chunk [kRecNext] the item's previous record
+                const bool mom = !cur_reg && Wt > 0.0;
+                double mine = 0.0;
+                if (mom) {
+                    wave_lds_sync();
+                    mine = lds_rows_total<27, 2>(m27, lane, 5);
+                    if (lane == 1) mine = Wt;
+                    if (lane == 2) mine = c0.x;
+                    if (lane == 3) mine = c0.y;
+                    if (lane == 4) mine = c0.z;
+                    if (lane == 32) mine = sx - Wt * c0.x;
+                    if (lane == 33) mine = sy - Wt * c0.y;
+                    if (lane == 34) mine = sz - Wt * c0.z;
+                }
+                if (lane == 0) mine = (double)cur;
+                if (lane >= kRecTen && lane < kRecTen + 10) mine = t10;
+                if (lane == kRecChunk) mine = (double)ch;
+                const int rgn_c = ch & (kRgn - 1);
+                int rs = 0;
+                if (lane == 0) rs = atomicAdd(g.rgn + rgn_c * kRgnStride + 1, 1);
+                rs = __builtin_amdgcn_readfirstlane(rs);
+                if (rs < g.rr_cap) {
+                    const int slot = rgn_c * g.rr_cap + rs;
+                    if (lane == kRecNext) mine = (double)atomicExch(&g.det[3 * (size_t)cur], slot);
+                    if (lane == kRecNext + 1) { atomicMin(&g.det[3 * (size_t)cur + 1], ch); atomicMax(&g.det[3 * (size_t)cur + 2], ch); }
+                    if (lane < kRecStrideFixed) g.rec[(size_t)slot * kRecStrideFixed + lane] = mine;
+                } else if (lane == 0) {
+                    atomicOr(g.status, kStRecOvf);
+                }
+                if (mom) wave_lds_sync();
+            } else {
             if (lane < 10 && t10 != 0.0) unsafeAtomicAdd(&g.acc[(size_t)cur * kAccStride + lane], t10);
             if (!cur_reg && Wt > 0.0) {
                 wave_lds_sync();
@@ -1119,6 +1183,7 @@ __global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
                     atomicOr(g.status, kStRecOvf);
                 }
                 wave_lds_sync();
+            }
             }
             const int nt = wave_total_i(n_tr, lane);
             if (lane == 0 && nt) atomicAdd(&g.icnt[4 * (size_t)cur + 3], nt);
@@ -1285,6 +1350,14 @@ __global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
         flush();
     }
 }
+__global__ void __launch_bounds__(64, 2) k_integ(IntegArgs g) {
+    __shared__ double m27[27 * 66];         // the 27 running moments of the current run, one column per lane
+    integ_body<false>(g, m27);
+}
+__global__ void __launch_bounds__(64, 2) k_integ_fixed(IntegArgs g) {
+    __shared__ double m27[27 * 66];
+    integ_body<true>(g, m27);
+}
 
 // Bristle friction pass (after k_eig): calc_spatial_bristle_force (friction.jl:171-201) + traction(::Bristle) (:32-48)
 // over the polygons k_narrow kept.  One lane per kept polygon, every load is a coalesced read of consecutive slots;
@@ -1301,8 +1374,10 @@ struct FricArgs {
     unsigned *status;
     const double *res;
     double *acc;
+    FixedSink sink;      // k_fric_fixed (option "fixed_order"): the six sums of a piece's runs leave as records (k_fixed_reduce)
 };
-__global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
+template <bool FX>
+__device__ __forceinline__ void fric_body(const FricArgs &g) {
     const int lane = threadIdx.x;
     const size_t P = (size_t)g.pcap;
     int n_c = *g.ccount;
@@ -1386,8 +1461,10 @@ __global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) {
                     contributed = true;
             }
         }
-        accumulate_items<6>(g.acc, item, active, contributed, sum, kAccFric);
+        accumulate_items<6, FX>(g.acc, item, active, contributed, sum, kAccFric, kAccStride, &g.sink, ch * 8 + (p0 >> 6));
       }
     }
 }
+__global__ void __launch_bounds__(64, 3) k_fric(FricArgs g) { fric_body<false>(g); }
+__global__ void __launch_bounds__(64, 3) k_fric_fixed(FricArgs g) { fric_body<true>(g); }
 

@@ -11,7 +11,7 @@ V="0 3 4 9 7 5"
 if [ "$1" = build ]; then
   mkdir -p $R/build/variants
   for e in $V; do
-    (cd $C && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DPFC_EXP=$e -o $R/build/variants/e$e.so pfc_hip.hip pfc_tree.cpp) &
+    (cd $C && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DPFC_EXP=$e -o $R/build/variants/e$e.so pfc_hip.hip pfc_tree.cpp pfc_sort.hip) &
   done
   wait; ls -la $R/build/variants
 else

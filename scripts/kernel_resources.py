@@ -14,7 +14,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fn
 
 def main():
     cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + sys.argv[1:] + ["-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/pfc_res.so",
-                                                            "pfc_hip.hip", "pfc_tree.cpp"]
+                                                            "pfc_hip.hip", "pfc_tree.cpp", "pfc_sort.hip"]
     out = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if out.returncode != 0:
         sys.stderr.write(out.stderr[-4000:])

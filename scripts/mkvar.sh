@@ -11,5 +11,5 @@ rm -rf /tmp/pfc_var && mkdir -p /tmp/pfc_var/a/b /tmp/pfc_var/include && cp $R/i
 cp $R/pressurefieldcontact.jl_amd/csrc/*.h $R/pressurefieldcontact.jl_amd/csrc/*.hip $R/pressurefieldcontact.jl_amd/csrc/*.cpp /tmp/pfc_var/a/b/
 cd /tmp/pfc_var/a/b && python3 "$1"
 mkdir -p $R/build/variants
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DPFC_VARIANT=1 $EXTRA_FLAGS -fPIC -shared -o $R/build/variants/$2.so pfc_hip.hip pfc_tree.cpp 2>&1 | grep -i " error" || true
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DPFC_VARIANT=1 $EXTRA_FLAGS -fPIC -shared -o $R/build/variants/$2.so pfc_hip.hip pfc_tree.cpp pfc_sort.hip 2>&1 | grep -i " error" || true
 ls -la $R/build/variants/$2.so
