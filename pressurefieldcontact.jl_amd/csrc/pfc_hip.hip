@@ -1724,7 +1724,7 @@ int pfc_check(pfc_handle h) {
         const long long pairs_h = h->h_emit[0];
         h->dual_hint = pairs_h;
         const int cpw_h = 64 / h->pending_ndir;
-        if (h->any_bristle && (size_t)((pairs_h + cpw_h - 1) / cpw_h) * 64 + 64 > h->pending_dpcap)
+        if ((h->any_bristle || h->opt_fixed_order) && (size_t)((pairs_h + cpw_h - 1) / cpw_h) * 64 + 64 > h->pending_dpcap)
             return fail(h, PFC_ERR_OVERFLOW, "Dual evaluation: %lld contributing pairs exceed the speculative polygon capacity: re-issue", pairs_h);
         h->dual_reuse_ok = true; h->dual_reuse_n = h->last_n_items; h->dual_reuse_emit = true;
         return PFC_OK;
@@ -1739,7 +1739,7 @@ int pfc_check(pfc_handle h) {
     const long long pairs = h->h_tail[12 + (((h->last_levels + 9) & ~1) + 1)];
     h->dual_hint = pairs;
     const int cpw = 64 / h->pending_ndir;
-    if (h->any_bristle && (size_t)((pairs + cpw - 1) / cpw) * 64 + 64 > h->pending_dpcap)
+    if ((h->any_bristle || h->opt_fixed_order) && (size_t)((pairs + cpw - 1) / cpw) * 64 + 64 > h->pending_dpcap)
         return fail(h, PFC_ERR_OVERFLOW, "Dual evaluation: %lld contributing pairs exceed the speculative polygon capacity: re-issue", pairs);
     h->dual_reuse_ok = true; h->dual_reuse_n = h->last_n_items; h->dual_reuse_emit = false;
     return PFC_OK;
@@ -1901,7 +1901,9 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     const int kgrid = grid_for(nk, 64, 1 << 20);
     const bool tt = h->any_tet_tet;
     // Dual polygons kept between the passes: a wave of k_narrow_dual owns 64 consecutive slots (no slot counter)
-    const size_t dpcap = h->any_bristle ? ((n_pairs_bound + cpw - 1) / cpw) * 64 + 64 : 64;   // 64 slots per group of cpw pairs
+    // (option fixed_order: the bound also sizes the record list of the passes' sums, for every model -- the callers compare the pair count
+    // with this capacity after their synchronisation and re-issue the passes when it was exceeded)
+    const size_t dpcap = (h->any_bristle || h->opt_fixed_order) ? ((n_pairs_bound + cpw - 1) / cpw) * 64 + 64 : 64;   // 64 slots per group of cpw pairs
     HIP_TRY(h, ensure_dual(h, h->dual_poly, dpcap * kDpFields));
     HIP_TRY(h, ensure_dual(h, h->dual_pkey, dpcap));
     a.dpoly = h->dual_poly.p; a.dpoly_key = h->dual_pkey.p; a.dpcap = (long long)dpcap;
@@ -2155,7 +2157,7 @@ int eval_dual_hybrid(pfc_context *h, int n_items, int n_dir, const int *ins_ids,
     const long long pairs = h->h_emit[0];
     h->dual_hint = pairs;
     const int cpw = 64 / n_dir;
-    if (h->any_bristle && (size_t)((pairs + cpw - 1) / cpw) * 64 + 64 > dpcap) return PFC_ERR_OVERFLOW;
+    if ((h->any_bristle || h->opt_fixed_order) && (size_t)((pairs + cpw - 1) / cpw) * 64 + 64 > dpcap) return PFC_ERR_OVERFLOW;
     const double *po = (const double *)h->pin_out;
     std::memcpy(wrench, po, sizeof(double) * n * 6);
     std::memcpy(sdot, po + n * 6, sizeof(double) * n * 6);
@@ -2229,7 +2231,7 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     if (!same) HIP_TRY(h, ensure_work(h, n_items));      // (not before a reuse: option poison refills the work lists there)
     HIP_TRY(h, ensure_dual(h, h->dual_acc, nk * kDaStride));
     HIP_TRY(h, ensure_dual(h, h->dual_res, nk * kDrStride));
-    const size_t dpcap = h->any_bristle ? ((bound + cpw - 1) / cpw) * 64 + 64 : 64;
+    const size_t dpcap = (h->any_bristle || h->opt_fixed_order) ? ((bound + cpw - 1) / cpw) * 64 + 64 : 64;
     HIP_TRY(h, ensure_dual(h, h->dual_poly, dpcap * kDpFields));
     HIP_TRY(h, ensure_dual(h, h->dual_pkey, dpcap));
     const int levels = eff_levels(h);
@@ -2312,7 +2314,7 @@ int eval_dual_small(pfc_context *h, int n_items, int n_dir, const int *ins_ids, 
     const int *tail = (const int *)h->pin_out;
     const long long pairs = tail[12 + (((h->last_levels + 9) & ~1) + 1)];
     h->dual_hint = pairs;
-    if (h->any_bristle && (size_t)((pairs + cpw - 1) / cpw) * 64 + 64 > dpcap) return PFC_ERR_OVERFLOW;
+    if ((h->any_bristle || h->opt_fixed_order) && (size_t)((pairs + cpw - 1) / cpw) * 64 + 64 > dpcap) return PFC_ERR_OVERFLOW;
     const double *po = reinterpret_cast<const double *>((const int *)h->pin_out + t0);
     std::memcpy(wrench, po, sizeof(double) * n * 6);
     std::memcpy(sdot, po + n * 6, sizeof(double) * n * 6);

@@ -12,7 +12,7 @@ from test_oracle_dual import tangents
 pytestmark = pytest.mark.gpu
 
 
-def run_case(pfc, O, w, n_dir, seed, wr_tol=1e-6, sd_tol=1e-5, zero_s=False):
+def run_case(pfc, O, w, n_dir, seed, wr_tol=1e-6, sd_tol=1e-5, zero_s=False, options=None):
     rng = np.random.default_rng(seed)
     n = w.n_items
     if not zero_s:
@@ -25,6 +25,8 @@ def run_case(pfc, O, w, n_dir, seed, wr_tol=1e-6, sd_tol=1e-5, zero_s=False):
         R0 = w.pose[k][:9].reshape(3, 3, order="F"); t0 = w.pose[k][9:12]
         d_pose[k] = tangents(R0, t0, dq[k])
     m = pfc.configs.build_scenario(w)
+    for name, value in (options or {}).items():
+        m.set_option(name, value)
     wr, sd, dw, dsd, counts = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, d_pose, d_twist, d_s, w.ins_ids)
     wr0, sd0, counts0 = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
     # same value path (atomic summation order differs between two launches: rounding-level differences only)

@@ -1,0 +1,139 @@
+"""Option "fixed_order": bit-reproducible evaluations.
+
+The reference sums an instruction's traction points in ONE order (candidate list order, src/contact_algorithms_non_friction.jl:136-143,
+then fan and quadrature order), so two calcXd! on the same state give the same bits.  The default GPU path does not: the broadphase
+appends candidate runs in the order its workgroups finish and the per-item sums are atomics.  That is harmless up to rounding --
+except where decompose_K! (src/contact_algorithms_friction.jl:85-117) clamps an eigenvalue that is zero in exact arithmetic (a flat
+patch: 4 of the 331 touching pairs of BASELINE config 5) at 1e-16 sigma_max (:92): there the last bits of K decide the branch and two
+identical evaluations differ by up to tens of percent in the partials of those items.  With the option on, the candidate list is
+sorted (csrc/pfc_sort.hip), an item's per-chunk records are added in chunk order (k_integ_fixed, k_shift_fixed), the Dual passes'
+sums leave as records added in list order (FixedSink, k_fixed_reduce) and k_dual_eig decomposes the value pass's K: every output is
+the same bit pattern in every run."""
+import numpy as np
+import pytest
+
+import helpers as H
+from test_gpu_dual import run_case
+from test_gpu_scale import _check_vs_oracle
+from test_oracle_dual import tangents
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload(pfc, cfg):
+    C = pfc.configs
+    if cfg == "c5":
+        return C.c5_pile()
+    if cfg == "c5ps":
+        return C.c5_pile(pencil_spoon=True)
+    if cfg == "c3x24":
+        return C.c3_blob_tool(24)
+    if cfg == "c4":
+        return C.c2_box_on_plane(256, montecarlo=True)
+    if cfg == "volvol":
+        return C.vol_vol(24, n_div=4, model="bristle")
+    if cfg == "c1":
+        return C.c1_boxes()
+    raise KeyError(cfg)
+
+
+def _seeds(w, n_dir, seed):
+    rng = np.random.default_rng(seed)
+    n = w.n_items
+    dq = rng.standard_normal((n, n_dir, 6)) * np.array([1, 1, 1, 0.05, 0.05, 0.05])
+    d_pose = np.zeros((n, n_dir, 24))
+    for k in range(n):
+        d_pose[k] = tangents(w.pose[k][:9].reshape(3, 3, order="F"), w.pose[k][9:12], dq[k])
+    return d_pose, rng.standard_normal((n, n_dir, 6)) * 0.1, rng.standard_normal((n, n_dir, 6)) * 1e-3
+
+
+@pytest.mark.parametrize("cfg", ["c5", "c5ps", "c3x24", "c4", "volvol", "c1"])
+def test_two_fresh_handles_give_the_same_bits(pfc, cfg):
+    """Value and Dual evaluation (6 directions, then 3 further directions on the kept value pass) on two fresh handles and twice on
+    one of them: counters, wrench, sdot and every partial bit-equal -- including the flat-patch pairs of the pile, whose partials
+    differ by O(1) between two default evaluations."""
+    w = _workload(pfc, cfg)
+    d6 = _seeds(w, 6, 5)
+    d3 = _seeds(w, 3, 6)
+    outs = []
+    for rep in range(2):
+        m = pfc.configs.build_scenario(w)
+        m.set_option("fixed_order", 1)
+        res = []
+        for again in range(2 if rep == 0 else 1):
+            res.append(m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids))
+            res.append(m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *d6, w.ins_ids))
+            res.append(m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *d3, w.ins_ids))      # a further chunk of the Jacobian
+        outs.append(res)
+        m.close()
+    assert (outs[0][0][2][:, 3] > 0).any()
+    ref = outs[0][:3]
+    for other in (outs[0][3:], outs[1]):
+        for a, b in zip(ref, other):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+    # the Dual evaluation's values are the value evaluation's (same value pass, same order)
+    assert np.array_equal(ref[0][0], ref[1][0]) and np.array_equal(ref[0][1], ref[1][1])
+
+
+def test_fixed_order_pile_against_the_oracle(pfc):
+    """BASELINE config 5 with the option on: counters bit-equal, wrench / sdot at the tolerances of the default path
+    (tests/test_gpu_scale.py::test_c5_pile_all_pairs)."""
+    w = pfc.configs.c5_pile()
+    m = pfc.configs.build_scenario(w)
+    m.set_option("fixed_order", 1)
+    wrench, sdot, counts = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert 50 < int((counts[:, 3] > 0).sum()) < 400
+    _check_vs_oracle(pfc, w, m, wrench, sdot, counts, tol=1e-6, oracle_debug=True)
+    m.close()
+
+
+@pytest.mark.parametrize("cfg", ["blob", "c4", "volvol_reg", "volvol_bri", "c1"])
+def test_fixed_order_dual_against_the_dual_oracle(pfc, O, cfg):
+    """The Dual path with the option on (sorted lists, record sinks, K of the value pass in k_dual_eig) against the Dual oracle:
+    tri-tet bristle (the folded pass), regularized, tet-tet (three passes) and the reference's box scene."""
+    C = pfc.configs
+    w = {"blob": lambda: C.c3_blob_tool(12, seed=3, n_div_blob=6, n_div_tool=4),
+         "c4": lambda: C.c2_box_on_plane(24, montecarlo=True),
+         "volvol_reg": lambda: C.vol_vol(6, n_div=3, model="regularized"),
+         "volvol_bri": lambda: C.vol_vol(6, n_div=3, model="bristle"),
+         "c1": lambda: C.c1_boxes()}[cfg]()
+    run_case(pfc, O, w, 6, 7, options={"fixed_order": 1})
+
+
+def test_fixed_order_goes_off_again(pfc):
+    """The option forces the batched path (no one-launch kernel, no split, eager launches) and gives those three options back when
+    it is cleared: a small scene is then evaluated by the one-launch kernel again."""
+    w = pfc.configs.c1_boxes()
+    m = pfc.configs.build_scenario(w)
+    a = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert m.last_parts() == 0     # the one-launch kernel
+    m.set_option("fixed_order", 1)
+    b = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert m.last_parts() == 1     # the batched launch sequence
+    m.set_option("fixed_order", 0)
+    c = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert m.last_parts() == 0
+    for x, y in zip(a, b):
+        assert np.allclose(x, y, rtol=1e-9, atol=1e-12)
+    for x, y in zip(a, c):
+        assert np.allclose(x, y, rtol=1e-9, atol=1e-12)
+    m.close()
+
+
+def test_fixed_order_on_a_multi_device_handle(pfc):
+    """The option reaches every shard of a multi-device handle (here {0, 0}): with the same item ranges -- the first evaluation of a
+    handle cuts them by the leaf counts -- two fresh handles give the same bits, value and Dual."""
+    w = pfc.configs.c5_pile()
+    d6 = _seeds(w, 6, 5)
+    outs = []
+    for rep in range(2):
+        m = pfc.configs.build_scenario(w, devices=[0, 0])
+        m.set_option("fixed_order", 1)
+        outs.append((m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids),
+                     m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *d6, w.ins_ids)))
+        assert m.last_shards() == 2
+        m.close()
+    for a, b in zip(outs[0], outs[1]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
