@@ -282,7 +282,19 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
  * "multi_min" (multi-device handles, see pfc_create_multi), "fused_f32" (default 1: the one-launch kernel runs the batched
  * broadphase's single-precision SAT filter in front of the exact Float64 test, undecided pairs settled in the same iteration;
  * same node tests, candidates and results; 0 = exact test only; items whose pose has a frame axis parallel to one of the other
- * body's -- a box resting on a plane -- run with the filter off by themselves). */
+ * body's -- a box resting on a plane -- run with the filter off by themselves), "dual_fold" (default 1: pass B of a Dual evaluation of
+ * tri-tet scenes is formed inside pass A), "fixed_order" (default 0.  1: BIT-REPRODUCIBLE evaluations.  The reference adds an
+ * instruction's traction points in one order (src/contact_algorithms_non_friction.jl:136-143), so calcXd! gives the same bits
+ * every time; the default path here appends candidates in the order its workgroups finish and sums with atomics, which changes
+ * last bits from run to run -- and, where decompose_K! clamps an eigenvalue that is zero in exact arithmetic at 1e-16 sigma_max
+ * (a flat patch; src/contact_algorithms_friction.jl:92), whole partials.  With the option on the candidate list is sorted by
+ * (item, element of mesh_1, tet of mesh_2), every per-item sum of the value and Dual passes is added in list order, and the Dual
+ * eigen-decomposition takes the value of K from the value pass: two evaluations of the same inputs on handles set up the same
+ * way return the same bit patterns in wrench, sdot, every partial and every counter.  Batched path only (no one-launch kernel,
+ * no two-half split, no graph replay: the three options are switched off and come back when the option is cleared); costs a
+ * radix sort of the candidate list's capacity per evaluation (BASELINE config 5: 0.26 -> 0.5 ms).  Needs
+ * log2(items) + log2(elements of mesh_1) + log2(tets of mesh_2) <= 64 (PFC_ERR_BAD_ARG otherwise) and at most 4 096 x 512
+ * candidates per item (PFC_ERR_STATE)). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);
 
 /* Totals of the last checked evaluation: out[0..7] = {node tests, candidate pairs, non-empty pairs, traction

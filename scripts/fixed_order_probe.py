@@ -1,6 +1,6 @@
 """Option "fixed_order" (sorted candidate list, run records added in chunk order, the Dual passes' eigen-decomposition on the value
 pass's K): agreement with the default path, and run-to-run repeatability of values, K and partials on fresh handles.
-usage: python scripts/fixed_order_probe.py [c5|c5ps|c3x64|c4|tt]"""
+usage: python scripts/fixed_order_probe.py [c5|c5ps|c3x64|c4] [--time]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pfc_pkg
@@ -53,7 +53,7 @@ def per_item(a, b):
     return d / s
 
 
-for name in (sys.argv[1:] or ["c5", "c3x64", "c4"]):
+for name in ([a for a in sys.argv[1:] if not a.startswith("--")] or ([] if "--time" in sys.argv else ["c5", "c3x64", "c4"])):
     w = workload(name)
     n = w.n_items
     rng = np.random.default_rng(11)
@@ -83,3 +83,35 @@ for name in (sys.argv[1:] or ["c5", "c3x64", "c4"]):
             print("   partials, two fresh handles: fixed worst %.2e (items > 1e-12: %d, > 1e-6: %d) | default worst %.2e (items > 1e-12: %d, > 1e-6: %d)" %
                   (pf.max(), int((pf > 1e-12).sum()), int((pf > 1e-6).sum()), pb.max(), int((pb > 1e-12).sum()), int((pb > 1e-6).sum())))
             print("   partials, fixed vs default: worst %.2e (items > 1e-6: %d)" % (px.max(), int((px > 1e-6).sum())))
+
+
+def timing():
+    """Cost of the option: warm evaluations through host buffers, median of 15."""
+    import statistics
+    for name, w in (("c5 (2 016 pairs)", C.c5_pile()), ("c3 x 64", C.c3_blob_tool(64)), ("c4 (256 scenes)", C.c2_box_on_plane(256, montecarlo=True)),
+                    ("c3 x 2048", C.c3_blob_tool(2048))):
+        n = w.n_items
+        rng = np.random.default_rng(3)
+        nd = 6
+        seeds = (rng.standard_normal((n, nd, 24)) * 1e-2, rng.standard_normal((n, nd, 6)) * 0.1, rng.standard_normal((n, nd, 6)) * 1e-3)
+        row = []
+        for fixed in (0, 1):
+            m = C.build_scenario(w)
+            m.set_option("fixed_order", fixed)
+            tv, td = [], []
+            for k in range(18):
+                t0 = time.perf_counter()
+                m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+                tv.append(time.perf_counter() - t0)
+            for k in range(8 if n > 1000 else 18):
+                t0 = time.perf_counter()
+                m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *seeds, w.ins_ids)
+                td.append(time.perf_counter() - t0)
+            m.close()
+            row.append((statistics.median(tv[3:]) * 1e6, statistics.median(td[3:]) * 1e6))
+        print("%-18s value %8.0f -> %8.0f us | Dual(6) %8.0f -> %8.0f us   (default -> fixed_order, host buffers)" %
+              (name, row[0][0], row[1][0], row[0][1], row[1][1]), flush=True)
+
+
+if "--time" in sys.argv:
+    timing()
