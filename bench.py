@@ -184,6 +184,37 @@ def small_scene_latencies(pfc, reps: int = 200):
     return out
 
 
+def fixed_order_block(pfc):
+    """Option fixed_order (bit-reproducible evaluations, DESIGN section 6 "Round 4" (3)) on BASELINE config 5 through host buffers: two
+    fresh handles must return the same bits -- values and Dual(6) partials, the flat-patch pairs included -- and what the option costs."""
+    import numpy as np
+    w = pfc.configs.c5_pile()
+    n = w.n_items
+    rng = np.random.default_rng(5)
+    seeds = (rng.standard_normal((n, 6, 24)) * 1e-2, rng.standard_normal((n, 6, 6)) * 0.1, rng.standard_normal((n, 6, 6)) * 1e-3)
+    res, cost = {}, {}
+    for fixed in (1, 0):
+        outs = []
+        for rep in range(2):
+            m = pfc.configs.build_scenario(w)
+            m.set_option("fixed_order", fixed)
+            v = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+            d = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *seeds, w.ins_ids)
+            outs.append(tuple(v) + tuple(d))
+            if rep == 1:
+                ts = []
+                for _ in range(12):
+                    t0 = time.perf_counter(); m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids); ts.append(time.perf_counter() - t0)
+                cost[fixed] = statistics.median(ts[2:]) * 1e6
+            m.close()
+        a, b = outs
+        dw = np.abs(a[5] - b[5]).reshape(n, -1).max(1) / np.maximum(np.abs(b[5]).reshape(n, -1).max(1), 1e-300)
+        res[fixed] = {"every_output_bit_equal": bool(all(np.array_equal(x, y) for x, y in zip(a, b))),
+                      "items_whose_partials_differ_by_more_than_1e-12": int((dw > 1e-12).sum()), "worst_relative_difference_of_a_partial": float(dw.max())}
+    return {"workload": "C5 pile, 2 016 instructions, value + Dual(6) on two fresh handles each", "fixed_order": res[1], "default": res[0],
+            "value_evaluation_us": {"default": cost[0], "fixed_order": cost[1]}}
+
+
 def dual_block(pfc, dev, n_dir: int = 6):
     """roofline_dual: what Radau's Jacobian evaluations cost on this path.  Device-resident Dual(n_dir) evaluations
     with dense seeds of C5 (2 016 pile instructions) and of a 2 048-pose C3 batch: a first chunk (value pass + Dual passes,
@@ -606,6 +637,7 @@ def main():
             out["small_scenes"] = small_scene_latencies(pfc)
             out["single_pose_ops_per_s"] = out["small_scenes"]["C3_single_pose"]["ops_per_s"]
             out["roofline_dual"] = dual_block(pfc, dev)
+            out["reproducibility"] = fixed_order_block(pfc)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pfc, w, args.cpu_seconds, 1)
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
