@@ -376,7 +376,6 @@ struct pfc_context {
     // option "fixed_order": the candidate list sorted (pfc_sort.hip), an item's run records added in chunk order (k_integ_fixed,
     // k_shift_fixed), the Dual passes' eigen-decomposition on the value pass's K -- batched path only, no graph, no split
     int opt_fixed_order = 0;
-    int fixed_saved[3] = {1, 1025, 1};        // fused, split_min, graph as they were before the option went on
     DevBuf<int> det;                          // per item: last record, first chunk, last chunk
     DevBuf<unsigned long long> sort_keys[2];
     DevBuf<char> sort_tmp;
@@ -817,7 +816,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     if (prof && !h->ev[0])
         for (int k = 0; k < EV_COUNT; ++k) HIP_TRY(h, hipEventCreate(&h->ev[k]));
     const int L = bfs_levels_for(h, n_items, levels);
-    bool use_graph = h->opt_graph && !prof;
+    bool use_graph = h->opt_graph && !prof && !h->opt_fixed_order;      // (fixed_order: the sort is library code, launched eagerly)
 #ifdef PFC_STAMPS
     use_graph = false;
 #endif
@@ -962,7 +961,7 @@ void team_release(pfc_context *h) {
 }
 
 bool fused_ok(const pfc_context *h, int n_items) {
-    return h->opt_fused && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv &&
+    return h->opt_fused && !h->opt_fixed_order && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv &&
            !h->is_twin && h->d_insfull && n_items <= kFusedMaxItems && h->max_leaves <= kFusedMaxLeaves;
 }
 // Team size for an evaluation of a few BIG pairs (more leaves than one workgroup takes: BASELINE config 3 as written is one
@@ -982,7 +981,7 @@ int fused_team(const pfc_context *h, int n_items) {
         if (nw > h->opt_team) nw = h->opt_team;
         return nw >= 4 ? nw : 1;
     }
-    if (!(h->opt_fused && h->opt_team && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv && !h->is_twin &&
+    if (!(h->opt_fused && !h->opt_fixed_order && h->opt_team && h->fused_skip == 0 && !h->opt_debug && !h->opt_profile && !h->want_surv && !h->is_twin &&
           h->d_insfull && h->max_leaves > kFusedMaxLeaves && n_items >= 1 && n_items <= kFusedMaxItems))
         return 0;
     int nw = blocks / n_items;
@@ -1660,7 +1659,7 @@ int pfc_eval_device(pfc_handle h, int n_items, const int *d_ins_ids, const doubl
         return rc_t;
     }
     if (h->fused_skip > 0 && n_items <= kFusedMaxItems) --h->fused_skip;
-    const bool split = h->opt_split_min > 0 && n_items >= h->opt_split_min && d_ins_ids && !h->opt_debug &&
+    const bool split = h->opt_split_min > 0 && n_items >= h->opt_split_min && d_ins_ids && !h->opt_debug && !h->opt_fixed_order &&
                        !h->want_surv && !h->is_twin && !pile_mode(h, n_items);
     if (!split) return enqueue_eval(h, n_items, d_ins_ids, d_pose, d_twist, d_s, d_wrench, d_sdot, d_counts, st);
     int rc = make_twin(h);
@@ -2685,15 +2684,9 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
     else if (!std::strcmp(name, "fused_f32")) h->opt_fused_f32 = value != 0;
     else if (!std::strcmp(name, "dual_fold")) { h->opt_dual_fold = value != 0; h->dghave = false; }
     else if (!std::strcmp(name, "fixed_order")) {
-        // the batched path only (no one-launch kernel, no two-half split, eager launches: the sort is library code); the three
-        // options come back as they were when the option goes off
+        // the batched path only while it is on, whatever "fused" / "team" / "split_min" / "graph" say (fused_ok, fused_team, the split
+        // rule and use_graph look at it): no one-launch kernel, no two-half split, eager launches (the sort is library code)
         const int on = value != 0;
-        if (on && !h->opt_fixed_order) {
-            h->fixed_saved[0] = h->opt_fused; h->fixed_saved[1] = h->opt_split_min; h->fixed_saved[2] = h->opt_graph;
-            h->opt_fused = 0; h->opt_split_min = 0; h->opt_graph = 0;
-        } else if (!on && h->opt_fixed_order) {
-            h->opt_fused = h->fixed_saved[0]; h->opt_split_min = h->fixed_saved[1]; h->opt_graph = h->fixed_saved[2];
-        }
         h->opt_fixed_order = on; h->fused_skip = 0;
         h->ghave[0] = h->ghave[1] = false; h->dghave = false;
         h->dual_reuse_ok = false; h->hyb_reuse_ok = false; h->small_reuse_ok = false;

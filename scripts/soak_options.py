@@ -1,5 +1,5 @@
 """Soak run of the option switches on one handle (debug lists on/off, graph replay on/off, profiling events, seed
-levels, Float64-only broadphase, split threshold, clip-only narrowphase + k_integ): every evaluation must agree with a default-options reference.
+levels, Float64-only broadphase, split threshold, clip-only narrowphase + k_integ, fixed_order): every evaluation must agree with a default-options reference.
 usage: python scripts/soak_options.py [n_evals]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +23,7 @@ for it in range(n_evals):
     opts = {"debug": int(rng.random() < 0.2), "graph": int(rng.random() < 0.7), "profile": int(rng.random() < 0.3),
             "bfs_levels": int(rng.choice([-1, 0, 1, 2])), "no_filter": int(rng.random() < 0.15),
             "split_min": int(rng.choice([0, 256, 1024])), "fused": int(rng.random() < 0.6), "clip_min": int(rng.choice([0, 1, 256, 1024])), "clip_queue": int(rng.random() < 0.6),
-            "max_levels": int(rng.choice([0, 0, 1, 3]))}
+            "max_levels": int(rng.choice([0, 0, 1, 3])), "fixed_order": int(rng.random() < 0.3)}
     for k, v in opts.items():
         m.set_option(k, v)
     got = m.force_all_elastic_intersections(w.pose[:s], w.twist[:s], w.s[:s], w.ins_ids[:s])
@@ -31,6 +31,9 @@ for it in range(n_evals):
     ok = np.array_equal(got[2], ref[s][2])
     for k, tol in ((0, 1e-10), (1, 1e-6)):
         ok = ok and np.abs(got[k] - ref[s][k]).max() <= tol * max(np.abs(ref[s][k]).max(), 1e-300)
+    if opts["fixed_order"] and not opts["debug"]:      # bit-reproducible whatever the other switches say
+        again = m.force_all_elastic_intersections(w.pose[:s], w.twist[:s], w.s[:s], w.ins_ids[:s])
+        ok = ok and all(np.array_equal(x, y) for x, y in zip(got, again))
     if opts["debug"] and s <= 64:
         pairs, clip_n = m.debug_pairs(0)
         ok = ok and len(pairs) == got[2][0, 1]

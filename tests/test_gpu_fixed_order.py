@@ -102,15 +102,19 @@ def test_fixed_order_dual_against_the_dual_oracle(pfc, O, cfg):
 
 
 def test_fixed_order_goes_off_again(pfc):
-    """The option forces the batched path (no one-launch kernel, no split, eager launches) and gives those three options back when
-    it is cleared: a small scene is then evaluated by the one-launch kernel again."""
+    """The option means the batched path (no one-launch kernel, no split, eager launches) whatever the other path options say -- also
+    when they are set while it is on -- and a small scene is evaluated by the one-launch kernel again once it is cleared."""
     w = pfc.configs.c1_boxes()
     m = pfc.configs.build_scenario(w)
     a = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
     assert m.last_parts() == 0     # the one-launch kernel
     m.set_option("fixed_order", 1)
+    m.set_option("fused", 1); m.set_option("graph", 1); m.set_option("split_min", 2)
     b = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
-    assert m.last_parts() == 1     # the batched launch sequence
+    assert m.last_parts() == 1     # the batched launch sequence, one part
+    b2 = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    assert all(np.array_equal(x, y) for x, y in zip(b, b2))
+    m.set_option("split_min", 1025)
     m.set_option("fixed_order", 0)
     c = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
     assert m.last_parts() == 0
