@@ -81,12 +81,6 @@ struct FuArgs {
     // state of the Dual scenario (calcTriTetIntersections!, src/contact_algorithms_non_friction.jl:94-101); null: the pose itself
     const double *bp_pose;
     int f32;            // option "fused_f32" (default 1): single-precision SAT filter in front of the exact test (0: Float64 only)
-    // Teams: the seeds of the shared-out descent beyond the first kTeamGrab per rank are a POOL every rank holds a copy of; a rank
-    // running low takes the next kTeamGrab of them through one counter per item: pool[item] - pool_base = seeds handed out so far.
-    // The counter is never reset: pool_base grows by kTeamPoolStep per launch and every rank lifts the counter to it (atomicMax)
-    // before its first grab, so a launch that ended early leaves nothing behind.
-    unsigned long long *pool;
-    unsigned long long pool_base;
 };
 constexpr int kTeamSlots = 48;           // doubles a workgroup publishes per phase (first phase: 10 sums, 4 counters, status, 27 moments, their reference point)
 constexpr int kTeamMaxWg = 48;           // workgroups per item at most
@@ -94,15 +88,6 @@ constexpr int kTeamMaxBlocks = 256;      // item * nw + rank < this (one workgro
 constexpr int kTeamSeedsBig = 32;        // the same for pairs too big for one workgroup: 12 full-size C3 poses 170 -> 144 us, 8: 114 -> 108, 16 poses of a 7 380-leaf pair 101 -> 92 (mid-sized pairs lose with it: four 4 880-leaf pairs 82 -> 93 us)
 constexpr int kTeamSeeds = 16;           // the descent is shared out once a level holds this many pairs per workgroup ...
 constexpr int kTeamShareMax = 768;       // ... or this many in all: its children (four per pair at most) still fit the stack above it
-#ifndef PFC_TEAM_POOL
-#define PFC_TEAM_POOL 1      // 0: the static share of round 3 (rank r keeps the seeds j = r mod nw): A/B builds
-#endif
-#ifndef PFC_TEAM_LOW
-#define PFC_TEAM_LOW 32
-#endif
-constexpr int kTeamLow = PFC_TEAM_LOW;   // a rank asks for more seeds when it has at most this many pairs left to pop
-constexpr int kTeamGrab = 8;             // seeds a rank takes from the pool at a time (and its static first share)
-constexpr unsigned long long kTeamPoolStep = 8192;      // > seeds of a shared level (< 4 kTeamShareMax) + one failed grab per rank
 constexpr int kTeamSpinMax = 1 << 15;    // bounded wait for the team (a poll is ~2 us: ~65 ms): if a workgroup never arrives -- teams of several handles
                                          // launched at once can each be PARTLY resident on a full chip -- the item reports kStFusedOvf and the host re-issues
                                          // the evaluation on the batched path (the one-launch kernel then stays off for 64 evaluations of that handle)
@@ -275,7 +260,6 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
     __shared__ double s_bp[12];                 // R_a_b (9, column-major), t_a_b (3) of the broadphase
     __shared__ float s_posef[13], s_q12[4];     // single-precision filter: fl32 of R_a_b, t_a_b, the error radius' absolute part; R_a_b as a quaternion
     __shared__ int s_pose_exact;                // the pose is not a proper rotation (pose_quat): every test of the item is the exact one
-    __shared__ int s_grab;                      // teams: first seed of the pool this workgroup was handed (>= pool size: none left)
     __shared__ int s_plist[kFuCand];            // candidates that gave a polygon (Dual passes)
     __shared__ int s_npoly;
     __shared__ double s_dacc[16][6];            // per direction: partials of the wrench
@@ -440,12 +424,8 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
         // over the workgroup and, the traversal being deterministic, over a team).
         bool f32_on = g.f32 != 0 && s_pose_exact == 0;
         int lo = 0, hi = MW ? 1 : 0, hi0 = hi;      // the level: stk[lo, hi); its children from hi0 on
-        // the pool of seeds (see FuArgs::pool): entries [pool_lo, pool_n) of it sit at the top of the stack array
-        bool dyn = false, pool_done = true;
-        int pool_n = 0, pool_lo = 0;
-        unsigned long long gv = 0;
         const int t_share = nw * g.team_seeds < kTeamShareMax ? nw * g.team_seeds : kTeamShareMax;
-        for (int guard = 0; (bfs ? hi > lo : (sp > 0 || (dyn && !pool_done))) && guard < (1 << 22); ++guard) {
+        for (int guard = 0; (bfs ? hi > lo : sp > 0) && guard < (1 << 22); ++guard) {
             unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0; (void)u0; (void)u1; (void)u2; (void)u3; (void)u4;
             STAMP(u0);
             // Lookahead.  An iteration costs ~4 000 cycles whatever the number of busy lanes (one Float64 test per lane, a
@@ -454,28 +434,7 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             // (32) lanes per popped pair: lane 0 the pair, lanes 1..4 its child pairs, lanes 5..20 theirs.  A lane's
             // result counts only if every ancestor pair it descends from overlaps (the reference tests a pair iff its
             // parent pair intersects, tree_types.jl:88-111), so node tests and candidates are the reference's.
-            // (the seeds of the pool nobody has taken yet stay where they are; kTeamGrab slots are kept for the ones this iteration asks for)
-            const int room = (dyn ? kFuStack - pool_n + pool_lo - kTeamGrab : kFuStack) - reserve - sp;
-            // Running low -- a few pairs left, the lanes of this iteration mostly test their descendants ahead of time --: ask for the next seeds now, take them at the end of the iteration (the
-            // counter's round trip, ~2 us across the XCDs, runs beside the node test).  One thread asks; uniform over the workgroup.
-            const bool issue = MW && PFC_TEAM_POOL && dyn && !pool_done && sp <= kTeamLow;
-            if (MW && PFC_TEAM_POOL && dyn && sp == 0) {      // nothing to pop at all: ask and wait
-                if (tid == 0) {
-                    const unsigned long long d = atomicAdd(g.pool + item, (unsigned long long)kTeamGrab) - g.pool_base;
-                    s_grab = d > 0x7FFFFFFFull ? 0x7FFFFFFF : (int)d;
-                }
-                __syncthreads();
-                const int idx = s_grab;
-                if (idx < pool_n) {
-                    const int cnt = pool_n - idx < kTeamGrab ? pool_n - idx : kTeamGrab;
-                    if (tid < cnt) B.stk[tid] = B.stk[kFuStack - pool_n + idx + tid];
-                    sp = cnt; pool_lo = idx + cnt;
-                } else {
-                    pool_done = true;
-                }
-                __syncthreads();
-                continue;
-            }
+            const int room = kFuStack - reserve - sp;
             const int avail = bfs ? hi - lo : sp;      // pairs that may be popped now
             const int top = bfs ? hi : sp;            // ... from here downwards
             int LA = 1, p;
@@ -558,9 +517,6 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                 need_exact = und;
                 hit = verdict == 1;
             }
-            // (behind the filter's loads in program order: vector memory results come back in order, the wave's own node fetch must
-            // not queue behind the counter)
-            if (MW && PFC_TEAM_POOL && issue && tid == 0) gv = atomicAdd(g.pool + item, (unsigned long long)kTeamGrab);
             if (__any(need_exact)) {       // (per wave: a wave whose pairs were all decided skips the exact test altogether)
                 NodeU ua, ub;
                 bool both_aabb = true;
@@ -645,23 +601,8 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
             }
             n_cand += c_tot;
             sp += p_tot;
-            if (n_cand > kFuCand) { ovf = true; sp = 0; hi = 0; lo = 0; bfs = false; dyn = false; }    // uniform: the item leaves for the batched path
-            if (MW && PFC_TEAM_POOL && issue && tid == 0) {
-                const unsigned long long d = gv - g.pool_base;
-                s_grab = d > 0x7FFFFFFFull ? 0x7FFFFFFF : (int)d;
-            }
+            if (n_cand > kFuCand) { ovf = true; sp = 0; hi = 0; lo = 0; bfs = false; }    // uniform: the item leaves for the batched path
             __syncthreads();
-            if (MW && PFC_TEAM_POOL && issue && dyn) {      // the seeds asked for at the top of the iteration
-                const int idx = s_grab;
-                if (idx < pool_n) {
-                    const int cnt = pool_n - idx < kTeamGrab ? pool_n - idx : kTeamGrab;
-                    if (tid < cnt) B.stk[sp + tid] = B.stk[kFuStack - pool_n + idx + tid];
-                    sp += cnt; pool_lo = idx + cnt;
-                } else {
-                    pool_done = true;
-                }
-                __syncthreads();
-            }
             if (MW && bfs && hi == lo && sp - hi0 < t_share && sp <= kFuStack / 2) {
                 // the level is used up and the next one, stk[hi0, sp), is small: it stays where it is (no copy, no barrier)
                 lo = hi0; hi = sp; hi0 = sp;
@@ -677,27 +618,12 @@ __global__ void __launch_bounds__(kFuBlock) k_fused(FuArgs g) {
                     keep[k] = j < n_next ? B.stk[hi0 + j] : make_int2(0, 0);
                 }
                 __syncthreads();
-                // Shared out: rank r starts on the seeds [r G, (r + 1) G) and the rest is the pool -- subtrees differ by two orders of
-                // magnitude in size (a full-size C3 pose: 52 .. 2 073 node tests per rank under the static share j = r mod nw, the
-                // slowest rank's pass 0 ending 19 us after the fastest's), so who runs low takes more (FuArgs::pool).
-                const bool pool = PFC_TEAM_POOL && share && n_next > nw * kTeamGrab && g.pool != nullptr;
 #pragma unroll
                 for (int k = 0; k < kFuStack / kFuBlock; ++k) {
                     const int j = tid + k * kFuBlock;
-                    if (pool) {
-                        if (j < n_next && j >= nw * kTeamGrab) B.stk[kFuStack - n_next + j] = keep[k];      // pool entry j - nw G
-                        else if (j >= wr * kTeamGrab && j < (wr + 1) * kTeamGrab) B.stk[j - wr * kTeamGrab] = keep[k];
-                    } else if (j < n_next && (!share || j % nw == wr)) {
-                        B.stk[share ? j / nw : j] = keep[k];
-                    }
+                    if (j < n_next && (!share || j % nw == wr)) B.stk[share ? j / nw : j] = keep[k];
                 }
-                if (pool) {
-                    sp = kTeamGrab; dyn = true; pool_done = false; pool_n = n_next - nw * kTeamGrab; pool_lo = 0;
-                    // the counter starts at this launch's base (whatever an earlier launch left in it lies below)
-                    if (tid == 0) atomicMax(g.pool + item, g.pool_base);
-                    if (wr != 0) { n_cand = 0; n_test = 0; }
-                    bfs = false;
-                } else if (share) {
+                if (share) {
                     sp = (n_next - wr + nw - 1) / nw;
                     if (wr != 0) { n_cand = 0; n_test = 0; }      // what has been counted and found so far stays with rank 0
                     bfs = false;

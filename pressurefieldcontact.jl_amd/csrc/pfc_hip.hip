@@ -233,7 +233,6 @@ struct pfc_context {
     void *pin_bp = nullptr;              // pinned host copy of the last broadphase pose block (pfc_eval_dual_bp)
     size_t pin_bp_cap = 0;
     int pin_bp_n = 0;                    // items it holds (0: the last host-buffer Dual evaluation had none)
-    unsigned long long team_pool_base = 0;     // FuArgs::pool_base of the last team launch
     bool team_owner = false;             // this handle holds its device's team slot (team_acquire)
     int opt_team_fault = -1;             // diagnostic option "team_fault": rank of every team that simulates a timed-out wait
     int opt_dual_fold = 1;               // option "dual_fold": pass B of the Dual evaluation formed inside pass A (tri-tet scenes, batched value pass)
@@ -1036,18 +1035,15 @@ int enqueue_fused(pfc_context *h, int n_items, const int *d_ins_ids, const doubl
     a.stamps = h->stamps.p;
 #endif
     a.bp_pose = h->bp_dev; a.team_fault = h->opt_team_fault; a.f32 = h->opt_fused_f32;
-    a.nw = h->fu_nw; a.team = nullptr; a.pool = nullptr; a.pool_base = 0;
+    a.nw = h->fu_nw; a.team = nullptr;
     a.team_seeds = h->max_leaves > kFusedMaxLeaves ? kTeamSeedsBig : kTeamSeeds;
     h->last_fu_nw = a.nw;
     if (a.nw > 1) {
         if (!h->team.p) {
-            HIP_TRY(h, h->team.ensure((size_t)kTeamMaxBlocks * 3 * 2 * kTeamSlots + kTeamMaxBlocks));      // (+ one seed-pool counter per item)
+            HIP_TRY(h, h->team.ensure((size_t)kTeamMaxBlocks * 3 * 2 * kTeamSlots));
             HIP_TRY(h, hipMemsetAsync(h->team.p, 0, sizeof(unsigned long long) * h->team.cap, st));
         }
         a.team = h->team.p;
-        a.pool = h->team.p + (size_t)kTeamMaxBlocks * 3 * 2 * kTeamSlots;
-        h->team_pool_base += kTeamPoolStep;
-        a.pool_base = h->team_pool_base;
         if (h->any_tet_tet) hipLaunchKernelGGL((k_fused<true, true>), dim3(n_items * a.nw), dim3(kFuBlock), 0, st, a);
         else hipLaunchKernelGGL((k_fused<false, true>), dim3(n_items * a.nw), dim3(kFuBlock), 0, st, a);
     } else
