@@ -145,7 +145,8 @@ struct DualArgs {
     // k_dual_poly<1> and its read of every kept polygon are not launched.  Null (hand-over from the fused small-scene
     // kernel, which keeps its cop in LDS): three passes as before.
     const double *vres;
-    // Option "fixed_order": the value pass's result rows again (cop, K).  Non-null: k_dual_eig takes the VALUE of the cop and of
+    // The value pass's result rows again (cop, K) -- whenever the value pass was the batched one, and always under option
+    // "fixed_order".  Non-null: k_dual_eig takes the VALUE of the cop and of
     // K from them -- the same numbers for every direction and every chunk of a Jacobian (src/radau/radau_functions.jl:2-14), summed
     // in a fixed order by the value pass -- and only the partials from the Dual sums, whose own value parts are the same quantities
     // summed in another, run-dependent order.  Where decompose_K! clamps an eigenvalue that is zero up to rounding (a flat patch,
