@@ -329,6 +329,8 @@ __device__ __forceinline__ void eig_item(const double *a, double k_bar, double m
     }
     wave_lds_sync();
     jacobi6_wave(A, V, lane);
+    if (lane < 36) r[kResV + lane] = V[lane];
+    if (lane < 6) r[kResLam + lane] = A[7 * lane];
     if (lane < 6) {
         double mx = A[0];
 #pragma unroll

@@ -145,13 +145,14 @@ struct DualArgs {
     // k_dual_poly<1> and its read of every kept polygon are not launched.  Null (hand-over from the fused small-scene
     // kernel, which keeps its cop in LDS): three passes as before.
     const double *vres;
-    // The value pass's result rows again (cop, K) -- whenever the value pass was the batched one, and always under option
-    // "fixed_order".  Non-null: k_dual_eig takes the VALUE of the cop and of
+    // Option "fixed_order" (or PFC_DUAL_VALUE_K=1): the value pass's result rows again (cop, K, the eigen-decomposition of K̄).
+    // Non-null: k_dual_eig takes the VALUE of the cop and of
     // K from them -- the same numbers for every direction and every chunk of a Jacobian (src/radau/radau_functions.jl:2-14), summed
     // in a fixed order by the value pass -- and only the partials from the Dual sums, whose own value parts are the same quantities
     // summed in another, run-dependent order.  Where decompose_K! clamps an eigenvalue that is zero up to rounding (a flat patch,
     // friction.jl:92) the last bits of K decide the branch: this way they decide it once per item and evaluation.
     const double *vres_k;
+    int stored_v;            // (with vres_k) 1: also the value pass's eigenvectors / eigenvalues / scaling; 0: k_dual_eig iterates itself (A/B)
     // ... and the sums that feed the eigen-decomposition -- pass A's (cop) and pass B's (patch stiffness) -- leave the passes as
     // records (FixedSink, pfc_np.h) that k_fixed_reduce adds per key in the order of the waves' positions in the contributing-pair
     // list, which pfc_sort.hip has sorted: the partials of K are then the same numbers in every evaluation of the same inputs
@@ -961,7 +962,7 @@ __global__ void __launch_bounds__(64) k_dual_eig(DualArgs g) {
         const Du t1 = (du(Kv[0], Kd[0]) + du(Kv[7], Kd[7])) + du(Kv[14], Kd[14]);
         const Du t2 = (du(Kv[21], Kd[21]) + du(Kv[28], Kd[28])) + du(Kv[35], Kd[35]);
         const Du sv = lane < 3 ? (du(1.0) / dsqrt(t1)) * it->magic : du(1.0) / dsqrt(t2);
-        SinvV[lane] = sv.v; SinvD[lane] = sv.d;
+        SinvV[lane] = (vk && g.stored_v) ? vk[kResSinv + lane] : sv.v; SinvD[lane] = sv.d;      // (vk: the scaling the stored decomposition belongs to)
     }
     wave_lds_sync();
     if (ent) {
@@ -970,7 +971,14 @@ __global__ void __launch_bounds__(64) k_dual_eig(DualArgs g) {
         A[lane] = kb.v; dK[lane] = kb.d;
     }
     wave_lds_sync();
-    jacobi6_wave(A, V, lane);
+    if (vk && g.stored_v) {
+        // the decomposition the value pass made of this very matrix (k_eig: same K, same scaling, same iteration): the six
+        // directions of an item -- and every chunk of a Jacobian -- need not repeat its ~8 us dependency chain
+        if (ent) { V[lane] = vk[kResV + lane]; if (i == j) A[lane] = vk[kResLam + i]; }
+        wave_lds_sync();
+    } else {
+        jacobi6_wave(A, V, lane);
+    }
     // M = V' dK V
     if (ent) {
         double x = 0.0;

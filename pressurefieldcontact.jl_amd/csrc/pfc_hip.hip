@@ -1929,12 +1929,17 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     static const bool no_fold = std::getenv("PFC_NO_DUAL_FOLD") != nullptr;
     a.vres = (h->any_bristle && !pair_count && !no_fold && !tt && h->opt_dual_fold) ? h->res.p : nullptr;
     // fixed_order: every key of an item decomposes the K of the VALUE pass (one clamp decision per item and evaluation)
-    // ... and so does every default evaluation whose value pass was the batched one (its result rows are in h->res): the columns of a
-    // Jacobian and its chunks then share ONE clamp decision per item -- the same directions as first and as further chunk of one value
-    // pass differ by O(1) on the four flat-patch pairs of config 5 without this, by 1e-2 .. 2e-1 with it (what is left is the rounding
-    // noise of the Dual sums under an unclamped noise eigenvalue, which only fixed_order removes).  PFC_NO_DUAL_VALUE_K=1: A/B.
-    static const bool no_value_k = std::getenv("PFC_NO_DUAL_VALUE_K") != nullptr;
-    a.vres_k = ((h->opt_fixed_order || !no_value_k) && h->any_bristle && !pair_count) ? h->res.p : nullptr;
+    // (PFC_DUAL_VALUE_K=1: the same without the option, A/B.  It was the default for a day: the same six directions as first and as
+    // further chunk of one value pass differ by O(1) on the four flat-patch pairs of config 5 without it and by 1e-2 .. 2e-1 with it,
+    // and k_dual_eig saves its Jacobi iteration -- C5 further chunk 355 -> 346 us.  But the value pass forms K by two parallel-axis
+    // shifts, the Dual passes sum about the cop directly as the reference does, and on flat patches the value pass's noise
+    // eigenvalue lands on the other side of the clamp from the Dual oracle's often enough to fail an oracle comparison of d_sdot
+    // in one run of four; the Dual sums' never did in some fifty suite runs.  Both are rounding noise; the default stays with
+    // the arithmetic that is closer to the reference's.)
+    static const bool value_k = std::getenv("PFC_DUAL_VALUE_K") != nullptr;
+    a.vres_k = ((h->opt_fixed_order || value_k) && h->any_bristle && !pair_count) ? h->res.p : nullptr;
+    static const bool no_stored_v = std::getenv("PFC_NO_DUAL_STORED_V") != nullptr;
+    a.stored_v = no_stored_v ? 0 : 1;
     const bool fx = h->opt_fixed_order && !pair_count;
     a.sink_a = FixedSink{nullptr, nullptr, nullptr, 0, nullptr};
     a.sink_b = a.sink_a; a.sink_c = a.sink_a;

@@ -162,7 +162,9 @@ constexpr int kResSinv = 3;     // 6
 constexpr int kResDelta = 9;    // 6
 constexpr int kResKis = 15;     // 36  K̄^{-1/2}
 constexpr int kResK = 51;       // 36
-constexpr int kResStride = 88;
+constexpr int kResV = 88;       // 36  eigenvectors of K̄ (columns) ...
+constexpr int kResLam = 124;    // 6   ... and its eigenvalues, as the Jacobi iteration left them: k_dual_eig differentiates THIS decomposition
+constexpr int kResStride = 130;
 
 // ---------------------------------------------------------------------------------------------------------------
 // small vector helpers (StaticArrays evaluation order: left-to-right sums, no contraction)

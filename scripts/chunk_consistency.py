@@ -16,4 +16,4 @@ for rep in range(6):
                    np.abs(a[3] - b[3]).reshape(n, -1).max(1) / np.maximum(np.abs(b[3]).reshape(n, -1).max(1), 1e-300))
     worst.append(d.max()); cnt6.append(int((d > 1e-6).sum())); cnt12.append(int((d > 1e-12).sum()))
     m.close()
-print("PFC_NO_DUAL_VALUE_K =", os.environ.get("PFC_NO_DUAL_VALUE_K"), "| same directions, first chunk vs further chunk of one value pass: worst", ["%.1e" % x for x in worst], "items > 1e-6:", cnt6, "> 1e-12:", cnt12)
+print("PFC_DUAL_VALUE_K =", os.environ.get("PFC_DUAL_VALUE_K"), "| same directions, first chunk vs further chunk of one value pass: worst", ["%.1e" % x for x in worst], "items > 1e-6:", cnt6, "> 1e-12:", cnt12)
