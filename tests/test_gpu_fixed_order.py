@@ -141,3 +141,32 @@ def test_fixed_order_on_a_multi_device_handle(pfc):
     for a, b in zip(outs[0], outs[1]):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+def test_fixed_order_growth_errors_and_poisoned_lists(pfc):
+    """With the option on: the first evaluation of a fresh handle (work lists, record lists and sort buffers grow, the evaluation is
+    re-issued) returns the bits of every later one, also from poisoned work lists; a non-finite pose is reported and the next
+    evaluation is clean; three sampled items against the oracle."""
+    L = pfc._lib
+    w = pfc.configs.c3_blob_tool(300, n_div_blob=8, n_div_tool=6)
+    m = pfc.configs.build_scenario(w)
+    m.set_option("fixed_order", 1)
+    first = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)      # minimal capacities: must grow
+    assert m.stats()["candidates"] > 65536
+    second = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    m.set_option("poison", 1)
+    third = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    m.set_option("poison", 0)
+    bad = w.pose.copy(); bad[7, 3] = np.nan
+    with pytest.raises(L.PFCError) as ei:
+        m.force_all_elastic_intersections(bad, w.twist, w.s, w.ins_ids)
+    assert ei.value.status == L.ERR_NONFINITE
+    fourth = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+    for other in (second, third, fourth):
+        for x, y in zip(first, other):
+            assert np.array_equal(x, y)
+    ref = H.oracle_run(pfc, w, items=[0, 150, 299], debug=False)
+    for k, r in zip([0, 150, 299], ref):
+        assert np.array_equal(first[2][k], r.counts)
+        assert H.rel_err(first[0][k], r.wrench) < 1e-9
+    m.close()
