@@ -2697,10 +2697,12 @@ int pfc_set_option(pfc_handle h, const char *name, long long value) {
         // the batched path only while it is on, whatever "fused" / "team" / "split_min" / "graph" say (fused_ok, fused_team, the split
         // rule and use_graph look at it): no one-launch kernel, no two-half split, eager launches (the sort is library code)
         const int on = value != 0;
-        h->opt_fixed_order = on; h->fused_skip = 0;
-        h->ghave[0] = h->ghave[1] = false; h->dghave = false;
-        h->dual_reuse_ok = false; h->hyb_reuse_ok = false; h->small_reuse_ok = false;
-        h->rec.release();      // (the records change their stride)
+        if (on != h->opt_fixed_order) {      // (setting it to what it is changes nothing: a kept value pass stays reusable)
+            h->opt_fixed_order = on; h->fused_skip = 0;
+            h->ghave[0] = h->ghave[1] = false; h->dghave = false;
+            h->dual_reuse_ok = false; h->hyb_reuse_ok = false; h->small_reuse_ok = false;
+            h->rec.release();      // (the records change their stride)
+        }
     }
     else if (!std::strcmp(name, "no_filter")) { h->opt_no_filter = (int)value; h->ghave[0] = h->ghave[1] = false; h->dghave = false; }
     else return fail(h, PFC_ERR_BAD_ARG, "unknown option %s", name);

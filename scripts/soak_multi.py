@@ -47,6 +47,12 @@ for it in range(n_evals):
     sc = 1.0 + 0.1 * it
     sd = (d_pose[sl] * sc, d_twist[sl], d_s[sl])
     ref = C.build_scenario(w)
+    # option fixed_order on the long-lived handle (every shard), switched every ~8 evaluations (any pfc_set_option drops a kept
+    # value pass): results as before up to the order of the sums
+    if it % 8 == 0:
+        fixed = bool(rng.random() < 0.4)
+        m.set_option("fixed_order", int(fixed))
+    kinds["fixed_order"] = kinds.get("fixed_order", 0) + int(fixed)
     if mode == "vh":
         got = m.force_all_elastic_intersections(po, tw, ss, ids); want = ref.force_all_elastic_intersections(po, tw, ss, ids)
         ok = np.array_equal(got[2], want[2]) and close(got[0], want[0], 1e-8)
