@@ -11,6 +11,10 @@
 //   pfc_dual.h     the same path on (value, partial) numbers: k_dual_flags / k_dual_select (the pairs a chunk's seeds
 //                  touch), k_narrow_dual, k_dual_poly, k_dual_eig, k_dual_final
 //   pfc_br.h       k_shift, k_eig (6x6 Jacobi, one wave per item), k_final (+ result packing), k_scatter, k_selftest
+//   option "fixed_order" (bit-reproducible evaluations): k_integ_fixed / k_fric_fixed (pfc_np.h), k_shift_fixed (pfc_br.h),
+//                  k_fixed_reduce (pfc_dual.h), the FixedSink record lists of accumulate_items / dual_accumulate, and
+//                  pfc_sort.hip (a translation unit of its own: rocPRIM radix sort of the candidate list)
+//   pfc_multi.h    host code: multi-device handles (pfc_create_multi)
 // This file: mesh record preparation (k_prep_tri, k_prep_tet), per-item setup (k_setup_items), work-list management,
 // hipGraph capture / replay, the two-half evaluation and every extern "C" entry point.
 #include "pfc_kernels.h"
