@@ -296,6 +296,7 @@ def main():
     ap.add_argument("--friction", choices=["bristle", "regularized"], default="bristle",
                     help="friction model of the C3 instruction (BASELINE: bristle; regularized is an experiment knob)")
     ap.add_argument("--split-min", type=int, default=-1, help="library option split_min (-1: library default 1025; 0: never split)")
+    ap.add_argument("--fixed-order", action="store_true", help="library option fixed_order (bit-reproducible evaluations): what the option costs at bench scale")
     ap.add_argument("--clip-min", type=int, default=-1, help="library option clip_min (-1: library default 384; 0: one-kernel narrowphase)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option for A/B runs (pfc_set_option), e.g. --opt clip_dense=0")
     ap.add_argument("--bfs-levels", type=int, default=-1, help="broadphase BFS levels before the DFS kernel (-1 = auto)")
@@ -390,6 +391,8 @@ def main():
         m.set_option("bfs_levels", args.bfs_levels)
     if args.split_min >= 0:
         m.set_option("split_min", args.split_min)
+    if args.fixed_order:
+        m.set_option("fixed_order", 1)
     if args.clip_min >= 0:
         m.set_option("clip_min", args.clip_min)
     for kv in args.opt:

@@ -360,9 +360,9 @@ __device__ __forceinline__ void dual_accumulate(double *buf, double *acc, int ke
     int slot0 = 0;
     bool room = true;
     if constexpr (FX) {      // one record per direction of the wave's item (see accumulate_items)
-        if (lane == 0) slot0 = atomicAdd(fx->count, n_dir);
-        slot0 = __builtin_amdgcn_readfirstlane(slot0);
-        room = slot0 + n_dir <= fx->cap;      // (no room: see accumulate_items)
+        // the wave's item in its n_dir directions: the direct slots of the wave's position (per_pos = n_dir) -- no counter
+        slot0 = fx->direct_base + order * n_dir;
+        room = order < fx->n_pos && fx->per_pos == n_dir;
     }
     wave_lds_sync();      // (the buffer may be the polygon ring the lanes have just read)
 #pragma unroll
@@ -857,8 +857,7 @@ __global__ void __launch_bounds__(64) k_fixed_reduce(FixedSink fx, int n_keys, d
     if (key >= n_keys) return;
     const int head = fx.head[key];
     if (head < 0) return;
-    int n_rec = *fx.count;
-    if (n_rec > fx.cap) n_rec = fx.cap;
+    const int n_rec = fx.cap;
     int n = 0;
     if (lane == 0) {
         for (int s = head; s >= 0 && s < n_rec && n < kSinkSpan; ++n) {

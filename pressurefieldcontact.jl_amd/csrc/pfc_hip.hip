@@ -478,6 +478,8 @@ hipError_t copy_sync(pfc_context *h, void *dst, const void *src, size_t bytes, h
     return hipStreamSynchronize(h->stream);
 }
 
+size_t fixed_fric_cap(size_t ccap, int n_items) { return 2 * (ccap / 64 + 1) + (size_t)n_items + 64; }      // (FixedSink of k_fric_fixed)
+
 hipError_t ensure_work(pfc_context *h, int n_items) {
     hipError_t e;
     const size_t caps0[] = {h->items.cap, h->acc.cap, h->res.cap, h->icnt.cap, h->ctr.cap, h->frontier[0].cap,
@@ -513,7 +515,7 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
     if ((e = h->rec.ensure(rc * (h->opt_fixed_order ? kRecStrideFixed : kRecStride))) != hipSuccess) return e;
     if (h->opt_fixed_order) {
         if ((e = h->det.ensure((size_t)n_items * 3)) != hipSuccess) return e;
-        if ((e = h->vfx_rec.ensure((c / 32 + (size_t)n_items + 64) * kSinkStride)) != hipSuccess) return e;
+        if ((e = h->vfx_rec.ensure(fixed_fric_cap(c, n_items) * kSinkStride)) != hipSuccess) return e;
         if ((e = h->vfx_head.ensure((size_t)n_items + 2)) != hipSuccess) return e;
         if ((e = h->sort_keys[0].ensure(c)) != hipSuccess) return e;
         if ((e = h->sort_keys[1].ensure(c)) != hipSuccess) return e;
@@ -782,14 +784,14 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         fr.chunk_switch = kNpChunkSwitch; fr.pcnt = h->pcnt.p;
         fr.pcap = np.pcap; fr.res = h->res.p; fr.acc = h->acc.p;
         fr.n_items = n_items; fr.status = h->status.p;
-        fr.sink = FixedSink{nullptr, nullptr, nullptr, 0, nullptr};
+        fr.sink = FixedSink{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr};
         if (h->opt_fixed_order && np_mode == 2) {
-            // records of the friction sums: one per (64-polygon piece, item) incidence -- fewer than pieces + items, and the pieces
-            // of the chunks are fewer than ccap / 64 + chunks
-            const size_t cap = h->ccap / 32 + (size_t)n_items + 64;      // (allocated by ensure_work)
+            // records of the friction sums: two direct slots per 64-polygon piece (a piece of a batch holds one item, two at a boundary),
+            // an overflow area for the pieces of piles that hold more -- at most one further record per item
+            const size_t n_pos = h->ccap / 64 + 1, cap = fixed_fric_cap(h->ccap, n_items);      // (allocated by ensure_work)
             HIP_TRY(h, hipMemsetAsync(h->vfx_head.p, 0xFF, sizeof(int) * (size_t)n_items, st));
             HIP_TRY(h, hipMemsetAsync(h->vfx_head.p + n_items, 0, sizeof(int) * 2, st));
-            fr.sink = FixedSink{h->vfx_rec.p, h->vfx_head.p + n_items, h->vfx_head.p, (int)cap, h->status.p};
+            fr.sink = FixedSink{h->vfx_rec.p, h->vfx_head.p + n_items, h->vfx_head.p, 0, 2, (int)n_pos, (int)(2 * n_pos), (int)cap, h->status.p};
         }
         // (grid cap 256 x 32, twice the other narrowphase kernels': paired A/B 4.32 -> 4.22 ms per 8 192-pose step; x 64 and x 128 alike)
         if (fr.sink.rec) {
@@ -1945,7 +1947,7 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     static const bool no_stored_v = std::getenv("PFC_NO_DUAL_STORED_V") != nullptr;
     a.stored_v = no_stored_v ? 0 : 1;
     const bool fx = h->opt_fixed_order && !pair_count;
-    a.sink_a = FixedSink{nullptr, nullptr, nullptr, 0, nullptr};
+    a.sink_a = FixedSink{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr};
     a.sink_b = a.sink_a; a.sink_c = a.sink_a;
     if (fx) {
         // the contributing pairs in candidate order (k_integ_fixed appended them piece by piece as its workgroups came by) ...
@@ -1957,15 +1959,18 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
         // ... and the records of passes A and B: per accumulator block at most one per (wave, item, direction), and since an item's
         // pairs are consecutive in the sorted list the (wave, item) incidences are fewer than waves + items
         const size_t n_grp = (n_pairs_bound + cpw - 1) / cpw;
-        const size_t cap = 3 * (size_t)n_dir * (n_grp + (size_t)n_items) + 64;      // (three blocks: passes A, B, C)
+        // Three blocks (passes A, B, C), each with n_dir direct slots per wave position and a shared overflow area for the waves that
+        // straddle items: (items - 1) n_dir records at most per block.
+        const size_t n_pos = n_grp + 1, direct = n_pos * (size_t)n_dir;
+        const size_t cap = 3 * direct + 3 * (size_t)n_dir * (size_t)n_items + 64;
         if (cap > ((size_t)1 << 30)) return fail(h, PFC_ERR_NOMEM, "option fixed_order: %zu Dual sum records: evaluate the batch in parts", cap);
         HIP_TRY(h, ensure_dual(h, h->fx_rec, cap * kSinkStride));
         HIP_TRY(h, ensure_dual(h, h->fx_head, 3 * nk + 2));
         HIP_TRY(h, hipMemsetAsync(h->fx_head.p, 0xFF, sizeof(int) * 3 * nk, st));
         HIP_TRY(h, hipMemsetAsync(h->fx_head.p + 3 * nk, 0, sizeof(int) * 2, st));
-        a.sink_a = FixedSink{h->fx_rec.p, h->fx_head.p + 3 * nk, h->fx_head.p, (int)cap, a.status};
-        a.sink_b = FixedSink{h->fx_rec.p, h->fx_head.p + 3 * nk, h->fx_head.p + nk, (int)cap, a.status};
-        a.sink_c = FixedSink{h->fx_rec.p, h->fx_head.p + 3 * nk, h->fx_head.p + 2 * nk, (int)cap, a.status};
+        a.sink_a = FixedSink{h->fx_rec.p, h->fx_head.p + 3 * nk, h->fx_head.p, 0, n_dir, (int)n_pos, (int)(3 * direct), (int)cap, a.status};
+        a.sink_b = FixedSink{h->fx_rec.p, h->fx_head.p + 3 * nk, h->fx_head.p + nk, (int)direct, n_dir, (int)n_pos, (int)(3 * direct), (int)cap, a.status};
+        a.sink_c = FixedSink{h->fx_rec.p, h->fx_head.p + 3 * nk, h->fx_head.p + 2 * nk, (int)(2 * direct), n_dir, (int)n_pos, (int)(3 * direct), (int)cap, a.status};
         if (!tt) a.vres = h->res.p;      // tri-tet: always the folded pass (one kernel carries both blocks)
     }
     if (fx) {

@@ -110,11 +110,15 @@ __device__ __forceinline__ int wave_total_i(int v, int lane) {
 // -- key, the wave's position in the pass, the key's previous record, N values -- and k_fixed_reduce adds a key's records in the
 // order of their positions (pfc_dual.h).
 constexpr int kSinkHdr = 4, kSinkStride = 48;      // [0] key [1] position [2] previous record of the key [3] -; then up to 44 values
+// Where a record goes: the first per_pos runs of the wave at position p of the pass (its 64-polygon piece / its group of pairs) have
+// slots of their own, direct_base + p per_pos + k -- no counter; further runs (a wave that straddles several items) take slots
+// behind ovf_base from ONE returning atomic per wave.  (A counter for every record took an atomic from each of the 125 000 pieces
+// of a bench step on one address: 1 ms of k_fric_fixed.)
 struct FixedSink {
     double *rec;
-    int *count;          // records handed out (may exceed cap: the excess is dropped and reported)
+    int *count;          // overflow records handed out (beyond the capacity: dropped)
     int *head;           // per key: its last record, -1: none
-    int cap;
+    int direct_base, per_pos, n_pos, ovf_base, cap;
     unsigned *status;
 };
 template <int N, bool FX = false>
@@ -124,12 +128,32 @@ __device__ __forceinline__ void accumulate_items(double *acc, int item, bool lis
     // polygons do not chop an item's run into pieces); any: the lane has a contribution
     static_assert(N <= 64, "one value per lane");
     if (__ballot(any) == 0) return;
+    if constexpr (FX) {
+        // A lane without a list entry (a slot marker, a polygon that is not for this pass) takes the key of the nearest listed lane
+        // below it, so that it does not chop that key's run in two: one record per (wave, key), and the bound of the record list --
+        // distinct keys per wave summed over the waves -- holds.  (Such a lane contributes nothing: any is false for it.)
+        const unsigned long long lm = __ballot(listed);
+        const int ln = lane_id();
+        const unsigned long long below = lm & (ln == 63 ? ~0ull : ((2ull << ln) - 1ull));
+        const int src = below ? 63 - __builtin_clzll(below) : ln;
+        const int filled = __shfl(item, src, 64);
+        item = below ? filled : -1;
+        listed = below != 0;
+    }
     const Seg sg = seg_setup(listed ? item : -1);
     double tot[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) tot[k] = seg_sum(any ? v[k] : 0.0, sg);
     unsigned long long tails = __ballot(sg.tail && sg.valid);
     const int lane = lane_id();
+    int fx_k = 0, fx_ovf = 0;
+    if constexpr (FX) {
+        const int n_ovf = __popcll(tails) - fx->per_pos;
+        if (n_ovf > 0) {
+            if (lane == 0) fx_ovf = atomicAdd(fx->count, n_ovf);
+            fx_ovf = __builtin_amdgcn_readfirstlane(fx_ovf);
+        }
+    }
     while (tails) {
         const int t = __builtin_ctzll(tails);
         tails &= tails - 1;
@@ -142,11 +166,12 @@ __device__ __forceinline__ void accumulate_items(double *acc, int item, bool lis
         }
         if constexpr (FX) {
             static_assert(N <= kSinkStride - kSinkHdr, "a record holds the run's values");
-            // (a run whose totals are all zero -- lanes that hold a list entry and contribute nothing -- adds nothing, as with the atomics)
+            // (a run whose totals are all zero -- lanes that hold a list entry and contribute nothing -- adds nothing, as with the
+            // atomics: its slot stays unlinked, k_fixed_reduce never sees it)
+            const int k = fx_k++;
+            int slot = k < fx->per_pos ? (order < fx->n_pos ? fx->direct_base + order * fx->per_pos + k : fx->cap)
+                                       : fx->ovf_base + fx_ovf + (k - fx->per_pos);
             if (__ballot(lane < N && mine != 0.0) == 0) continue;
-            int slot = 0;
-            if (lane == 0) slot = atomicAdd(fx->count, 1);
-            slot = __builtin_amdgcn_readfirstlane(slot);
             if (slot < fx->cap) {
                 double *r = fx->rec + (size_t)slot * kSinkStride;
                 if (lane < N) r[kSinkHdr + lane] = mine;
@@ -1461,7 +1486,7 @@ __device__ __forceinline__ void fric_body(const FricArgs &g) {
                     contributed = true;
             }
         }
-        accumulate_items<6, FX>(g.acc, item, active, contributed, sum, kAccFric, kAccStride, &g.sink, ch * 8 + (p0 >> 6));
+        accumulate_items<6, FX>(g.acc, item, FX ? (active && (pk >> 28) >= 3u) : active, contributed, sum, kAccFric, kAccStride, &g.sink, (ch * C + p0) >> 6);
       }
     }
 }
