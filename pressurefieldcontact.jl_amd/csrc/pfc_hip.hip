@@ -390,6 +390,11 @@ struct pfc_context {
     DevBuf<int> vfx_head;
     DevBuf<int> fx_head;                      // per key and accumulator block: last record; then the record counter
     long long surv_sorted_serial = -1;        // value pass whose list of contributing pairs has been sorted
+    // Slots of the candidate list the sort covers: its capacity for the first evaluation and whenever the list turned out longer
+    // than covered (the evaluation is then re-issued), else a power of two above twice the previous evaluation's candidates -- a
+    // reference-sized scene sorts 1 024 keys in one launch instead of 65 536 in fifteen.
+    size_t sort_cover = 0;                    // 0: the capacity
+    size_t sort_cover_used = 0;               // what the pending evaluation covered
     int opt_clip_queue = 1;            // option "clip_queue": clip-only narrowphase of big tri-tet batches in k_clip_queue (survivors queued in the ring); 0: k_narrow<.., 2 / 3>
     int fused_skip = 0;                // evaluations left for which the fused kernel stays off after an item did not fit
     int fused_seq = 0;                 // sequence number of the last fused launch (completion word of the polled path)
@@ -709,8 +714,11 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         const int bits = pfc_sort_key_bits(n_items, h->max_elem1, h->max_elem2, &ba, &bb);
         if (bits > 64)
             return fail(h, PFC_ERR_BAD_ARG, "option fixed_order: (item, element, element) needs %d key bits for %d items, more than 64", bits, n_items);
-        HIP_TRY(h, pfc_sort_candidates(h->cand.p, ccount, h->ccap, h->sort_keys[0].p, h->sort_keys[1].p, h->sort_tmp.p, h->sort_tmp.cap,
-                                       n_items, ba, bb, bits, st));
+        size_t cover = h->sort_cover ? h->sort_cover : h->ccap;
+        if (cover > h->ccap) cover = h->ccap;
+        h->sort_cover_used = cover;
+        HIP_TRY(h, pfc_sort_candidates(h->cand.p, ccount, cover, h->sort_keys[0].p, h->sort_keys[1].p, h->sort_tmp.p, h->sort_tmp.cap,
+                                       n_items, ba, bb, bits, h->status.p, kStFixedCover, st));
         hipLaunchKernelGGL(k_fixed_init, dim3(grid_for(n_items, 256, 1 << 20)), dim3(256), 0, st, n_items, h->det.p);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));
@@ -822,13 +830,19 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
     if (prof && !h->ev[0])
         for (int k = 0; k < EV_COUNT; ++k) HIP_TRY(h, hipEventCreate(&h->ev[k]));
     const int L = bfs_levels_for(h, n_items, levels);
-    bool use_graph = h->opt_graph && !prof && !h->opt_fixed_order;      // (fixed_order: the sort is library code, launched eagerly)
+    bool use_graph = h->opt_graph && !prof;
 #ifdef PFC_STAMPS
     use_graph = false;
 #endif
     if (use_graph) {
         pfc_context::GraphKey key = {};
         key.n_items = n_items; key.levels = levels; key.L = L; key.debug = (h->opt_debug ? 1 : 0) | (h->in_split ? 2 : 0) | (bp_block_for(h, n_items) << 4);
+        if (h->opt_fixed_order) {      // (the sort's launches depend on the slots it covers: 2^k, k in the key)
+            size_t cover = h->sort_cover ? h->sort_cover : h->ccap;
+            int lg = 0;
+            while (((size_t)1 << lg) < cover && lg < 40) ++lg;
+            key.debug |= (lg + 1) << 16;
+        }
         key.bristle = (h->any_bristle ? 1 : 0) | (h->any_tet_tet ? 2 : 0);
         key.surv = h->want_surv ? 1 : 0;
         key.p[0] = d_ins_ids; key.p[1] = d_pose; key.p[2] = d_twist; key.p[3] = d_s; key.p[4] = d_wrench;
@@ -903,6 +917,17 @@ int check_one(pfc_context *h) {
     }
     if (status & kStAbort) return fail(h, PFC_ERR_STATE, "broadphase aborted: iteration guard hit (corrupt tree?)");
     if (status & kStPolyOvf) return fail(h, PFC_ERR_STATE, "internal error: a kept-polygon region overflowed");
+    if (h->opt_fixed_order) {
+        if (status & kStFixedCover) {      // more candidates than the sort covered: cover the whole list and evaluate again
+            h->sort_cover = 0;
+            h->ghave[0] = h->ghave[1] = false;
+            return fail(h, PFC_ERR_OVERFLOW, "option fixed_order: the candidate list outgrew the part the sort covered (%zu slots): re-issue", h->sort_cover_used);
+        }
+        size_t want = 1024;
+        while (want < 2 * (size_t)ctr[0] + 1024) want *= 2;
+        if (want >= h->ccap) want = 0;
+        if (want != h->sort_cover && (want == 0 || h->sort_cover == 0 || want > h->sort_cover || 4 * want <= h->sort_cover)) h->sort_cover = want;
+    }
     if (status & (kStFixedSpan | kStFixedList))
         return fail(h, PFC_ERR_STATE, "option fixed_order: the candidates of one item span more than %d chunks of 512, or one key has more than %d sum records (status %u): evaluate it without the option",
                     kFixedSpan, kSinkSpan, status);
@@ -1952,7 +1977,9 @@ int launch_dual(pfc_context *h, int n_items, int n_dir, const int *tail, const d
     if (fx) {
         // the contributing pairs in candidate order (k_integ_fixed appended them piece by piece as its workgroups came by) ...
         if (h->surv_sorted_serial != h->value_serial) {
-            HIP_TRY(h, pfc_sort_indices(h->surv.p, a.scount, h->ccap, reinterpret_cast<unsigned *>(h->sort_keys[0].p),
+            // (as many slots as the candidate sort covered: the contributing pairs are a subset of the candidates)
+            HIP_TRY(h, pfc_sort_indices(h->surv.p, a.scount, (h->sort_cover_used && h->sort_cover_used < h->ccap) ? h->sort_cover_used : h->ccap,
+                                        reinterpret_cast<unsigned *>(h->sort_keys[0].p),
                                         reinterpret_cast<unsigned *>(h->sort_keys[1].p), h->sort_tmp.p, h->sort_tmp.cap, st));
             h->surv_sorted_serial = h->value_serial;
         }

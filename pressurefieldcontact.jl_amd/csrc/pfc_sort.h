@@ -7,8 +7,10 @@
 int pfc_sort_key_bits(int n_items, int max_elem_1, int max_elem_2, int *bits_a, int *bits_b);
 hipError_t pfc_sort_temp_bytes(size_t cap, int bits, size_t *bytes);
 // Sorts cand[0 .. min(*ccount, cap)) -- 16-byte records (item, a, b, 0) -- by key, on stream st; keys_in / keys_out: cap words each.
+// cap may be less than the list's capacity (the slots the caller expects to be in use): *ccount > cap sets cover_bit in *status.
 hipError_t pfc_sort_candidates(void *cand, const int *ccount, size_t cap, unsigned long long *keys_in, unsigned long long *keys_out,
-                               void *temp, size_t temp_bytes, int n_items, int bits_a, int bits_b, int bits, hipStream_t st);
+                               void *temp, size_t temp_bytes, int n_items, int bits_a, int bits_b, int bits, unsigned *status,
+                               unsigned cover_bit, hipStream_t st);
 // Sorts the non-negative indices list[0 .. min(*count, cap)) ascending (negative entries go last), on stream st; keys_in / keys_out:
 // cap 32-bit words each.  The temporary storage of pfc_sort_temp_bytes for the same cap is large enough.
 hipError_t pfc_sort_indices(int *list, const int *count, size_t cap, unsigned *keys_in, unsigned *keys_out, void *temp, size_t temp_bytes,

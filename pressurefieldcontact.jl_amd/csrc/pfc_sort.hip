@@ -19,9 +19,12 @@ namespace {
 struct alignas(16) Rec16 { int item, a, b, pad; };      // = pfc::WorkRec (pfc_kernels.h)
 
 __global__ void __launch_bounds__(256) k_sort_pack(const Rec16 *cand, const int *ccount, size_t cap, unsigned long long *keys,
-                                                   int n_items, int bits_a, int bits_b) {
+                                                   int n_items, int bits_a, int bits_b, unsigned *status, unsigned cover_bit) {
     size_t n_c = (size_t)(*ccount < 0 ? 0 : *ccount);
-    if (n_c > cap) n_c = cap;
+    if (n_c > cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && status) atomicOr(status, cover_bit);
+        n_c = cap;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (size_t)gridDim.x * blockDim.x) {
         unsigned long long k;
         if (i < n_c) {
@@ -98,12 +101,13 @@ hipError_t pfc_sort_indices(int *list, const int *count, size_t cap, unsigned *k
 }
 
 hipError_t pfc_sort_candidates(void *cand, const int *ccount, size_t cap, unsigned long long *keys_in, unsigned long long *keys_out,
-                               void *temp, size_t temp_bytes, int n_items, int bits_a, int bits_b, int bits, hipStream_t st) {
+                               void *temp, size_t temp_bytes, int n_items, int bits_a, int bits_b, int bits, unsigned *status,
+                               unsigned cover_bit, hipStream_t st) {
     if (cap == 0) return hipSuccess;
     size_t g = (cap + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
     hipLaunchKernelGGL(k_sort_pack, dim3((unsigned)g), dim3(256), 0, st, (const Rec16 *)cand, ccount, cap, keys_in, n_items, bits_a,
-                       bits_b);
+                       bits_b, status, cover_bit);
     hipError_t e = rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, cap, 0u, (unsigned)bits, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_sort_unpack, dim3((unsigned)g), dim3(256), 0, st, (Rec16 *)cand, ccount, cap, keys_out, bits_a, bits_b);

@@ -102,7 +102,7 @@ def test_fixed_order_dual_against_the_dual_oracle(pfc, O, cfg):
 
 
 def test_fixed_order_goes_off_again(pfc):
-    """The option means the batched path (no one-launch kernel, no split, eager launches) whatever the other path options say -- also
+    """The option means the batched path (no one-launch kernel, no split) whatever the other path options say -- also
     when they are set while it is on -- and a small scene is evaluated by the one-launch kernel again once it is cleared."""
     w = pfc.configs.c1_boxes()
     m = pfc.configs.build_scenario(w)
@@ -169,4 +169,25 @@ def test_fixed_order_growth_errors_and_poisoned_lists(pfc):
     for k, r in zip([0, 150, 299], ref):
         assert np.array_equal(first[2][k], r.counts)
         assert H.rel_err(first[0][k], r.wrench) < 1e-9
+    m.close()
+
+
+def test_fixed_order_sort_follows_the_list_length(pfc):
+    """The sort covers a power of two above twice the previous evaluation's candidates, not the list's capacity (a reference-sized
+    scene sorts 1 024 keys in one launch): a handle that has seen two items and is then given three hundred must notice that the
+    list outgrew the covered part, evaluate again over the whole list, and return the bits a fresh handle returns -- and the other
+    way round."""
+    w = pfc.configs.c3_blob_tool(300, n_div_blob=8, n_div_tool=6)
+    fresh = {}
+    for n in (2, 300):
+        f = pfc.configs.build_scenario(w)
+        f.set_option("fixed_order", 1)
+        fresh[n] = f.force_all_elastic_intersections(w.pose[:n], w.twist[:n], w.s[:n], w.ins_ids[:n])
+        f.close()
+    m = pfc.configs.build_scenario(w)
+    m.set_option("fixed_order", 1)
+    for n in (2, 2, 300, 300, 2, 2, 300):
+        got = m.force_all_elastic_intersections(w.pose[:n], w.twist[:n], w.s[:n], w.ins_ids[:n])
+        for x, y in zip(got, fresh[n]):
+            assert np.array_equal(x, y), n
     m.close()
