@@ -293,7 +293,7 @@ int pfc_scatter_generalized_device(pfc_handle h, int n_items, const double *d_wr
  * way return the same bit patterns in wrench, sdot, every partial and every counter.  Batched path only while the option is on, whatever "fused", "team"
  * and "split_min" say (no one-launch kernel, no two-half split: a reference-sized scene costs 100 - 180 us instead of 35 - 90);
  * with "debug" the value pass's sums are the debug kernel's atomics again; costs a
- * radix sort of the candidate list's capacity per evaluation (BASELINE config 5: 0.29 -> 0.48 ms, an 8 192-pose batch 3.9 -> 5.5 ms).  Needs
+ * radix sort of the candidate list's capacity per evaluation (BASELINE config 5: 0.29 -> 0.48 ms, an 8 192-pose batch 3.9 -> 5.4 ms).  Needs
  * log2(items) + log2(elements of mesh_1) + log2(tets of mesh_2) <= 64 (PFC_ERR_BAD_ARG otherwise) and at most 4 096 x 512
  * candidates per item (PFC_ERR_STATE)). */
 int pfc_set_option(pfc_handle h, const char *name, long long value);
