@@ -382,6 +382,9 @@ struct pfc_context {
     int opt_fixed_order = 0;
     DevBuf<int> det;                          // per item: last record, first chunk, last chunk
     DevBuf<unsigned long long> sort_keys[2];
+    DevBuf<int> canon_off, canon_fill, canon_item;      // segments of the candidate list by item (pfc_canon_candidates)
+    int sort_tmp_items = 0;
+    bool fixed_whole_list = false;            // an item had more candidates than a segment sort takes: the whole list is sorted from then on
     DevBuf<char> sort_tmp;
     size_t sort_tmp_for = 0;                  // (capacity, bits) the temporary storage was sized for
     int sort_tmp_bits = 0;
@@ -526,11 +529,14 @@ hipError_t ensure_work(pfc_context *h, int n_items) {
         if ((e = h->sort_keys[1].ensure(c)) != hipSuccess) return e;
         int ba, bb;
         const int bits = pfc_sort_key_bits(n_items, h->max_elem1, h->max_elem2, &ba, &bb);
-        if (h->sort_tmp_for != c || h->sort_tmp_bits != bits) {
+        if ((e = h->canon_off.ensure((size_t)n_items + 1)) != hipSuccess) return e;
+        if ((e = h->canon_fill.ensure((size_t)n_items)) != hipSuccess) return e;
+        if ((e = h->canon_item.ensure(c)) != hipSuccess) return e;
+        if (h->sort_tmp_for != c || h->sort_tmp_bits != bits || h->sort_tmp_items < n_items) {
             size_t bytes = 0;
             if ((e = pfc_sort_temp_bytes(c, bits > 64 ? 64 : bits, &bytes)) != hipSuccess) return e;      // (covers the index sort too)
             if ((e = h->sort_tmp.ensure(bytes ? bytes : 1)) != hipSuccess) return e;
-            h->sort_tmp_for = c; h->sort_tmp_bits = bits;
+            h->sort_tmp_for = c; h->sort_tmp_bits = bits; h->sort_tmp_items = n_items;
         }
     }
     if ((e = h->frontier[0].ensure(f)) != hipSuccess) return e;
@@ -717,8 +723,15 @@ int record_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double 
         size_t cover = h->sort_cover ? h->sort_cover : h->ccap;
         if (cover > h->ccap) cover = h->ccap;
         h->sort_cover_used = cover;
-        HIP_TRY(h, pfc_sort_candidates(h->cand.p, ccount, cover, h->sort_keys[0].p, h->sort_keys[1].p, h->sort_tmp.p, h->sort_tmp.cap,
-                                       n_items, ba, bb, bits, h->status.p, kStFixedCover, st));
+        // by segments (the per-item counts of the broadphase give the offsets; only the segments are sorted), or -- A/B,
+        // PFC_FIXED_GLOBAL_SORT=1 -- by one sort of the covered part of the list: the same order either way
+        static const bool global_sort = std::getenv("PFC_FIXED_GLOBAL_SORT") != nullptr;
+        if (global_sort || h->fixed_whole_list)
+            HIP_TRY(h, pfc_sort_candidates(h->cand.p, ccount, cover, h->sort_keys[0].p, h->sort_keys[1].p, h->sort_tmp.p, h->sort_tmp.cap,
+                                           n_items, ba, bb, bits, h->status.p, kStFixedCover, st));
+        else
+            HIP_TRY(h, pfc_canon_candidates(h->cand.p, ccount, cover, h->icnt.p, n_items, h->sort_keys[0].p, h->sort_keys[1].p, h->canon_off.p,
+                                            h->canon_fill.p, h->canon_item.p, bb, h->status.p, kStFixedCover, kStFixedBig, st));
         hipLaunchKernelGGL(k_fixed_init, dim3(grid_for(n_items, 256, 1 << 20)), dim3(256), 0, st, n_items, h->det.p);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[EV_BP], st));
@@ -841,7 +854,7 @@ int enqueue_eval(pfc_context *h, int n_items, const int *d_ins_ids, const double
             size_t cover = h->sort_cover ? h->sort_cover : h->ccap;
             int lg = 0;
             while (((size_t)1 << lg) < cover && lg < 40) ++lg;
-            key.debug |= (lg + 1) << 16;
+            key.debug |= ((lg + 1) << 16) | (h->fixed_whole_list ? 1 << 24 : 0);
         }
         key.bristle = (h->any_bristle ? 1 : 0) | (h->any_tet_tet ? 2 : 0);
         key.surv = h->want_surv ? 1 : 0;
@@ -918,6 +931,11 @@ int check_one(pfc_context *h) {
     if (status & kStAbort) return fail(h, PFC_ERR_STATE, "broadphase aborted: iteration guard hit (corrupt tree?)");
     if (status & kStPolyOvf) return fail(h, PFC_ERR_STATE, "internal error: a kept-polygon region overflowed");
     if (h->opt_fixed_order) {
+        if (status & kStFixedBig) {      // an item with more candidates than the segment sort takes: sort the whole list, evaluate again
+            h->fixed_whole_list = true;
+            h->ghave[0] = h->ghave[1] = false;
+            return fail(h, PFC_ERR_OVERFLOW, "option fixed_order: an item has more than 4096 candidates: the whole list is sorted from now on, re-issue");
+        }
         if (status & kStFixedCover) {      // more candidates than the sort covered: cover the whole list and evaluate again
             h->sort_cover = 0;
             h->ghave[0] = h->ghave[1] = false;
@@ -1331,6 +1349,7 @@ void pfc_destroy(pfc_handle h) {
     h->items.release(); h->frontier[0].release(); h->frontier[1].release(); h->cand.release();
     h->clip_n.release(); h->icnt.release(); h->trac_item.release(); h->acc.release(); h->res.release();
     h->fx_rec.release(); h->fx_head.release(); h->vfx_rec.release(); h->vfx_head.release();
+    h->canon_off.release(); h->canon_fill.release(); h->canon_item.release();
     h->det.release(); h->sort_keys[0].release(); h->sort_keys[1].release(); h->sort_tmp.release();
     h->trac_d.release(); h->rec.release(); h->ctr.release(); h->status.release(); h->stamps.release();
     h->h_pose.release();

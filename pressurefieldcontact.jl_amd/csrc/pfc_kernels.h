@@ -26,6 +26,7 @@ enum : unsigned {
     // (512, 1024: the one-launch kernel's own bits, pfc_fused.h)
     kStFixedSpan = 2048u,   // option "fixed_order": the candidates of one item span more chunks than k_shift_fixed's table holds
     kStFixedCover = 8192u,  // option "fixed_order": more candidates than the slots the sort was asked to cover
+    kStFixedBig = 16384u,   // option "fixed_order": an item with more candidates than the per-item segment sort takes
     kStFixedList = 4096u,   // option "fixed_order": a key has more sum records than k_fixed_reduce orders at a time
 };
 

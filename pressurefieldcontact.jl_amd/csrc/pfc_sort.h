@@ -15,3 +15,9 @@ hipError_t pfc_sort_candidates(void *cand, const int *ccount, size_t cap, unsign
 // cap 32-bit words each.  The temporary storage of pfc_sort_temp_bytes for the same cap is large enough.
 hipError_t pfc_sort_indices(int *list, const int *count, size_t cap, unsigned *keys_in, unsigned *keys_out, void *temp, size_t temp_bytes,
                             hipStream_t st);
+// The same order by segments: offsets from the per-item candidate counts icnt[4 i + 1] (off: n_items + 1 ints), every candidate
+// dropped into its item's segment (fill: n_items ints, item_of: cap ints), the segments sorted by (a, b) in LDS.  An item with more
+// than 4 096 candidates sets big_bit in *status (nothing is sorted then: the caller falls back to pfc_sort_candidates).
+hipError_t pfc_canon_candidates(void *cand, const int *ccount, size_t cap, const int *icnt, int n_items, unsigned long long *keys_in,
+                                unsigned long long *keys_out, int *off, int *fill, int *item_of, int bits_b, unsigned *status,
+                                unsigned cover_bit, unsigned big_bit, hipStream_t st);

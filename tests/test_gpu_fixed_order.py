@@ -191,3 +191,48 @@ def test_fixed_order_sort_follows_the_list_length(pfc):
         for x, y in zip(got, fresh[n]):
             assert np.array_equal(x, y), n
     m.close()
+
+
+def test_fixed_order_first_evaluation_on_dirty_memory(pfc):
+    """The first evaluation of a fresh handle overflows its minimal candidate list; the per-item counts then say more than the list
+    holds, and cutting the list into per-item segments by them would leave slots nobody writes -- whatever the freshly allocated
+    buffers held -- to be read as candidates.  Device memory is filled with a wild pattern first (fresh allocations are usually zero
+    pages, which hides this); the evaluation must come back clean and with the bits of a second handle."""
+    import torch
+    junk = [torch.full((2 ** 28,), 0x7F7F7F7F, dtype=torch.int32, device="cuda") for _ in range(4)]      # 4 GiB
+    torch.cuda.synchronize()
+    del junk
+    torch.cuda.empty_cache()
+    w = pfc.configs.c5_pile()
+    outs = []
+    for rep in range(2):
+        m = pfc.configs.build_scenario(w)
+        m.set_option("fixed_order", 1)
+        outs.append(m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids))
+        assert m.stats()["candidates"] > 65536      # (the list started smaller than that)
+        m.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+
+
+def test_fixed_order_item_with_more_candidates_than_a_segment_sort_takes(pfc):
+    """The candidate list is put in order per item (a bitonic network in LDS, up to 4 096 candidates); an item with more is reported,
+    the handle sorts the whole list from then on (rocPRIM) and the evaluation is re-issued: deep overlaps of the full-size C3 pair
+    (tens of thousands of candidates per item) against the oracle, two handles bit-equal, value and Dual."""
+    w = pfc.configs.c3_blob_tool(3, distance=0.12)
+    d6 = _seeds(w, 6, 5)
+    outs = []
+    for rep in range(2):
+        m = pfc.configs.build_scenario(w)
+        m.set_option("fixed_order", 1)
+        v = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        assert v[2][:, 1].max() > 4096
+        d = m.force_all_elastic_intersections_dual(w.pose, w.twist, w.s, *d6, w.ins_ids)
+        v2 = m.force_all_elastic_intersections(w.pose, w.twist, w.s, w.ins_ids)
+        outs.append(tuple(v) + tuple(d) + tuple(v2))
+        _check_vs_oracle(pfc, w, m, *v, tol=1e-9, oracle_debug=True)
+        m.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    for x, y in zip(outs[0][:3], outs[0][8:]):
+        assert np.array_equal(x, y)
